@@ -1,0 +1,966 @@
+// oracle/oracle.cpp -- TEST INFRASTRUCTURE.  CPU restatement of fredholm's path-tracing hot path,
+// used ONLY as the checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+// Nothing under fredholm_amd/ may call into this library.
+//
+// PARITY STATUS: "parity unpinned" except for the anchor values recorded in SURVEY.md 8(c)
+// (tests/test_oracle_anchors.py).  The reference needs the CUDA toolkit and the OptiX SDK
+// (/root/reference/CMakeLists.txt:2,20-31, fredholm/include/fredholm/shared.h:2-3), neither of
+// which exists in this image, so it is unbuildable here and no oracle/_ref is provided; the
+// reference ships no tests or golden vectors.
+//
+// What is restated (reference file:line):
+//   ray generation, Russian roulette, running-mean accumulate   fredholm/modules/pt.cu:418-502
+//   miss programs                                               pt.cu:504-543
+//   closest-hit radiance (surface, NEE x3 with MIS, light ray)  pt.cu:680-944, :141-179, :181-280
+//   closest-hit light                                           pt.cu:952-999
+//   sampler seeding                                             pt.cu:378-399
+//   self-intersection offset                                    pt.cu:402-416
+//   thin-lens camera                                            fredholm/modules/camera.cu:24-53
+//   Hosek-Wilkie sky (cook + radiance)                          fredholm/include/fredholm/arhosek.h:145-322,
+//                                                               fredholm/modules/arhosek.cu:103-127
+//   area-light list                                             fredholm/include/fredholm/renderer.h:388-402
+//   post-process chain                                          fredholm/kernels/src/post-process.cu:5-153,
+//                                                               fredholm/kernels/include/kernels/post-process.h:13-124
+// Third-party arithmetic not in the tree (OptiX BVH traversal + triangle test, CUDA tex2D) is
+// replaced by a binned-SAH BVH + the watertight test of Woop/Benthin/Wald 2013; closest hits are
+// made independent of BVH shape by breaking equal-t ties towards the lower face index.
+// Textures are not supported by the checker (all *_texture_id must be -1).
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "obsdf.h"
+
+namespace orc {
+
+const uint32_t* g_sobol_matrices = nullptr;
+const float* g_lut_reflection = nullptr;
+const float* g_lut_sheen = nullptr;
+static const float* g_hosek = nullptr;  // 3x1080 config + 3x120 radiance
+static std::vector<uint32_t> s_sobol;
+static std::vector<float> s_refl, s_sheen, s_hosek;
+
+// ----------------------------------------------------------------------------- scene
+struct Material {  // shared.h:100-142, 180 bytes
+  float diffuse; float base_color[3]; int base_color_tex; float diffuse_roughness;
+  float specular; float specular_color[3]; int specular_color_tex; float specular_roughness; int specular_roughness_tex;
+  float metalness; int metalness_tex; int metallic_roughness_tex;
+  float coat; int coat_tex; float coat_color[3]; float coat_roughness; int coat_roughness_tex;
+  float transmission; float transmission_color[3];
+  float sheen; float sheen_color[3]; float sheen_roughness;
+  float subsurface; float subsurface_color[3];
+  float thin_walled;
+  float emission; float emission_color[3]; int emission_tex;
+  int heightmap_tex, normalmap_tex, alpha_tex;
+};
+static_assert(sizeof(Material) == 180, "Material ABI");
+
+struct AreaLight { U3 idx; uint32_t material_id, instance_idx; };  // shared.h:149-153
+struct DirLight { V3 le, dir; float angle; };                       // shared.h:155-159
+struct HosekState { float cfg[3][9]; float rad[3]; };
+
+struct Camera { M34 xf; float fov, F, focus; };  // shared.h:59-64
+
+struct BvhNode { float lo[3]; uint32_t left_or_first; float hi[3]; uint32_t count; };  // count==0: inner, children left, left+1
+
+struct Scene {
+  std::vector<V3> verts, normals; std::vector<V2> uvs; std::vector<U3> faces;
+  std::vector<uint32_t> mat_ids, inst_ids; std::vector<Material> mats;
+  std::vector<M34> o2w, w2o; std::vector<AreaLight> lights;
+  // world-space triangles for intersection
+  std::vector<V3> wtri;  // 3 per face
+  std::vector<BvhNode> nodes; std::vector<uint32_t> order;
+  // environment
+  bool has_dir = false; DirLight dir{};
+  bool has_hosek = false; HosekState hosek{};
+  V3 sun_dir = {0, 1, 0}; float sky_intensity = 1.0f;
+};
+
+// ----------------------------------------------------------------------------- intersection
+struct Hit { float t, u, v; uint32_t prim; };
+struct RayPre { int kx, ky, kz; float Sx, Sy, Sz; };
+
+static inline float comp(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+static inline RayPre ray_prepare(V3 d)
+{
+  RayPre r;
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  r.kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+  r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0;
+  r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0;
+  if (comp(d, r.kz) < 0.0f) std::swap(r.kx, r.ky);
+  r.Sx = comp(d, r.kx) / comp(d, r.kz);
+  r.Sy = comp(d, r.ky) / comp(d, r.kz);
+  r.Sz = 1.0f / comp(d, r.kz);
+  return r;
+}
+
+// Watertight ray/triangle test.  Returns true and (t,u,v) for 0 <= t; u,v weight v1,v2.
+static inline bool tri_test(const RayPre& r, V3 org, V3 p0, V3 p1, V3 p2, float& t, float& bu, float& bv)
+{
+  const V3 A = p0 - org, B = p1 - org, C = p2 - org;
+  const float Akz = comp(A, r.kz), Bkz = comp(B, r.kz), Ckz = comp(C, r.kz);
+  const float Ax = fmaf(-r.Sx, Akz, comp(A, r.kx)), Ay = fmaf(-r.Sy, Akz, comp(A, r.ky));
+  const float Bx = fmaf(-r.Sx, Bkz, comp(B, r.kx)), By = fmaf(-r.Sy, Bkz, comp(B, r.ky));
+  const float Cx = fmaf(-r.Sx, Ckz, comp(C, r.kx)), Cy = fmaf(-r.Sy, Ckz, comp(C, r.ky));
+  float U = Cx * By - Cy * Bx;
+  float V = Ax * Cy - Ay * Cx;
+  float W = Bx * Ay - By * Ax;
+  if (U == 0.0f || V == 0.0f || W == 0.0f) {
+    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+  }
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+  const float det = U + V + W;
+  if (det == 0.0f) return false;
+  const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+  const float T = fmaf(W, Cz, fmaf(V, Bz, U * Az));
+  const float rcp = 1.0f / det;
+  t = T * rcp;
+  if (!(t >= 0.0f)) return false;
+  bu = V * rcp;
+  bv = W * rcp;
+  return true;
+}
+
+static void build_bvh(Scene& s)
+{
+  const uint32_t n = (uint32_t)s.faces.size();
+  s.order.resize(n);
+  std::vector<V3> lo(n), hi(n), cen(n);
+  float maxabs = 0.0f;
+  for (uint32_t i = 0; i < n; ++i) {
+    s.order[i] = i;
+    const V3 a = s.wtri[3 * i], b = s.wtri[3 * i + 1], c = s.wtri[3 * i + 2];
+    lo[i] = v3(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
+    hi[i] = v3(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
+    cen[i] = 0.5f * (lo[i] + hi[i]);
+    maxabs = fmaxf(maxabs, fmaxf(fmaxf(fabsf(lo[i].x), fabsf(lo[i].y)), fabsf(lo[i].z)));
+    maxabs = fmaxf(maxabs, fmaxf(fmaxf(fabsf(hi[i].x), fabsf(hi[i].y)), fabsf(hi[i].z)));
+  }
+  const float pad = fmaxf(maxabs, 1e-3f) * (1.0f / 65536.0f);  // the slab test must never cull what tri_test accepts
+  s.nodes.clear();
+  s.nodes.reserve(2 * (size_t)n + 2);
+  s.nodes.push_back({});
+  struct Job { uint32_t node, first, count; };
+  std::vector<Job> stack{{0, 0, n}};
+  while (!stack.empty()) {
+    const Job j = stack.back();
+    stack.pop_back();
+    V3 blo = v3(1e30f), bhi = v3(-1e30f), clo = v3(1e30f), chi = v3(-1e30f);
+    for (uint32_t i = j.first; i < j.first + j.count; ++i) {
+      const uint32_t p = s.order[i];
+      blo = v3(fminf(blo.x, lo[p].x), fminf(blo.y, lo[p].y), fminf(blo.z, lo[p].z));
+      bhi = v3(fmaxf(bhi.x, hi[p].x), fmaxf(bhi.y, hi[p].y), fmaxf(bhi.z, hi[p].z));
+      clo = v3(fminf(clo.x, cen[p].x), fminf(clo.y, cen[p].y), fminf(clo.z, cen[p].z));
+      chi = v3(fmaxf(chi.x, cen[p].x), fmaxf(chi.y, cen[p].y), fmaxf(chi.z, cen[p].z));
+    }
+    BvhNode nd;
+    nd.lo[0] = blo.x - pad; nd.lo[1] = blo.y - pad; nd.lo[2] = blo.z - pad;
+    nd.hi[0] = bhi.x + pad; nd.hi[1] = bhi.y + pad; nd.hi[2] = bhi.z + pad;
+    nd.left_or_first = j.first;
+    nd.count = j.count;
+    const V3 ext = chi - clo;
+    int axis = ext.x > ext.y ? (ext.x > ext.z ? 0 : 2) : (ext.y > ext.z ? 1 : 2);
+    const float aext = comp(ext, axis);
+    if (j.count <= 4 || !(aext > 0.0f)) { s.nodes[j.node] = nd; continue; }
+    // binned SAH on the longest centroid axis
+    constexpr int NB = 16;
+    struct Bin { V3 lo = v3(1e30f), hi = v3(-1e30f); uint32_t n = 0; } bins[NB];
+    const float cmin = comp(clo, axis), scale = NB / aext;
+    auto bin_of = [&](uint32_t p) { int b = (int)((comp(cen[p], axis) - cmin) * scale); return b < 0 ? 0 : (b >= NB ? NB - 1 : b); };
+    for (uint32_t i = j.first; i < j.first + j.count; ++i) {
+      const uint32_t p = s.order[i];
+      Bin& b = bins[bin_of(p)];
+      b.n++;
+      b.lo = v3(fminf(b.lo.x, lo[p].x), fminf(b.lo.y, lo[p].y), fminf(b.lo.z, lo[p].z));
+      b.hi = v3(fmaxf(b.hi.x, hi[p].x), fmaxf(b.hi.y, hi[p].y), fmaxf(b.hi.z, hi[p].z));
+    }
+    auto area = [](V3 l, V3 h) { const V3 e = h - l; return e.x * e.y + e.y * e.z + e.z * e.x; };
+    float rarea[NB]; uint32_t rcnt[NB];
+    {
+      V3 l = v3(1e30f), h = v3(-1e30f); uint32_t c = 0;
+      for (int b = NB - 1; b > 0; --b) {
+        if (bins[b].n) { l = v3(fminf(l.x, bins[b].lo.x), fminf(l.y, bins[b].lo.y), fminf(l.z, bins[b].lo.z)); h = v3(fmaxf(h.x, bins[b].hi.x), fmaxf(h.y, bins[b].hi.y), fmaxf(h.z, bins[b].hi.z)); }
+        c += bins[b].n;
+        rarea[b] = c ? area(l, h) : 0.0f;
+        rcnt[b] = c;
+      }
+    }
+    float best = 1e30f; int bsplit = -1;
+    {
+      V3 l = v3(1e30f), h = v3(-1e30f); uint32_t c = 0;
+      for (int b = 0; b < NB - 1; ++b) {
+        if (bins[b].n) { l = v3(fminf(l.x, bins[b].lo.x), fminf(l.y, bins[b].lo.y), fminf(l.z, bins[b].lo.z)); h = v3(fmaxf(h.x, bins[b].hi.x), fmaxf(h.y, bins[b].hi.y), fmaxf(h.z, bins[b].hi.z)); }
+        c += bins[b].n;
+        if (c == 0 || rcnt[b + 1] == 0) continue;
+        const float cost = area(l, h) * c + rarea[b + 1] * rcnt[b + 1];
+        if (cost < best) { best = cost; bsplit = b; }
+      }
+    }
+    uint32_t mid;
+    if (bsplit < 0) {
+      mid = j.first + j.count / 2;
+      std::nth_element(s.order.begin() + j.first, s.order.begin() + mid, s.order.begin() + j.first + j.count,
+                       [&](uint32_t a, uint32_t b) { return comp(cen[a], axis) < comp(cen[b], axis); });
+    } else {
+      auto it = std::partition(s.order.begin() + j.first, s.order.begin() + j.first + j.count, [&](uint32_t p) { return bin_of(p) <= bsplit; });
+      mid = (uint32_t)(it - s.order.begin());
+    }
+    const uint32_t left = (uint32_t)s.nodes.size();
+    s.nodes.push_back({});
+    s.nodes.push_back({});
+    nd.left_or_first = left;
+    nd.count = 0;
+    s.nodes[j.node] = nd;
+    stack.push_back({left, j.first, mid - j.first});
+    stack.push_back({left + 1, mid, j.first + j.count - mid});
+  }
+}
+
+static inline bool slab(const BvhNode& n, V3 o, V3 id, float tmax)
+{
+  float t0 = (n.lo[0] - o.x) * id.x, t1 = (n.hi[0] - o.x) * id.x;
+  float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+  t0 = (n.lo[1] - o.y) * id.y; t1 = (n.hi[1] - o.y) * id.y;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  t0 = (n.lo[2] - o.z) * id.z; t1 = (n.hi[2] - o.z) * id.z;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  tf *= 1.000001f;
+  return tn <= tf && tf >= 0.0f && tn <= tmax;
+}
+
+static inline V3 safe_inv(V3 d)
+{
+  auto f = [](float x) { return 1.0f / (fabsf(x) < 1e-20f ? copysignf(1e-20f, x) : x); };
+  return v3(f(d.x), f(d.y), f(d.z));
+}
+
+// closest hit in [0, tmax]; ties -> lowest face index.  any_hit: stop at the first accepted hit.
+static bool intersect(const Scene& s, V3 o, V3 d, float tmax, bool any_hit, Hit& best)
+{
+  best.t = tmax; best.prim = 0xffffffffu; best.u = best.v = 0;
+  if (s.nodes.empty()) return false;
+  const RayPre rp = ray_prepare(d);
+  const V3 id = safe_inv(d);
+  uint32_t stack[128]; int sp = 0;
+  stack[sp++] = 0;
+  bool found = false;
+  while (sp) {
+    const BvhNode& n = s.nodes[stack[--sp]];
+    if (!slab(n, o, id, best.t)) continue;
+    if (n.count) {
+      for (uint32_t i = n.left_or_first; i < n.left_or_first + n.count; ++i) {
+        const uint32_t p = s.order[i];
+        float t, u, v;
+        if (!tri_test(rp, o, s.wtri[3 * p], s.wtri[3 * p + 1], s.wtri[3 * p + 2], t, u, v)) continue;
+        if (t > tmax) continue;
+        if (found && (t > best.t || (t == best.t && p > best.prim))) continue;
+        best = {t, u, v, p};
+        found = true;
+        if (any_hit) return true;
+      }
+    } else {
+      stack[sp++] = n.left_or_first;
+      stack[sp++] = n.left_or_first + 1;
+    }
+  }
+  return found;
+}
+
+static bool intersect_brute(const Scene& s, V3 o, V3 d, float tmax, bool any_hit, Hit& best)
+{
+  best.t = tmax; best.prim = 0xffffffffu; best.u = best.v = 0;
+  const RayPre rp = ray_prepare(d);
+  bool found = false;
+  for (uint32_t p = 0; p < s.faces.size(); ++p) {
+    float t, u, v;
+    if (!tri_test(rp, o, s.wtri[3 * p], s.wtri[3 * p + 1], s.wtri[3 * p + 2], t, u, v)) continue;
+    if (t > tmax) continue;
+    if (found && (t > best.t || (t == best.t && p > best.prim))) continue;
+    best = {t, u, v, p};
+    found = true;
+    if (any_hit) return true;
+  }
+  return found;
+}
+
+// ----------------------------------------------------------------------------- sky
+// arhosek.h:145-227 / :229-301 (quintic Bezier in elevation^(1/3), bilinear in turbidity and albedo)
+static float hosek_bezier(const float* m, int stride, float e)
+{
+  const float ie = 1.0f - e;
+  return fhe_pow(ie, 5.0f) * m[0] + 5.0f * fhe_pow(ie, 4.0f) * e * m[stride] + 10.0f * fhe_pow(ie, 3.0f) * fhe_pow(e, 2.0f) * m[2 * stride] +
+         10.0f * fhe_pow(ie, 2.0f) * fhe_pow(e, 3.0f) * m[3 * stride] + 5.0f * ie * fhe_pow(e, 4.0f) * m[4 * stride] + fhe_pow(e, 5.0f) * m[5 * stride];
+}
+static HosekState hosek_cook(float turbidity, float albedo, float elevation)
+{
+  HosekState st{};
+  const int it = (int)turbidity;
+  const float tr = turbidity - (float)it;
+  const float e = fhe_pow(elevation / (kPi / 2.0f), (1.0f / 3.0f));
+  for (int ch = 0; ch < 3; ++ch) {
+    const float* ds = g_hosek + 1080 * ch;
+    const float* dr = g_hosek + 3240 + 120 * ch;
+    for (int i = 0; i < 9; ++i) {
+      float c = (1.0f - albedo) * (1.0f - tr) * hosek_bezier(ds + 9 * 6 * (it - 1) + i, 9, e);
+      c += albedo * (1.0f - tr) * hosek_bezier(ds + 9 * 6 * 10 + 9 * 6 * (it - 1) + i, 9, e);
+      if (it != 10) {
+        c += (1.0f - albedo) * tr * hosek_bezier(ds + 9 * 6 * it + i, 9, e);
+        c += albedo * tr * hosek_bezier(ds + 9 * 6 * 10 + 9 * 6 * it + i, 9, e);
+      }
+      st.cfg[ch][i] = c;
+    }
+    float r = (1.0f - albedo) * (1.0f - tr) * hosek_bezier(dr + 6 * (it - 1), 1, e);
+    r += albedo * (1.0f - tr) * hosek_bezier(dr + 6 * 10 + 6 * (it - 1), 1, e);
+    if (it != 10) {
+      r += (1.0f - albedo) * tr * hosek_bezier(dr + 6 * it, 1, e);
+      r += albedo * tr * hosek_bezier(dr + 6 * 10 + 6 * it, 1, e);
+    }
+    st.rad[ch] = r;
+  }
+  return st;
+}
+// arhosek.cu:103-127
+static float hosek_channel(const HosekState& st, int ch, float theta, float gamma)
+{
+  const float* c = st.cfg[ch];
+  const float cg = fhe_cos(gamma), ct = fhe_cos(theta);
+  const float expM = fhe_exp(c[4] * gamma);
+  const float rayM = cg * cg;
+  const float mieM = (1.0f + cg * cg) / fhe_pow((1.0f + c[8] * c[8] - 2.0f * c[8] * cg), 1.5f);
+  const float zenith = sqrtf(ct);
+  return (1.0f + c[0] * fhe_exp(c[1] / (ct + 0.01f))) * (c[2] + c[3] * expM + c[5] * rayM + c[6] * mieM + c[7] * zenith) * st.rad[ch];
+}
+// pt.cu:352-363 (+ math.cu:111-118; the azimuth is computed there but never used)
+static V3 sky_radiance(const Scene& s, V3 v)
+{
+  const float theta = fhe_acos(clampf(v.y, -1.0f, 1.0f));
+  const float gamma = fhe_acos(dot(s.sun_dir, v));
+  return s.sky_intensity * v3(hosek_channel(s.hosek, 0, theta, gamma), hosek_channel(s.hosek, 1, theta, gamma), hosek_channel(s.hosek, 2, theta, gamma));
+}
+
+// ----------------------------------------------------------------------------- integrator pieces
+// math.cu:7-17
+static inline void onb(V3 n, V3& t, V3& b)
+{
+  const float sign = copysignf(1.0f, n.z);
+  const float a = -1.0f / (sign + n.z);
+  const float bb = n.x * n.y * a;
+  t = v3(1.0f + sign * n.x * n.x * a, sign * bb, -sign * n.x);
+  b = v3(bb, sign + n.y * n.y * a, -n.y);
+}
+static inline V3 to_local(V3 v, V3 t, V3 n, V3 b) { return v3(dot(v, t), dot(v, n), dot(v, b)); }  // math.cu:19-25
+static inline V3 to_world(V3 v, V3 t, V3 n, V3 b)                                                    // math.cu:27-35
+{
+  return v3(v.x * t.x + v.y * n.x + v.z * b.x, v.x * t.y + v.y * n.y + v.z * b.y, v.x * t.z + v.y * n.z + v.z * b.z);
+}
+
+// pt.cu:402-416
+static inline V3 offset_origin(V3 p, V3 n)
+{
+  const float origin = 1.0f / 32.0f, float_scale = 1.0f / 65536.0f, int_scale = 256.0f;
+  const int ox = (int)(int_scale * n.x), oy = (int)(int_scale * n.y), oz = (int)(int_scale * n.z);
+  const V3 pi = v3(i2f(f2i(p.x) + ((p.x < 0) ? -ox : ox)), i2f(f2i(p.y) + ((p.y < 0) ? -oy : oy)), i2f(f2i(p.z) + ((p.z < 0) ? -oz : oz)));
+  return v3(fabsf(p.x) < origin ? p.x + float_scale * n.x : pi.x, fabsf(p.y) < origin ? p.y + float_scale * n.y : pi.y,
+            fabsf(p.z) < origin ? p.z + float_scale * n.z : pi.z);
+}
+
+// camera.cu:24-53 ; inv_tan_half_fov = 1/tanf(0.5 fov) is launch-constant and computed by the host libm
+static inline void camera_ray(const Camera& cam, float f, V2 uv, V2 u, V3& org, V3& dir)
+{
+  const float b = cam.focus;
+  const float a = 1.0f / (1.0f + f - 1.0f / b);
+  const float lens_radius = 2.0f * f / cam.F;
+  const V3 p_sensor = v3(uv.x, uv.y, 0);
+  const V3 p_lens_center = v3(0, 0, f);
+  const V2 pd = lens_radius * concentric_disk(u);
+  const V3 p_lens = p_lens_center + v3(pd.x, pd.y, 0);
+  const V3 s2c = normalize(p_lens_center - p_sensor);
+  const V3 p_object = p_sensor + ((a + b) / s2c.z) * s2c;
+  org = xform_point(cam.xf, p_lens);
+  V3 d = normalize(p_object - p_lens);
+  d.z *= -1.0f;
+  dir = xform_dir(cam.xf, d);
+}
+
+static inline bool emissive(const Material& m) { return m.emission_color[0] > 0 || m.emission_color[1] > 0 || m.emission_color[2] > 0 || m.emission_tex != -1; }  // pt.cu:125-129
+
+struct Surface { float t; V3 x, ng, ns; V2 uv; V3 tangent, bitangent; bool entering; };
+
+// pt.cu:141-179
+static void surface_at(const Scene& s, V3 rd, const Hit& h, Surface& si)
+{
+  const U3 idx = s.faces[h.prim];
+  const M34& o2w = s.o2w[s.inst_ids[h.prim]];
+  const M34& w2o = s.w2o[s.inst_ids[h.prim]];
+  si.t = h.t;
+  const V3 p0 = xform_point(o2w, s.verts[idx.x]), p1 = xform_point(o2w, s.verts[idx.y]), p2 = xform_point(o2w, s.verts[idx.z]);
+  si.x = (1.0f - h.u - h.v) * p0 + h.u * p1 + h.v * p2;
+  si.ng = normalize(cross(p1 - p0, p2 - p0));
+  const V3 n0 = xform_normal(w2o, s.normals[idx.x]), n1 = xform_normal(w2o, s.normals[idx.y]), n2 = xform_normal(w2o, s.normals[idx.z]);
+  si.ns = normalize((1.0f - h.u - h.v) * n0 + h.u * n1 + h.v * n2);
+  const V2 t0 = s.uvs[idx.x], t1 = s.uvs[idx.y], t2 = s.uvs[idx.z];
+  si.uv = (1.0f - h.u - h.v) * t0 + h.u * t1 + h.v * t2;
+  si.entering = dot(-rd, si.ng) > 0;
+  si.ns = si.entering ? si.ns : -si.ns;
+  si.ng = si.entering ? si.ng : -si.ng;
+  onb(si.ns, si.tangent, si.bitangent);
+}
+
+// pt.cu:181-280 with every texture id == -1
+static ShadingParams shading_params(const Material& m)
+{
+  ShadingParams p;
+  p.diffuse = m.diffuse;
+  p.diffuse_roughness = m.diffuse_roughness;
+  p.base_color = v3(m.base_color[0], m.base_color[1], m.base_color[2]);
+  p.specular = m.specular;
+  p.specular_color = v3(m.specular_color[0], m.specular_color[1], m.specular_color[2]);
+  p.specular_roughness = clampf(m.specular_roughness, 0.01f, 1.0f);
+  p.metalness = m.metalness;
+  p.coat = clampf(m.coat, 0.0f, 1.0f);
+  p.coat_roughness = clampf(m.coat_roughness, 0.0f, 1.0f);
+  p.transmission = m.transmission;
+  p.transmission_color = v3(m.transmission_color[0], m.transmission_color[1], m.transmission_color[2]);
+  p.sheen = m.sheen;
+  p.sheen_color = v3(m.sheen_color[0], m.sheen_color[1], m.sheen_color[2]);
+  p.sheen_roughness = m.sheen_roughness;
+  p.subsurface = m.subsurface;
+  p.subsurface_color = v3(m.subsurface_color[0], m.subsurface_color[1], m.subsurface_color[2]);
+  p.thin_walled = m.thin_walled;
+  return p;  // coat_color keeps its default (1,1,1): the reference never copies it
+}
+
+struct Payload {  // pt.cu:19-36
+  V3 origin, direction, throughput = {1, 1, 1}, radiance = {0, 0, 0};
+  Sampler sampler;
+  bool done = false, firsthit = true;
+  V3 position = {0, 0, 0}, normal = {0, 0, 0}; float depth = 0; V2 texcoord = {0, 0}; V3 albedo = {0, 0, 0};
+};
+
+struct Frame { uint32_t width, height, seed; V3 bg; };
+
+static inline bool shadow_visible(const Scene& s, V3 o, V3 d, float tmax)
+{
+  Hit h;
+  return !intersect(s, o, d, tmax - 0.001f, true, h);  // pt.cu:103
+}
+static inline V3 env_radiance(const Scene& s, const Frame& fr, V3 d) { return s.has_hosek ? sky_radiance(s, d) : fr.bg; }
+static inline float mis(float a, float b) { return a / (a + b); }
+static inline V3 regularize(V3 w) { return clamp3(w, v3(0.0f), v3(1.0f)); }
+
+// pt.cu:680-944
+static void closest_hit_radiance(const Scene& s, const Frame& fr, const Hit& h, V3 ro, V3 rd, Payload& pl)
+{
+  (void)ro;
+  const Material& mat = s.mats[s.mat_ids[h.prim]];
+  Surface si;
+  surface_at(s, rd, h, si);
+  const ShadingParams sp = shading_params(mat);
+  const V3 tangent = si.tangent, normal = si.ns, bitangent = si.bitangent;
+  if (pl.firsthit) {
+    pl.position = si.x; pl.normal = normal; pl.depth = si.t; pl.texcoord = si.uv; pl.albedo = sp.base_color;
+    pl.firsthit = false;
+    if (emissive(mat)) {
+      pl.radiance += pl.throughput * v3(mat.emission_color[0], mat.emission_color[1], mat.emission_color[2]);
+      pl.done = true;
+      return;
+    }
+  }
+  const V3 wo = to_local(-rd, tangent, normal, bitangent);
+  const Bsdf bsdf(wo, sp, si.entering);
+  {
+    const V3 so = offset_origin(si.x, si.ng);
+    if (s.has_dir) {  // pt.cu:772-793, :324-342
+      const V2 pd = concentric_disk(sample_2d(pl.sampler));
+      const float dist = 1e9f;
+      const float radius = dist * tanf(0.5f * s.dir.angle * kPi / 180.0f);
+      V3 t, b;
+      onb(s.dir.dir, t, b);
+      const V3 p = dist * s.dir.dir + radius * (t * pd.x + b * pd.y);
+      const V3 sd = normalize(p - so);
+      if (shadow_visible(s, so, sd, 1e9f)) {
+        const V3 wi = to_local(sd, tangent, normal, bitangent);
+        const V3 f = bsdf.eval(wo, wi);
+        const float pdf = 1.0f;
+        const float w = mis(pdf, bsdf.eval_pdf(wo, wi));
+        pl.radiance += regularize(pl.throughput * w * f * abs_cos(wi) / pdf) * s.dir.le;
+      }
+    }
+    {  // sky / constant background NEE, pt.cu:817-857 (IBL branch :796-816 not supported by the checker)
+      const V3 wi = cosine_hemisphere(sample_2d(pl.sampler));
+      const V3 sd = to_world(wi, tangent, normal, bitangent);
+      if (shadow_visible(s, so, sd, 1e9f)) {
+        const V3 f = bsdf.eval(wo, wi);
+        const float pdf = abs_cos(wi) / kPi;
+        const float w = mis(pdf, bsdf.eval_pdf(wo, wi));
+        pl.radiance += regularize(pl.throughput * w * f * abs_cos(wi) / pdf) * env_radiance(s, fr, sd);
+      }
+    }
+    if (!s.lights.empty()) {  // pt.cu:860-889, :282-322
+      const uint32_t nl = (uint32_t)s.lights.size();
+      const float u1 = sample_1d(pl.sampler);
+      const V2 u2 = sample_2d(pl.sampler);
+      const uint32_t li = clampu((uint32_t)(u1 * nl), 0u, nl - 1);
+      const AreaLight& L = s.lights[li];
+      const V2 bc = triangle_barycentric(u2);
+      const M34& o2w = s.o2w[L.instance_idx];
+      const M34& w2o = s.w2o[L.instance_idx];
+      const V3 p0 = xform_point(o2w, s.verts[L.idx.x]), p1 = xform_point(o2w, s.verts[L.idx.y]), p2 = xform_point(o2w, s.verts[L.idx.z]);
+      const V3 n0 = xform_normal(w2o, s.normals[L.idx.x]), n1 = xform_normal(w2o, s.normals[L.idx.y]), n2 = xform_normal(w2o, s.normals[L.idx.z]);
+      const V3 p = (1.0f - bc.x - bc.y) * p0 + bc.x * p1 + bc.y * p2;
+      const V3 n = (1.0f - bc.x - bc.y) * n0 + bc.x * n1 + bc.y * n2;
+      const float area = 0.5f * length(cross(p1 - p0, p2 - p0));
+      const Material& lm = s.mats[L.material_id];
+      const V3 le = v3(lm.emission_color[0], lm.emission_color[1], lm.emission_color[2]);
+      const float pdf_area = 1.0f / (nl * area);
+      const V3 sd = normalize(p - so);
+      const float r = length(p - so);
+      if (shadow_visible(s, so, sd, r) && dot(-sd, n) > 0.0f) {
+        const V3 wi = to_local(sd, tangent, normal, bitangent);
+        const V3 f = bsdf.eval(wo, wi);
+        const float pdf = r * r / fabsf(dot(-sd, n)) * pdf_area;
+        const float w = mis(pdf, bsdf.eval_pdf(wo, wi));
+        pl.radiance += regularize(pl.throughput * w * f * abs_cos(wi) / pdf) * le;
+      }
+    }
+  }
+  {  // BSDF-sampled light ray, pt.cu:893-925 and closest-hit/miss light :952-999, :531-543
+    V3 f; float pdf;
+    const float u1 = sample_1d(pl.sampler);
+    const V2 u2 = sample_2d(pl.sampler);
+    const V3 wi = bsdf.sample(wo, u1, u2, f, pdf);
+    const V3 ld = to_world(wi, tangent, normal, bitangent);
+    const bool transmitted = dot(ld, si.ng) < 0;
+    const V3 lo = offset_origin(si.x, transmitted ? -si.ng : si.ng);
+    Hit lh;
+    V3 le = v3(0.0f);
+    float pdf_light;
+    bool hit_light = false;
+    V3 lp = v3(0.0f), ln = v3(0.0f);
+    float larea = 0.0f;
+    if (intersect(s, lo, ld, 1e9f, false, lh)) {
+      const U3 idx = s.faces[lh.prim];
+      const M34& o2w = s.o2w[s.inst_ids[lh.prim]];
+      const M34& w2o = s.w2o[s.inst_ids[lh.prim]];
+      const Material& lm = s.mats[s.mat_ids[lh.prim]];
+      const V3 p0 = xform_point(o2w, s.verts[idx.x]), p1 = xform_point(o2w, s.verts[idx.y]), p2 = xform_point(o2w, s.verts[idx.z]);
+      const V3 n0 = xform_normal(w2o, s.normals[idx.x]), n1 = xform_normal(w2o, s.normals[idx.y]), n2 = xform_normal(w2o, s.normals[idx.z]);
+      lp = (1.0f - lh.u - lh.v) * p0 + lh.u * p1 + lh.v * p2;
+      ln = (1.0f - lh.u - lh.v) * n0 + lh.u * n1 + lh.v * n2;
+      if (emissive(lm) && dot(-ld, ln) > 0.0f) {
+        hit_light = true;
+        le = v3(lm.emission_color[0], lm.emission_color[1], lm.emission_color[2]);
+        larea = 0.5f * length(cross(p1 - p0, p2 - p0));
+      }
+    } else {
+      le = env_radiance(s, fr, ld);
+    }
+    if (hit_light) {
+      const float r2 = dot(lp - lo, lp - lo);
+      const float pdf_area = 1.0f / ((uint32_t)s.lights.size() * larea);
+      pdf_light = r2 / fabsf(dot(-ld, ln)) * pdf_area;
+    } else {
+      pdf_light = abs_cos(wi) / kPi;
+    }
+    const float w = mis(pdf, pdf_light);
+    pl.radiance += regularize(pl.throughput * w * f * abs_cos(wi) / pdf) * le;
+  }
+  {  // next direction, pt.cu:928-943
+    V3 f; float pdf;
+    const float u1 = sample_1d(pl.sampler);
+    const V2 u2 = sample_2d(pl.sampler);
+    const V3 wi = bsdf.sample(wo, u1, u2, f, pdf);
+    const V3 wd = to_world(wi, tangent, normal, bitangent);
+    pl.throughput *= f * abs_cos(wi) / pdf;
+    const bool transmitted = dot(wd, si.ng) < 0;
+    pl.origin = offset_origin(si.x, transmitted ? -si.ng : si.ng);
+    pl.direction = wd;
+  }
+}
+
+struct Layers { float *beauty, *position, *depth, *normal, *texcoord, *albedo; uint32_t* sample_count; };
+
+// pt.cu:418-502 for one pixel.  The payload lives outside the spp loop exactly as in the reference
+// (pt.cu:432), which is the "firsthit is never reset" quirk of SURVEY.md 3-D-2 when n_samples > 1.
+static void render_pixel(const Scene& s, const Frame& fr, const Camera& cam, float inv_tan, uint32_t px, uint32_t py, uint32_t n_samples, uint32_t max_depth, const Layers& L)
+{
+  const uint32_t image_idx = px + fr.width * py;
+  uint32_t n_spp = L.sample_count[image_idx];
+  V3 beauty = v3(L.beauty[4 * image_idx], L.beauty[4 * image_idx + 1], L.beauty[4 * image_idx + 2]);
+  V3 position = v3(L.position[4 * image_idx], L.position[4 * image_idx + 1], L.position[4 * image_idx + 2]);
+  V3 normal = v3(L.normal[4 * image_idx], L.normal[4 * image_idx + 1], L.normal[4 * image_idx + 2]);
+  float depth = L.depth[image_idx];
+  V2 texcoord = v2(L.texcoord[4 * image_idx], L.texcoord[4 * image_idx + 1]);
+  V3 albedo = v3(L.albedo[4 * image_idx], L.albedo[4 * image_idx + 1], L.albedo[4 * image_idx + 2]);
+  Payload pl;
+  for (uint32_t spp = 0; spp < n_samples; ++spp) {
+    // pt.cu:378-399
+    pl.sampler.sobol.index = (uint64_t)(image_idx + n_spp * fr.width * fr.height);  // 32-bit wrap, then widened
+    pl.sampler.sobol.dimension = 1;
+    pl.sampler.sobol.seed = xxhash32_1(fr.seed);
+    pl.sampler.cmj.image_idx = image_idx;
+    pl.sampler.cmj.depth = 0;
+    pl.sampler.cmj.n_spp = n_spp;
+    pl.sampler.cmj.scramble = xxhash32_1(fr.seed);
+    V2 u = sample_2d(pl.sampler);
+    V2 uv = v2((2.0f * (px + u.x) - fr.width) / fr.height, (2.0f * (py + u.y) - fr.height) / fr.height);
+    uv.x = -uv.x;
+    u = sample_2d(pl.sampler);
+    camera_ray(cam, inv_tan, uv, u, pl.origin, pl.direction);
+    pl.radiance = v3(0.0f);
+    pl.throughput = v3(1.0f);
+    pl.done = false;
+    for (uint32_t d = 0; d < max_depth; ++d) {
+      const float prr = d == 0 ? 1.0f : clampf(luminance(pl.throughput), 0.0f, 1.0f);
+      if (sample_1d(pl.sampler) >= prr) break;
+      pl.throughput /= prr;
+      Hit h;
+      if (intersect(s, pl.origin, pl.direction, 1e9f, false, h)) {
+        closest_hit_radiance(s, fr, h, pl.origin, pl.direction, pl);
+      } else {  // pt.cu:504-523
+        if (pl.firsthit) pl.radiance += pl.throughput * env_radiance(s, fr, pl.direction);
+        pl.done = true;
+      }
+      if (anynan(pl.throughput) || anyinf(pl.throughput)) break;
+      if (pl.done) break;
+    }
+    V3 radiance = v3(0.0f);
+    if (!anynan(pl.radiance) && !anyinf(pl.radiance)) radiance = pl.radiance;
+    const float coef = 1.0f / (n_spp + 1.0f);
+    beauty = coef * (n_spp * beauty + radiance);
+    position = coef * (n_spp * position + pl.position);
+    normal = coef * (n_spp * normal + pl.normal);
+    depth = coef * (n_spp * depth + pl.depth);
+    texcoord = coef * (n_spp * texcoord + pl.texcoord);
+    albedo = coef * (n_spp * albedo + pl.albedo);
+    n_spp++;
+  }
+  L.sample_count[image_idx] = n_spp;
+  auto put4 = [&](float* dst, V3 v, float w) { dst[4 * image_idx] = v.x; dst[4 * image_idx + 1] = v.y; dst[4 * image_idx + 2] = v.z; dst[4 * image_idx + 3] = w; };
+  put4(L.beauty, beauty, 1.0f);
+  put4(L.position, position, 1.0f);
+  put4(L.normal, normal, 1.0f);
+  L.depth[image_idx] = depth;
+  L.texcoord[4 * image_idx] = texcoord.x; L.texcoord[4 * image_idx + 1] = texcoord.y; L.texcoord[4 * image_idx + 2] = 0.0f; L.texcoord[4 * image_idx + 3] = 1.0f;
+  put4(L.albedo, albedo, 1.0f);
+}
+
+// ----------------------------------------------------------------------------- post-process
+// post-process.h:13-124 / post-process.cu:49-153.  Double-precision literals are honoured.
+struct PostParams { int use_bloom; float bloom_threshold, bloom_sigma, ISO, chromatic_aberration; };
+static inline float smoothstep_f(float e0, float e1, float x) { if (x < e0) return 0.0f; if (x > e1) return 1.0f; x = (x - e0) / (e1 - e0); return x * x * (3.0f - 2.0f * x); }
+static inline float uchimura1(float x)
+{
+  const float P = 1.0, a = 1.0, m = 0.22, l = 0.4, c = 1.33, b = 0.0;
+  const float l0 = ((P - m) * l) / a;
+  const float S0 = m + l0;
+  const float S1 = m + a * l0;
+  const float C2 = (a * P) / (P - S1);
+  const float CP = -C2 / P;
+  const float w0 = 1.0f - smoothstep_f(0.0f, m, x);
+  const float w2 = (x < m + l0) ? 0.0f : 1.0f;
+  const float w1 = 1.0f - w0 - w2;
+  const float T = m * fhe_pow(x / m, c) + b;
+  const float S = P - (P - S1) * fhe_exp(CP * (x - S0));
+  const float Lc = m + a * (x - m);
+  return T * w0 + Lc * w1 + S * w2;
+}
+static inline float srgb1(float x) { return x < 0.0031308 ? (float)(12.92 * x) : (float)(1.055 * fhe_pow(x, 1.0f / 2.4f) - 0.055); }
+
+static void post_process(const float* in, float* hi, float* tmp, int w, int h, const PostParams& pp, float* out)
+{
+  const int gw = std::max(w / 16, 1) * 16, gh = std::max(h / 16, 1) * 16;  // floor-division launch grid, post-process.cu:9-11
+  auto covered = [&](int i, int j) { return i < gw && j < gh && i < w && j < h; };
+  if (pp.use_bloom) {
+    for (int j = 0; j < h; ++j)
+      for (int i = 0; i < w; ++i) {
+        if (!covered(i, j)) continue;
+        const float* b = in + 4 * (i + w * j);
+        const float lum = luminance(v3(b[0], b[1], b[2]));
+        for (int k = 0; k < 4; ++k) hi[4 * (i + w * j) + k] = lum > pp.bloom_threshold ? b[k] : 0.0f;
+      }
+    for (int j = 0; j < h; ++j)
+      for (int i = 0; i < w; ++i) {
+        if (!covered(i, j)) continue;
+        V4 sum = {0, 0, 0, 0};
+        float wsum = 0.0f;
+        for (int v = -16; v <= 16; ++v)
+          for (int u = -16; u <= 16; ++u) {
+            const int x = clampi(i + u, 0, w - 1), y = clampi(j + v, 0, h - 1);
+            const float* b1 = hi + 4 * (x + w * y);
+            const float dist2 = (float)(u * u + v * v);
+            const float hh = fhe_exp(-dist2 / (2.0f * pp.bloom_sigma));
+            sum += hh * v4(b1[0], b1[1], b1[2], b1[3]);
+            wsum += hh;
+          }
+        const V4 r = v4(in[4 * (i + w * j)], in[4 * (i + w * j) + 1], in[4 * (i + w * j) + 2], in[4 * (i + w * j) + 3]) + sum / wsum;
+        float* o = tmp + 4 * (i + w * j);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+      }
+  } else {
+    for (int j = 0; j < h; ++j)
+      for (int i = 0; i < w; ++i)
+        if (covered(i, j)) std::memcpy(tmp + 4 * (i + w * j), in + 4 * (i + w * j), 16);
+  }
+  const float EV100 = fhe_log2((float)(1.0f * 1.0f / 1.0f * 100.0 / pp.ISO));
+  const float maxLum = (float)(1.2 * fhe_pow(2.0f, EV100));
+  const float exposure = 1.0f / maxLum;
+  for (int j = 0; j < h; ++j)
+    for (int i = 0; i < w; ++i) {
+      if (!covered(i, j)) continue;
+      const V2 uv = v2((float)i / w, (float)j / h);
+      const V2 uvc = uv - v2(0.5f);
+      const float inv = 1.0f / (float)(w * h);
+      const V2 d = v2(uvc.x * inv * pp.chromatic_aberration, uvc.y * inv * pp.chromatic_aberration);
+      const V2 ur = clamp2(uv - 0.0f * d, v2(0.0f), v2(1.0f)), ug = clamp2(uv - 1.0f * d, v2(0.0f), v2(1.0f)), ub = clamp2(uv - 2.0f * d, v2(0.0f), v2(1.0f));
+      const int ir = (int)(ur.x * w + w * (ur.y * h)), ig = (int)(ug.x * w + w * (ug.y * h)), ib = (int)(ub.x * w + w * (ub.y * h));
+      V3 c = v3(tmp[4 * ir], tmp[4 * ig + 1], tmp[4 * ib + 2]);
+      c *= exposure;
+      c = v3(uchimura1(c.x), uchimura1(c.y), uchimura1(c.z));
+      c = v3(srgb1(c.x), srgb1(c.y), srgb1(c.z));
+      float* o = out + 4 * (i + w * j);
+      o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = 1.0f;
+    }
+}
+
+static bool load_file(const char* dir, const char* name, void* dst, size_t bytes)
+{
+  char path[1024];
+  snprintf(path, sizeof path, "%s/%s", dir, name);
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  const size_t got = fread(dst, 1, bytes, f);
+  fclose(f);
+  return got == bytes;
+}
+
+}  // namespace orc
+
+// =============================================================================== C interface (ctypes)
+using namespace orc;
+
+extern "C" {
+
+int orc_init(const char* data_dir)
+{
+  s_sobol.resize(1024 * 52); s_refl.resize(512); s_sheen.resize(256); s_hosek.resize(3600);
+  if (!load_file(data_dir, "sobol_1024x52.u32", s_sobol.data(), s_sobol.size() * 4)) return -1;
+  if (!load_file(data_dir, "lut_reflection.f32", s_refl.data(), s_refl.size() * 4)) return -2;
+  if (!load_file(data_dir, "lut_sheen.f32", s_sheen.data(), s_sheen.size() * 4)) return -3;
+  if (!load_file(data_dir, "hosek_rgb.f32", s_hosek.data(), s_hosek.size() * 4)) return -4;
+  g_sobol_matrices = s_sobol.data(); g_lut_reflection = s_refl.data(); g_lut_sheen = s_sheen.data(); g_hosek = s_hosek.data();
+  return 0;
+}
+
+// ---- known-answer entry points
+uint32_t orc_xxhash32_1(uint32_t a) { return xxhash32_1(a); }
+uint32_t orc_xxhash32_3(uint32_t a, uint32_t b, uint32_t c) { return xxhash32_3(a, b, c); }
+uint32_t orc_xxhash32_4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return xxhash32_4(a, b, c, d); }
+uint32_t orc_cmj_permute(uint32_t i, uint32_t l, uint32_t p) { return cmj_permute(i, l, p); }
+void orc_cmj_2d(uint64_t n_spp, uint32_t scramble, uint32_t depth, uint32_t image_idx, int count, float* out)
+{
+  CmjState s{n_spp, scramble, depth, image_idx};
+  for (int i = 0; i < count; ++i) { const V2 r = cmj_2d(s); out[2 * i] = r.x; out[2 * i + 1] = r.y; }
+}
+void orc_sobol_owen(uint64_t index, uint32_t dimension, uint32_t seed, int count, float* out)
+{
+  SobolState s{index, dimension, seed};
+  for (int i = 0; i < count; ++i) out[i] = sobol_owen(s);
+}
+uint32_t orc_sobol_raw(uint64_t index, uint32_t dimension) { return sobol_u32(index, dimension); }
+void orc_offset_origin(const float* p, const float* n, float* out)
+{
+  const V3 r = offset_origin(v3(p[0], p[1], p[2]), v3(n[0], n[1], n[2]));
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_elementary(int fn, int n, const float* x, const float* y, float* out)
+{
+  for (int i = 0; i < n; ++i) {
+    switch (fn) {
+      case 0: out[i] = fhe_sin(x[i]); break;
+      case 1: out[i] = fhe_cos(x[i]); break;
+      case 2: out[i] = fhe_exp(x[i]); break;
+      case 3: out[i] = fhe_log(x[i]); break;
+      case 4: out[i] = fhe_pow(x[i], y[i]); break;
+      case 5: out[i] = fhe_acos(x[i]); break;
+      case 6: out[i] = fhe_atan2(x[i], y[i]); break;
+      case 7: out[i] = fhe_log2(x[i]); break;
+    }
+  }
+}
+// warps: kind 0 concentric disk (2 out), 1 cosine hemisphere (3), 2 triangle (2), 3 vndf (3; needs wo[3], alpha[2])
+void orc_warp(int kind, int n, const float* u, const float* wo, const float* alpha, float* out)
+{
+  for (int i = 0; i < n; ++i) {
+    const V2 uu = v2(u[2 * i], u[2 * i + 1]);
+    if (kind == 0) { const V2 r = concentric_disk(uu); out[2 * i] = r.x; out[2 * i + 1] = r.y; }
+    else if (kind == 1) { const V3 r = cosine_hemisphere(uu); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+    else if (kind == 2) { const V2 r = triangle_barycentric(uu); out[2 * i] = r.x; out[2 * i + 1] = r.y; }
+    else { const V3 r = vndf(v3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), v2(alpha[0], alpha[1]), uu); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+  }
+}
+// BSDF known answers for one material: per sample i, wo[i], wi[i], u1[i], u2[i] ->
+//   out[i] = { eval.rgb, eval_pdf, sample.wi.xyz, sample.f.rgb, sample.pdf, weights[7] } (18 floats)
+void orc_bsdf(const void* material180, int entering, int n, const float* wo, const float* wi, const float* u1, const float* u2, float* out)
+{
+  const ShadingParams sp = shading_params(*(const Material*)material180);
+  for (int i = 0; i < n; ++i) {
+    const V3 o = v3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), in = v3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+    const Bsdf b(o, sp, entering != 0);
+    const V3 e = b.eval(o, in);
+    V3 f; float pdf;
+    const V3 swi = b.sample(o, u1[i], v2(u2[2 * i], u2[2 * i + 1]), f, pdf);
+    float* r = out + 18 * i;
+    r[0] = e.x; r[1] = e.y; r[2] = e.z; r[3] = b.eval_pdf(o, in);
+    r[4] = swi.x; r[5] = swi.y; r[6] = swi.z; r[7] = f.x; r[8] = f.y; r[9] = f.z; r[10] = pdf;
+    for (int k = 0; k < 7; ++k) r[11 + k] = b.weights[k];
+  }
+}
+void orc_hosek_cook(float turbidity, float albedo, const float* sun_dir, float* out30)
+{
+  const float elevation = (float)(0.5f * M_PI - fhe_acos(clampf(sun_dir[1], -1.0f, 1.0f)));  // renderer.h:592-601
+  const HosekState st = hosek_cook(turbidity, albedo, elevation);
+  std::memcpy(out30, &st, sizeof st);
+}
+void orc_hosek_radiance(const float* state30, const float* sun_dir, float intensity, int n, const float* dirs, float* out)
+{
+  Scene s;
+  std::memcpy(&s.hosek, state30, sizeof s.hosek);
+  s.sun_dir = v3(sun_dir[0], sun_dir[1], sun_dir[2]);
+  s.sky_intensity = intensity;
+  for (int i = 0; i < n; ++i) { const V3 r = sky_radiance(s, v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+}
+// camera rays for pixel list; cam16 = 12 floats (3x4 rows) + fov, F, focus; out = origin.xyz dir.xyz per entry
+void orc_camera_rays(const float* cam15, uint32_t width, uint32_t height, uint32_t seed, int n, const uint32_t* pixel_idx, const uint32_t* n_spp, float* out)
+{
+  Camera cam;
+  std::memcpy(&cam, cam15, sizeof(Camera));
+  const float inv_tan = 1.0f / tanf(0.5f * cam.fov);
+  for (int i = 0; i < n; ++i) {
+    const uint32_t px = pixel_idx[i] % width, py = pixel_idx[i] / width;
+    Sampler sm;
+    sm.cmj = {n_spp[i], xxhash32_1(seed), 0, pixel_idx[i]};
+    V2 u = sample_2d(sm);
+    V2 uv = v2((2.0f * (px + u.x) - width) / height, (2.0f * (py + u.y) - height) / height);
+    uv.x = -uv.x;
+    u = sample_2d(sm);
+    V3 o, d;
+    camera_ray(cam, inv_tan, uv, u, o, d);
+    out[6 * i] = o.x; out[6 * i + 1] = o.y; out[6 * i + 2] = o.z; out[6 * i + 3] = d.x; out[6 * i + 4] = d.y; out[6 * i + 5] = d.z;
+  }
+}
+
+// ---- scene + render
+void* orc_scene_create(uint32_t n_verts, const float* verts, const float* normals, const float* uvs, uint32_t n_faces, const uint32_t* faces, const uint32_t* mat_ids,
+                       const uint32_t* inst_ids, uint32_t n_mats, const void* mats180, uint32_t n_xf, const float* o2w, const float* w2o)
+{
+  Scene* s = new Scene;
+  s->verts.resize(n_verts); s->normals.resize(n_verts); s->uvs.resize(n_verts);
+  std::memcpy(s->verts.data(), verts, 12ull * n_verts);
+  std::memcpy(s->normals.data(), normals, 12ull * n_verts);
+  std::memcpy(s->uvs.data(), uvs, 8ull * n_verts);
+  s->faces.resize(n_faces); s->mat_ids.resize(n_faces); s->inst_ids.assign(n_faces, 0);
+  std::memcpy(s->faces.data(), faces, 12ull * n_faces);
+  std::memcpy(s->mat_ids.data(), mat_ids, 4ull * n_faces);
+  if (inst_ids) std::memcpy(s->inst_ids.data(), inst_ids, 4ull * n_faces);
+  s->mats.resize(n_mats);
+  std::memcpy(s->mats.data(), mats180, 180ull * n_mats);
+  for (const Material& m : s->mats)
+    if (m.base_color_tex != -1 || m.specular_color_tex != -1 || m.specular_roughness_tex != -1 || m.metalness_tex != -1 || m.metallic_roughness_tex != -1 || m.coat_tex != -1 ||
+        m.coat_roughness_tex != -1 || m.emission_tex != -1 || m.heightmap_tex != -1 || m.normalmap_tex != -1 || m.alpha_tex != -1) { delete s; return nullptr; }
+  if (n_xf == 0) {
+    M34 id = {{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}}};
+    s->o2w.assign(1, id); s->w2o.assign(1, id);
+  } else {
+    s->o2w.resize(n_xf); s->w2o.resize(n_xf);
+    std::memcpy(s->o2w.data(), o2w, 48ull * n_xf);
+    std::memcpy(s->w2o.data(), w2o, 48ull * n_xf);
+  }
+  s->wtri.resize(3ull * n_faces);
+  for (uint32_t f = 0; f < n_faces; ++f) {
+    const M34& m = s->o2w[s->inst_ids[f]];
+    s->wtri[3 * f] = xform_point(m, s->verts[s->faces[f].x]);
+    s->wtri[3 * f + 1] = xform_point(m, s->verts[s->faces[f].y]);
+    s->wtri[3 * f + 2] = xform_point(m, s->verts[s->faces[f].z]);
+    if (emissive(s->mats[s->mat_ids[f]])) s->lights.push_back({s->faces[f], s->mat_ids[f], s->inst_ids[f]});  // renderer.h:388-402
+  }
+  build_bvh(*s);
+  return s;
+}
+void orc_scene_destroy(void* h) { delete (Scene*)h; }
+uint32_t orc_scene_n_lights(void* h) { return (uint32_t)((Scene*)h)->lights.size(); }
+void orc_set_directional_light(void* h, int enable, const float* le, const float* dir, float angle)
+{
+  Scene* s = (Scene*)h;
+  s->has_dir = enable != 0;
+  if (!enable) return;
+  s->dir.le = v3(le[0], le[1], le[2]);
+  s->dir.dir = normalize(v3(dir[0], dir[1], dir[2]));  // renderer.h:554-567
+  s->dir.angle = angle;
+  s->sun_dir = s->dir.dir;
+}
+void orc_set_sky_intensity(void* h, float v) { ((Scene*)h)->sky_intensity = v; }
+void orc_set_hosek(void* h, int enable, float turbidity, float albedo)
+{
+  Scene* s = (Scene*)h;
+  s->has_hosek = enable != 0;
+  if (!enable) return;
+  const float elevation = (float)(0.5f * M_PI - fhe_acos(clampf(s->sun_dir.y, -1.0f, 1.0f)));
+  s->hosek = hosek_cook(turbidity, albedo, elevation);
+}
+// rays: o.xyz, d.xyz, tmax per ray; out: t,u,v as float + prim as uint32 (0xffffffff = miss)
+void orc_trace(void* h, int n, const float* rays7, int any_hit, int brute, float* tuv, uint32_t* prim)
+{
+  const Scene& s = *(Scene*)h;
+  for (int i = 0; i < n; ++i) {
+    const float* r = rays7 + 7 * i;
+    Hit hit;
+    const bool ok = brute ? intersect_brute(s, v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), r[6], any_hit != 0, hit)
+                          : intersect(s, v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), r[6], any_hit != 0, hit);
+    tuv[3 * i] = ok ? hit.t : 0; tuv[3 * i + 1] = ok ? hit.u : 0; tuv[3 * i + 2] = ok ? hit.v : 0;
+    prim[i] = ok ? hit.prim : 0xffffffffu;
+  }
+}
+// render n_samples more samples into the layer buffers (progressive, like Renderer::render)
+void orc_render(void* h, const float* cam15, uint32_t width, uint32_t height, const float* bg, uint32_t seed, uint32_t n_samples, uint32_t max_depth, float* beauty, float* position,
+                float* depth, float* normal, float* texcoord, float* albedo, uint32_t* sample_count, int n_threads, uint32_t y0, uint32_t y1)
+{
+  const Scene& s = *(Scene*)h;
+  Camera cam;
+  std::memcpy(&cam, cam15, sizeof(Camera));
+  const float inv_tan = 1.0f / tanf(0.5f * cam.fov);
+  const Frame fr{width, height, seed, v3(bg[0], bg[1], bg[2])};
+  const Layers L{beauty, position, depth, normal, texcoord, albedo, sample_count};
+  if (y1 > height) y1 = height;
+  if (n_threads <= 1) {
+    for (uint32_t y = y0; y < y1; ++y)
+      for (uint32_t x = 0; x < width; ++x) render_pixel(s, fr, cam, inv_tan, x, y, n_samples, max_depth, L);
+    return;
+  }
+  std::atomic<uint32_t> next{y0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; ++t)
+    th.emplace_back([&] {
+      for (;;) {
+        const uint32_t y = next.fetch_add(1);
+        if (y >= y1) break;
+        for (uint32_t x = 0; x < width; ++x) render_pixel(s, fr, cam, inv_tan, x, y, n_samples, max_depth, L);
+      }
+    });
+  for (auto& t : th) t.join();
+}
+void orc_post_process(const float* in, float* hi, float* tmp, int w, int h, int use_bloom, float threshold, float sigma, float iso, float ca, float* out)
+{
+  const PostParams pp{use_bloom, threshold, sigma, iso, ca};
+  post_process(in, hi, tmp, w, h, pp, out);
+}
+int orc_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+// oracle/osampler.h -- TEST INFRASTRUCTURE (CPU checker), never linked into the product.
+//
+// Restates the reference samplers:
+//   xxhash32 (uint / uint3 / uint4)      fredholm/include/fredholm/shared.h:282-319
+//   CMJ 4x4 (Kensler 2013)               fredholm/modules/cmj.cu:12-80
+//   Sobol' + Owen scrambling (Burley)    fredholm/modules/sobol.cu:10661-10742
+//   disk / hemisphere / triangle / VNDF  fredholm/modules/sampling.cu:54-110
+//   discrete 1-D distribution            fredholm/modules/sampling.cu:112-150
+// Integer parts are bit-exact by construction; float parts use include/fh_elementary.h.
+#pragma once
+#include "../include/fh_elementary.h"
+#include "ovec.h"
+
+namespace orc {
+
+inline uint32_t rotl17(uint32_t v) { return (v << 17) | (v >> 15); }
+
+// shared.h:282-291
+inline uint32_t xxhash32_1(uint32_t p)
+{
+  const uint32_t P2 = 2246822519U, P3 = 3266489917U, P4 = 668265263U, P5 = 374761393U;
+  uint32_t h = p + P5;
+  h = P4 * rotl17(h);
+  h = P2 * (h ^ (h >> 15));
+  h = P3 * (h ^ (h >> 13));
+  return h ^ (h >> 16);
+}
+// shared.h:293-304
+inline uint32_t xxhash32_3(uint32_t x, uint32_t y, uint32_t z)
+{
+  const uint32_t P2 = 2246822519U, P3 = 3266489917U, P4 = 668265263U, P5 = 374761393U;
+  uint32_t h = z + P5 + x * P3;
+  h = P4 * rotl17(h);
+  h += y * P3;
+  h = P4 * rotl17(h);
+  h = P2 * (h ^ (h >> 15));
+  h = P3 * (h ^ (h >> 13));
+  return h ^ (h >> 16);
+}
+// shared.h:306-319
+inline uint32_t xxhash32_4(uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{
+  const uint32_t P2 = 2246822519U, P3 = 3266489917U, P4 = 668265263U, P5 = 374761393U;
+  uint32_t h = w + P5 + x * P3;
+  h = P4 * rotl17(h);
+  h += y * P3;
+  h = P4 * rotl17(h);
+  h += z * P3;
+  h = P4 * rotl17(h);
+  h = P2 * (h ^ (h >> 15));
+  h = P3 * (h ^ (h >> 13));
+  return h ^ (h >> 16);
+}
+
+// cmj.cu:12-43
+inline uint32_t cmj_permute(uint32_t i, uint32_t l, uint32_t p)
+{
+  uint32_t w = l - 1;
+  w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+  do {
+    i ^= p;             i *= 0xe170893d;
+    i ^= p >> 16;
+    i ^= (i & w) >> 4;
+    i ^= p >> 8;        i *= 0x0929eb3f;
+    i ^= p >> 23;
+    i ^= (i & w) >> 1;  i *= 1 | p >> 27;
+                        i *= 0x6935fa69;
+    i ^= (i & w) >> 11; i *= 0x74dcb303;
+    i ^= (i & w) >> 2;  i *= 0x9e501cc3;
+    i ^= (i & w) >> 2;  i *= 0xc860a3df;
+    i &= w;
+    i ^= i >> 5;
+  } while (i >= l);
+  return (i + p) % l;
+}
+// cmj.cu:45-58
+inline float cmj_randfloat(uint32_t i, uint32_t p)
+{
+  i ^= p;
+  i ^= i >> 17;
+  i ^= i >> 10; i *= 0xb36534e5;
+  i ^= i >> 12;
+  i ^= i >> 21; i *= 0x93fc4795;
+  i ^= 0xdf6e307f;
+  i ^= i >> 17; i *= 1 | p >> 18;
+  return i * (1.0f / 4294967808.0f);
+}
+// cmj.cu:60-69 (M = N = 4)
+inline V2 cmj_sample(uint32_t index, uint32_t scramble)
+{
+  index = cmj_permute(index, 16, scramble * 0x51633e2d);
+  const uint32_t sx = cmj_permute(index % 4, 4, scramble * 0xa511e9b3);
+  const uint32_t sy = cmj_permute(index / 4, 4, scramble * 0x63d83595);
+  const float jx = cmj_randfloat(index, scramble * 0xa399d265);
+  const float jy = cmj_randfloat(index, scramble * 0x711ad6a5);
+  return v2((index % 4 + (sy + jx) / 4) / 4, (index / 4 + (sx + jy) / 4) / 4);
+}
+
+struct CmjState { uint64_t n_spp; uint32_t scramble, depth, image_idx; };  // shared.h:77-82
+// cmj.cu:71-80
+inline V2 cmj_2d(CmjState& s)
+{
+  const uint32_t index = (uint32_t)(s.n_spp % 16);
+  const uint32_t scramble = xxhash32_4((uint32_t)(s.n_spp / 16), s.image_idx, s.depth, s.scramble);
+  const V2 r = cmj_sample(index, scramble);
+  s.depth++;
+  return r;
+}
+
+extern const uint32_t* g_sobol_matrices;  // 1024 x 52, loaded from fredholm_amd/data
+
+// sobol.cu:10661-10671
+inline uint32_t sobol_u32(uint64_t index, uint32_t dimension)
+{
+  uint32_t r = 0;
+  for (uint32_t i = dimension * 52; index; index >>= 1, ++i)
+    if (index & 1) r ^= g_sobol_matrices[i];
+  return r;
+}
+// sobol.cu:10697-10704
+inline uint32_t reverse_bits(uint32_t x)
+{
+  x = ((x & 0xaaaaaaaa) >> 1) | ((x & 0x55555555) << 1);
+  x = ((x & 0xcccccccc) >> 2) | ((x & 0x33333333) << 2);
+  x = ((x & 0xf0f0f0f0) >> 4) | ((x & 0x0f0f0f0f) << 4);
+  x = ((x & 0xff00ff00) >> 8) | ((x & 0x00ff00ff) << 8);
+  return (x >> 16) | (x << 16);
+}
+// sobol.cu:10706-10715
+inline uint32_t laine_karras(uint32_t x, uint32_t seed)
+{
+  x += seed;
+  x ^= x * 0x6c50b47cu;
+  x ^= x * 0xb82f1e52u;
+  x ^= x * 0xc7afe638u;
+  x ^= x * 0x8d22f6e6u;
+  return x;
+}
+inline uint32_t hash_combine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); }  // :10717-10721
+inline uint32_t owen_scramble(uint32_t x, uint32_t seed) { return reverse_bits(laine_karras(reverse_bits(x), seed)); }  // :10724-10731
+
+struct SobolState { uint64_t index; uint32_t dimension, seed; };  // shared.h:71-75
+// sobol.cu:10733-10742 -- note the 64-bit index is truncated to 32 bits by the callee's parameter type
+inline float sobol_owen(SobolState& s)
+{
+  const uint32_t index = owen_scramble((uint32_t)s.index, s.seed);
+  const uint32_t v = owen_scramble(sobol_u32(index, s.dimension), hash_combine(s.seed, s.dimension));
+  const float r = v * (1.0f / (1ULL << 32));
+  s.dimension += 1;
+  return r;
+}
+
+struct Sampler { SobolState sobol; CmjState cmj; };
+inline float sample_1d(Sampler& s) { return sobol_owen(s.sobol); }  // sampling.cu:19-22
+inline V2 sample_2d(Sampler& s) { return cmj_2d(s.cmj); }           // sampling.cu:24-29
+
+// sampling.cu:54-64
+inline V2 concentric_disk(V2 u)
+{
+  const V2 u0 = 2.0f * u - 1.0f;
+  if (u0.x == 0.0f && u0.y == 0.0f) return v2(0.0f);
+  const float r = fabsf(u0.x) > fabsf(u0.y) ? u0.x : u0.y;
+  const float theta = fabsf(u0.x) > fabsf(u0.y) ? 0.25f * kPi * u0.y / u0.x : 0.5f * kPi - 0.25f * kPi * u0.x / u0.y;
+  float s, c;
+  fhe_sincos(theta, &s, &c);
+  return v2(r * c, r * s);
+}
+// sampling.cu:66-78
+inline V3 cosine_hemisphere(V2 u)
+{
+  const V2 d = concentric_disk(u);
+  V3 p;
+  p.x = d.x;
+  p.z = d.y;
+  p.y = sqrtf(fmaxf(0.0f, 1.0f - p.x * p.x - p.z * p.z));
+  return p;
+}
+// sampling.cu:80-84
+inline V2 triangle_barycentric(V2 u)
+{
+  const float su0 = sqrtf(u.x);
+  return v2(1.0f - su0, u.y * su0);
+}
+// sampling.cu:87-110 (Heitz 2018); phi is formed in double (M_PI) and rounded to float
+inline V3 vndf(V3 wo, V2 alpha, V2 u)
+{
+  const V3 Vh = normalize(v3(alpha.x * wo.x, wo.y, alpha.y * wo.z));
+  const float lensq = Vh.x * Vh.x + Vh.z * Vh.z;
+  const V3 T1 = lensq > 0 ? v3(Vh.z, 0, -Vh.x) / sqrtf(lensq) : v3(0, 0, 1);
+  const V3 T2 = cross(Vh, T1);
+  const float r = sqrtf(u.x);
+  const float phi = (float)(2.0f * M_PI * u.y);
+  float sp, cp;
+  fhe_sincos(phi, &sp, &cp);
+  const float t1 = r * cp;
+  float t2 = r * sp;
+  const float s = 0.5f * (1.0f + Vh.y);
+  t2 = (1.0f - s) * sqrtf(fmaxf(1.0f - t1 * t1, 0.0f)) + s * t2;
+  const V3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(1.0f - t1 * t1 - t2 * t2, 0.0f)) * Vh;
+  return normalize(v3(alpha.x * Nh.x, fmaxf(0.0f, Nh.y), alpha.y * Nh.z));
+}
+
+// sampling.cu:112-150
+struct Discrete7 {
+  float cdf[8];
+  void init(const float* w)
+  {
+    float sum = 0.0f;
+    for (int i = 0; i < 7; ++i) sum += w[i];
+    cdf[0] = 0.0f;
+    for (int i = 1; i < 8; ++i) cdf[i] = cdf[i - 1] + w[i - 1] / sum;
+  }
+  int sample(float u, float& pmf) const
+  {
+    float c = 0.0f;
+    for (int i = 1; i <= 7; ++i) {
+      c += cdf[i] - cdf[i - 1];
+      if (u < c) { pmf = cdf[i] - cdf[i - 1]; return i - 1; }
+    }
+    pmf = cdf[7] - cdf[6];
+    return 6;
+  }
+  float pmf(int i) const { return cdf[i + 1] - cdf[i]; }
+};
+
+}  // namespace orc
