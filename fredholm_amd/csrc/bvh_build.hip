@@ -1,0 +1,308 @@
+// bvh_build.hip -- on-device BVH construction.
+//
+// Replaces Renderer::build_gas / build_ias (fredholm/include/fredholm/renderer.h:434-552), i.e. the
+// closed-source optixAccelBuild.  Pipeline, all on the context stream:
+//   1. per-face world-space bounds + scene bounds              (k_face_bounds)
+//   2. 63-bit Morton code of the box centre                    (k_morton)
+//   3. rocPRIM radix sort of (code, face)                      (sort)
+//   4. Karras 2012 radix-tree hierarchy, one thread per node   (k_hierarchy)
+//   5. bottom-up box refit with arrival counters               (k_refit)
+//   6. emit the traversal layout: 64-byte two-child nodes whose children are inner nodes or leaves of
+//      <= 4 Morton-contiguous triangles, and the triangle array in leaf order (k_emit2 / k_emit_tris)
+//   7. collapse to the 8-wide quantised layout the traversal kernels prefer (bvh8 section)
+// Triangle order is the Morton order, so leaf reads are contiguous 48-byte records.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <chrono>
+
+#include "context.h"
+#include "fh_trace.h"
+
+namespace fh {
+
+namespace {
+
+constexpr uint32_t kLeafMax2 = 4;
+
+__device__ __forceinline__ int float_order(float f)
+{
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ __forceinline__ float order_float(int i)
+{
+  const int j = i >= 0 ? i : i ^ 0x7fffffff;
+  float f;
+  memcpy(&f, &j, 4);
+  return f;
+}
+
+// bounds[0..2] = min (ordered ints), bounds[3..5] = max
+__global__ void k_face_bounds(const float4* face_rec, uint32_t n, float4* lo, float4* hi, int* bounds)
+{
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  float l[3] = {3e38f, 3e38f, 3e38f}, h[3] = {-3e38f, -3e38f, -3e38f};
+  if (f < n) {
+    const float4 a = face_rec[7 * f], b = face_rec[7 * f + 1], c = face_rec[7 * f + 2];
+    l[0] = fminf(a.x, fminf(b.x, c.x)); l[1] = fminf(a.y, fminf(b.y, c.y)); l[2] = fminf(a.z, fminf(b.z, c.z));
+    h[0] = fmaxf(a.x, fmaxf(b.x, c.x)); h[1] = fmaxf(a.y, fmaxf(b.y, c.y)); h[2] = fmaxf(a.z, fmaxf(b.z, c.z));
+    lo[f] = make_float4(l[0], l[1], l[2], 0.0f);
+    hi[f] = make_float4(h[0], h[1], h[2], 0.0f);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float mn = l[k], mx = h[k];
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, off));
+      mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&bounds[k], float_order(mn));
+      atomicMax(&bounds[3 + k], float_order(mx));
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long expand21(unsigned long long v)
+{
+  v &= 0x1fffffull;
+  v = (v | v << 32) & 0x1f00000000ffffull;
+  v = (v | v << 16) & 0x1f0000ff0000ffull;
+  v = (v | v << 8) & 0x100f00f00f00f00full;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+  v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+
+__global__ void k_morton(const float4* lo, const float4* hi, uint32_t n, const int* bounds, unsigned long long* keys, uint32_t* vals)
+{
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const float bl[3] = {order_float(bounds[0]), order_float(bounds[1]), order_float(bounds[2])};
+  const float bh[3] = {order_float(bounds[3]), order_float(bounds[4]), order_float(bounds[5])};
+  const float4 l = lo[f], h = hi[f];
+  const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+  unsigned long long q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float ext = bh[k] - bl[k];
+    float x = ext > 0.0f ? (c[k] - bl[k]) / ext : 0.0f;
+    x = fminf(fmaxf(x * 2097152.0f, 0.0f), 2097151.0f);
+    q[k] = (unsigned long long)x;
+  }
+  keys[f] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+  vals[f] = f;
+}
+
+__device__ __forceinline__ int delta(const unsigned long long* keys, int n, int i, int j)
+{
+  if (j < 0 || j >= n) return -1;
+  const unsigned long long x = keys[i] ^ keys[j];
+  if (x == 0ull) return 64 + __clz((unsigned)(i ^ j));
+  return __clzll((long long)x);
+}
+
+// child reference: >= 0 inner node, < 0 leaf (~ref = sorted position)
+__global__ void k_hierarchy(const unsigned long long* keys, int n, int2* children, int2* ranges, int* node_parent, int* leaf_parent)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + min(d, 0);
+  const int first = min(i, j), last = max(i, j);
+  const int left = (first == gamma) ? ~gamma : gamma;
+  const int right = (last == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+  children[i] = make_int2(left, right);
+  ranges[i] = make_int2(first, last);
+  if (left >= 0) node_parent[left] = i; else leaf_parent[~left] = i;
+  if (right >= 0) node_parent[right] = i; else leaf_parent[~right] = i;
+  if (i == 0) node_parent[0] = -1;
+}
+
+__device__ __forceinline__ void child_box(int ref, const float4* node_lo, const float4* node_hi, const float4* leaf_lo, const float4* leaf_hi, float4& lo, float4& hi)
+{
+  if (ref >= 0) { lo = node_lo[ref]; hi = node_hi[ref]; }
+  else { lo = leaf_lo[~ref]; hi = leaf_hi[~ref]; }
+}
+
+// bottom-up refit: the second thread to arrive at a node merges the two child boxes
+__global__ void k_refit(const uint32_t* sorted_face, const float4* face_lo, const float4* face_hi, int n, const int2* children, const int* node_parent, const int* leaf_parent,
+                        float4* node_lo, float4* node_hi, float4* leaf_lo, float4* leaf_hi, unsigned int* arrive)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = sorted_face[i];
+  leaf_lo[i] = face_lo[f];
+  leaf_hi[i] = face_hi[f];
+  int cur = leaf_parent[i];
+  while (cur >= 0) {
+    __threadfence();  // publish this subtree's box before signalling
+    const unsigned int prev = atomicAdd(&arrive[cur], 1u);
+    if (prev == 0u) return;
+    __threadfence();  // see the sibling's box
+    const int2 ch = children[cur];
+    float4 al, ah, bl, bh;
+    child_box(ch.x, node_lo, node_hi, leaf_lo, leaf_hi, al, ah);
+    child_box(ch.y, node_lo, node_hi, leaf_lo, leaf_hi, bl, bh);
+    node_lo[cur] = make_float4(fminf(al.x, bl.x), fminf(al.y, bl.y), fminf(al.z, bl.z), 0.0f);
+    node_hi[cur] = make_float4(fmaxf(ah.x, bh.x), fmaxf(ah.y, bh.y), fmaxf(ah.z, bh.z), 0.0f);
+    cur = node_parent[cur];
+  }
+}
+
+// traversal reference of a radix-tree child: small subtrees become leaves
+__device__ __forceinline__ int emit_ref(int ref, const int2* ranges)
+{
+  if (ref < 0) return ~(int)(((uint32_t)(~ref) << 3) | 0u);
+  const int2 r = ranges[ref];
+  const uint32_t cnt = (uint32_t)(r.y - r.x + 1);
+  if (cnt <= kLeafMax2) return ~(int)(((uint32_t)r.x << 3) | (cnt - 1u));
+  return ref;
+}
+
+__global__ void k_emit2(int n_inner, const int2* children, const int2* ranges, const float4* node_lo, const float4* node_hi, const float4* leaf_lo, const float4* leaf_hi, float pad,
+                        float4* out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_inner) return;
+  const int2 ch = children[i];
+  float4 al, ah, bl, bh;
+  child_box(ch.x, node_lo, node_hi, leaf_lo, leaf_hi, al, ah);
+  child_box(ch.y, node_lo, node_hi, leaf_lo, leaf_hi, bl, bh);
+  const int ra = emit_ref(ch.x, ranges), rb = emit_ref(ch.y, ranges);
+  out[4 * i] = make_float4(al.x - pad, al.y - pad, al.z - pad, ah.x + pad);
+  out[4 * i + 1] = make_float4(ah.y + pad, ah.z + pad, bl.x - pad, bl.y - pad);
+  out[4 * i + 2] = make_float4(bl.z - pad, bh.x + pad, bh.y + pad, bh.z + pad);
+  out[4 * i + 3] = make_float4(__int_as_float(ra), __int_as_float(rb), 0.0f, 0.0f);
+}
+
+// root for scenes with <= kLeafMax2 faces: child 0 is the only leaf, child 1 is an empty box
+__global__ void k_emit2_tiny(int n, const float4* face_lo, const float4* face_hi, float pad, float4* out)
+{
+  float l[3] = {3e38f, 3e38f, 3e38f}, h[3] = {-3e38f, -3e38f, -3e38f};
+  for (int f = 0; f < n; ++f) {
+    l[0] = fminf(l[0], face_lo[f].x); l[1] = fminf(l[1], face_lo[f].y); l[2] = fminf(l[2], face_lo[f].z);
+    h[0] = fmaxf(h[0], face_hi[f].x); h[1] = fmaxf(h[1], face_hi[f].y); h[2] = fmaxf(h[2], face_hi[f].z);
+  }
+  out[0] = make_float4(l[0] - pad, l[1] - pad, l[2] - pad, h[0] + pad);
+  out[1] = make_float4(h[1] + pad, h[2] + pad, 3e38f, 3e38f);
+  out[2] = make_float4(3e38f, 3e38f, 3e38f, 3e38f);  // unreachable point box: every slab test fails
+  const int ra = ~(int)((0u << 3) | (uint32_t)(n - 1));
+  out[3] = make_float4(__int_as_float(ra), __int_as_float(ra), 0.0f, 0.0f);
+}
+
+__global__ void k_emit_tris(const float4* face_rec, const uint32_t* sorted_face, uint32_t n, float4* tris)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = sorted_face[i];
+  const float4 a = face_rec[7 * f], b = face_rec[7 * f + 1], c = face_rec[7 * f + 2];
+  tris[3 * i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
+  tris[3 * i + 1] = make_float4(b.x, b.y, b.z, 0.0f);
+  tris[3 * i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+}  // namespace
+
+int bvh_build_device(fh_ctx* ctx)
+{
+  const auto t_begin = std::chrono::steady_clock::now();
+  hipStream_t st = ctx->stream;
+  const uint32_t n = ctx->n_faces;
+  if (ctx->d_bvh2_nodes) { (void)hipFree(ctx->d_bvh2_nodes); ctx->d_bvh2_nodes = nullptr; }
+  if (ctx->d_bvh2_tris) { (void)hipFree(ctx->d_bvh2_tris); ctx->d_bvh2_tris = nullptr; }
+  ctx->bvh2_n_nodes = ctx->bvh2_n_tris = 0;
+  ctx->bvh_valid = false;
+  if (n == 0) { ctx->bvh_valid = true; return FH_OK; }
+
+  DevBuf<float4> face_lo, face_hi, node_lo, node_hi, leaf_lo, leaf_hi;
+  DevBuf<int> bounds, node_parent, leaf_parent;
+  DevBuf<unsigned long long> keys_a, keys_b;
+  DevBuf<uint32_t> vals_a, vals_b;
+  DevBuf<int2> children, ranges;
+  DevBuf<unsigned int> arrive;
+  FH_HIP(face_lo.alloc(n)); FH_HIP(face_hi.alloc(n));
+  FH_HIP(bounds.alloc(6));
+  const int init_bounds[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  FH_HIP(hipMemcpyAsync(bounds.p, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, st));
+  const uint32_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_face_bounds, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, n, face_lo.p, face_hi.p, bounds.p);
+  int hb[6];
+  FH_HIP(hipMemcpyAsync(hb, bounds.p, sizeof hb, hipMemcpyDeviceToHost, st));
+  FH_HIP(hipStreamSynchronize(st));
+  float maxabs = 0.0f;
+  for (int k = 0; k < 6; ++k) maxabs = fmaxf(maxabs, fabsf(order_float(hb[k])));
+  const float pad = fmaxf(maxabs, 1e-3f) * (1.0f / 65536.0f);
+
+  FH_HIP(hipMalloc((void**)&ctx->d_bvh2_tris, sizeof(float4) * 3ull * n));
+  ctx->bvh2_n_tris = n;
+
+  if (n <= kLeafMax2) {
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh2_nodes, sizeof(float4) * 4));
+    FH_HIP(vals_a.alloc(n));
+    std::vector<uint32_t> ident(n);
+    for (uint32_t i = 0; i < n; ++i) ident[i] = i;
+    FH_HIP(hipMemcpyAsync(vals_a.p, ident.data(), 4ull * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_emit2_tiny, dim3(1), dim3(1), 0, st, (int)n, face_lo.p, face_hi.p, pad, ctx->d_bvh2_nodes);
+    hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, vals_a.p, n, ctx->d_bvh2_tris);
+    FH_HIP(hipStreamSynchronize(st));
+    ctx->bvh2_n_nodes = 1;
+  } else {
+    FH_HIP(keys_a.alloc(n)); FH_HIP(keys_b.alloc(n)); FH_HIP(vals_a.alloc(n)); FH_HIP(vals_b.alloc(n));
+    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, st, face_lo.p, face_hi.p, n, bounds.p, keys_a.p, vals_a.p);
+    size_t temp_bytes = 0;
+    FH_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)n, 0u, 63u, st));
+    DevBuf<char> temp;
+    FH_HIP(temp.alloc(temp_bytes));
+    FH_HIP(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)n, 0u, 63u, st));
+    const uint32_t n_inner = n - 1;
+    FH_HIP(children.alloc(n_inner)); FH_HIP(ranges.alloc(n_inner)); FH_HIP(node_parent.alloc(n_inner)); FH_HIP(leaf_parent.alloc(n));
+    FH_HIP(node_lo.alloc(n_inner)); FH_HIP(node_hi.alloc(n_inner)); FH_HIP(leaf_lo.alloc(n)); FH_HIP(leaf_hi.alloc(n));
+    FH_HIP(arrive.alloc(n_inner));
+    FH_HIP(hipMemsetAsync(arrive.p, 0, 4ull * n_inner, st));
+    const uint32_t iblocks = (n_inner + 255) / 256;
+    hipLaunchKernelGGL(k_hierarchy, dim3(iblocks), dim3(256), 0, st, keys_b.p, (int)n, children.p, ranges.p, node_parent.p, leaf_parent.p);
+    hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, st, vals_b.p, face_lo.p, face_hi.p, (int)n, children.p, node_parent.p, leaf_parent.p, node_lo.p, node_hi.p, leaf_lo.p,
+                       leaf_hi.p, arrive.p);
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh2_nodes, sizeof(float4) * 4ull * n_inner));
+    hipLaunchKernelGGL(k_emit2, dim3(iblocks), dim3(256), 0, st, (int)n_inner, children.p, ranges.p, node_lo.p, node_hi.p, leaf_lo.p, leaf_hi.p, pad, ctx->d_bvh2_nodes);
+    hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, vals_b.p, n, ctx->d_bvh2_tris);
+    FH_HIP(hipGetLastError());
+    FH_HIP(hipStreamSynchronize(st));
+    ctx->bvh2_n_nodes = n_inner;
+  }
+  ctx->bvh_valid = true;
+  ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
+  ctx->stats.bvh_nodes = ctx->bvh2_n_nodes;
+  ctx->stats.bvh_node_bytes = 64ull * ctx->bvh2_n_nodes;
+  ctx->stats.bvh_tri_bytes = 48ull * ctx->bvh2_n_tris;
+  return FH_OK;
+}
+
+}  // namespace fh

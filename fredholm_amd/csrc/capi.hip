@@ -1,0 +1,489 @@
+// capi.hip -- implementation of the C ABI declared in include/fredholm_hip.h (context, scene
+// upload, environment, frame state, stats, device-memory helpers, tile pack/unpack).
+// Mirrors the host duties of fredholm::Renderer (fredholm/include/fredholm/renderer.h).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "context.h"
+#include "fh_bsdf.h"
+#include "fh_trace.h"
+
+// generated at build time from fredholm_amd/data/*.{u32,f32} by tools/gen_tables_inc.py
+#include "gen/tables.inc"
+
+namespace fh {
+
+int fail(fh_ctx* ctx, int code, const std::string& msg)
+{
+  static thread_local std::string g_last;
+  g_last = msg;
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+namespace {
+std::string g_create_error;
+
+m34 load_m34(const float* m)
+{
+  m34 r;
+  for (int k = 0; k < 3; ++k) r.r[k] = make_float4(m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
+  return r;
+}
+const float kIdentity12[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+
+bool material_emissive(const fh_material& m) { return m.emission_color[0] > 0 || m.emission_color[1] > 0 || m.emission_color[2] > 0 || m.emission_texture_id != -1; }
+bool material_textured(const fh_material& m)
+{
+  return m.base_color_texture_id != -1 || m.specular_color_texture_id != -1 || m.specular_roughness_texture_id != -1 || m.metalness_texture_id != -1 ||
+         m.metallic_roughness_texture_id != -1 || m.coat_texture_id != -1 || m.coat_roughness_texture_id != -1 || m.emission_texture_id != -1 || m.heightmap_texture_id != -1 ||
+         m.normalmap_texture_id != -1 || m.alpha_texture_id != -1;
+}
+
+// lobes a material can ever enable (see fh_bsdf.h).  metalness == 1 zeroes the weight and the
+// layering multiplier of every lobe after the metal one, so those lobes are dropped exactly.
+uint32_t material_lobes(const fh_material& m)
+{
+  uint32_t l = 0;
+  const float coat = clampf(m.coat, 0.0f, 1.0f);
+  if (coat > 0.0f) l |= L_COAT;
+  if (m.metalness > 0.0f) l |= L_METAL;
+  const bool metal_full = m.metalness == 1.0f;
+  if (!metal_full) {
+    if (m.specular * lum(mk3(m.specular_color[0], m.specular_color[1], m.specular_color[2])) > 0.0f) l |= L_SPEC;
+    if (m.transmission > 0.0f) l |= L_TRANS;
+    if (m.sheen * lum(mk3(m.sheen_color[0], m.sheen_color[1], m.sheen_color[2])) != 0.0f) l |= L_SHEEN;
+    if (m.subsurface * m.thin_walled > 0.0f) l |= L_DT;
+    if (m.diffuse > 0.0f) l |= L_DIFF;
+  }
+  return l;
+}
+
+// Rebuild everything derived from the flat scene + transforms: face records, classes, lights.
+int rebuild_device_scene(fh_ctx* ctx)
+{
+  const uint32_t nf = (uint32_t)ctx->h_indices.size() / 3;
+  const uint32_t nv = (uint32_t)ctx->h_vertices.size() / 3;
+  const uint32_t nm = (uint32_t)ctx->h_materials.size();
+  const uint32_t ni = (uint32_t)ctx->h_o2w.size() / 12;
+  // classes
+  std::vector<MaterialDev> mats(nm);
+  ctx->n_classes = 0;
+  for (uint32_t i = 0; i < nm; ++i) {
+    static_assert(sizeof(fh_material) == 180, "fh_material must match the reference Material (shared.h:100-142)");
+    std::memcpy(mats[i].w, &ctx->h_materials[i], 180);
+    const uint32_t lobes = material_lobes(ctx->h_materials[i]);
+    mats[i].lobes = lobes;
+    mats[i].emissive = material_emissive(ctx->h_materials[i]) ? 1u : 0u;
+    uint32_t c = 0;
+    for (; c < ctx->n_classes; ++c)
+      if (ctx->class_lobes[c] == lobes) break;
+    if (c == ctx->n_classes) {
+      if (ctx->n_classes < kMaxClasses) ctx->class_lobes[ctx->n_classes++] = lobes;
+      else { c = kMaxClasses - 1; ctx->class_lobes[c] = L_ALL; }  // overflow: fold into one generic class
+    }
+    mats[i].cls = c;
+  }
+  if (ctx->n_classes == kMaxClasses)  // materials folded into the generic class must see the generic mask
+    for (uint32_t i = 0; i < nm; ++i)
+      if (mats[i].cls == kMaxClasses - 1) ctx->class_lobes[kMaxClasses - 1] |= mats[i].lobes;
+
+  std::vector<float4> rec(7ull * nf);
+  std::vector<uint8_t> cls(nf);
+  std::vector<AreaLightDev> lights;
+  for (uint32_t f = 0; f < nf; ++f) {
+    const uint32_t inst = ctx->h_instance_ids.empty() ? 0u : ctx->h_instance_ids[f];
+    if (inst >= ni) return fail(ctx, FH_E_INVALID, "instance id out of range");
+    const m34 o2w = load_m34(&ctx->h_o2w[12ull * inst]), w2o = load_m34(&ctx->h_w2o[12ull * inst]);
+    const uint32_t mid = ctx->h_material_ids[f];
+    if (mid >= nm) return fail(ctx, FH_E_INVALID, "material id out of range");
+    f3 p[3], n[3];
+    float uv[3][2];
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t v = ctx->h_indices[3ull * f + k];
+      if (v >= nv) return fail(ctx, FH_E_INVALID, "vertex index out of range");
+      p[k] = xform_point(o2w, mk3(ctx->h_vertices[3ull * v], ctx->h_vertices[3ull * v + 1], ctx->h_vertices[3ull * v + 2]));
+      n[k] = xform_normal(w2o, mk3(ctx->h_normals[3ull * v], ctx->h_normals[3ull * v + 1], ctx->h_normals[3ull * v + 2]));
+      uv[k][0] = ctx->h_texcoords[2ull * v];
+      uv[k][1] = ctx->h_texcoords[2ull * v + 1];
+    }
+    float4* r = &rec[7ull * f];
+    r[0] = mk4(p[0], uv[0][0]); r[1] = mk4(p[1], uv[0][1]); r[2] = mk4(p[2], uv[1][0]);
+    r[3] = mk4(n[0], uv[1][1]); r[4] = mk4(n[1], uv[2][0]); r[5] = mk4(n[2], uv[2][1]);
+    uint32_t midbits = mid, instbits = inst;
+    float a, b;
+    std::memcpy(&a, &midbits, 4);
+    std::memcpy(&b, &instbits, 4);
+    r[6] = make_float4(a, b, 0.0f, 0.0f);
+    cls[f] = (uint8_t)(mats[mid].cls | (mats[mid].emissive ? 0x80u : 0u));
+    if (mats[mid].emissive) lights.push_back({f, mid});  // renderer.h:388-402, face order
+  }
+  auto re_alloc = [&](auto*& ptr, size_t bytes) -> hipError_t {
+    if (ptr) { (void)hipFree(ptr); ptr = nullptr; }
+    return hipMalloc((void**)&ptr, bytes ? bytes : 16);
+  };
+  FH_HIP(re_alloc(ctx->d_face_rec, rec.size() * sizeof(float4)));
+  FH_HIP(re_alloc(ctx->d_face_cls, cls.size()));
+  FH_HIP(re_alloc(ctx->d_materials, mats.size() * sizeof(MaterialDev)));
+  FH_HIP(re_alloc(ctx->d_lights, lights.size() * sizeof(AreaLightDev)));
+  FH_HIP(hipMemcpy(ctx->d_face_rec, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+  FH_HIP(hipMemcpy(ctx->d_face_cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
+  FH_HIP(hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
+  if (!lights.empty()) FH_HIP(hipMemcpy(ctx->d_lights, lights.data(), lights.size() * sizeof(AreaLightDev), hipMemcpyHostToDevice));
+  ctx->n_faces = nf;
+  ctx->n_lights = (uint32_t)lights.size();
+  ctx->n_materials = nm;
+  ctx->bvh_valid = false;
+  return FH_OK;
+}
+
+int rebuild_ownership(fh_ctx* ctx)
+{
+  if (ctx->d_owned) { (void)hipFree(ctx->d_owned); ctx->d_owned = nullptr; }
+  ctx->n_owned = 0;
+  if (ctx->width == 0 || ctx->height == 0) return FH_OK;
+  std::vector<uint32_t> owned;
+  const uint32_t tw = ctx->tile_w, th = ctx->tile_h;
+  const uint32_t tx = (ctx->width + tw - 1) / tw, ty = (ctx->height + th - 1) / th;
+  for (uint32_t t = 0; t < tx * ty; ++t) {
+    if (t % ctx->shard_world != ctx->shard_rank) continue;
+    const uint32_t x0 = (t % tx) * tw, y0 = (t / tx) * th;
+    for (uint32_t y = y0; y < y0 + th && y < ctx->height; ++y)
+      for (uint32_t x = x0; x < x0 + tw && x < ctx->width; ++x) owned.push_back(x + ctx->width * y);
+  }
+  ctx->n_owned = (uint32_t)owned.size();
+  FH_HIP(hipMalloc((void**)&ctx->d_owned, owned.empty() ? 16 : owned.size() * 4));
+  if (!owned.empty()) FH_HIP(hipMemcpy(ctx->d_owned, owned.data(), owned.size() * 4, hipMemcpyHostToDevice));
+  return FH_OK;
+}
+
+__global__ void k_pack(const float* layer, const uint32_t* owned, uint32_t n, uint32_t fpp, float* packed)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n * fpp; i += gridDim.x * blockDim.x) packed[i] = layer[(size_t)owned[i / fpp] * fpp + i % fpp];
+}
+__global__ void k_unpack(const float* packed, const uint32_t* owned, uint32_t n, uint32_t fpp, float* layer)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n * fpp; i += gridDim.x * blockDim.x) layer[(size_t)owned[i / fpp] * fpp + i % fpp] = packed[i];
+}
+
+}  // namespace
+}  // namespace fh
+
+using namespace fh;
+
+#define CTX_CHECK(ctx)                      \
+  if (!(ctx)) return FH_E_INVALID;          \
+  if (hipSetDevice((ctx)->device) != hipSuccess) return fh::fail(ctx, FH_E_HIP, "hipSetDevice failed")
+
+extern "C" {
+
+int fh_ctx_create(int device, fh_ctx** out)
+{
+  if (!out) return FH_E_INVALID;
+  *out = nullptr;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { g_create_error = "no HIP device available: the fredholm HIP path has no CPU fallback"; return FH_E_HIP; }
+  if (device < 0 || device >= n_dev) { g_create_error = "device index out of range"; return FH_E_INVALID; }
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return FH_E_HIP; }
+  fh_ctx* ctx = new fh_ctx;
+  ctx->device = device;
+  auto bail = [&](const char* what) { g_create_error = what; delete ctx; return FH_E_HIP; };
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+  if (hipMalloc((void**)&ctx->d_sobol, kSobolMatricesBytes) != hipSuccess) return bail("hipMalloc failed");
+  if (hipMalloc((void**)&ctx->d_lut_refl, kLutReflectionBytes) != hipSuccess) return bail("hipMalloc failed");
+  if (hipMalloc((void**)&ctx->d_lut_sheen, kLutSheenBytes) != hipSuccess) return bail("hipMalloc failed");
+  if (hipMalloc((void**)&ctx->d_trace_counters, 4 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
+  if (hipMemcpy(ctx->d_sobol, kSobolMatrices, kSobolMatricesBytes, hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
+  (void)hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice);
+  (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
+  (void)hipMemset(ctx->d_trace_counters, 0, 4 * sizeof(unsigned long long));
+  (void)hipEventCreate(&ctx->ev_render_begin);
+  (void)hipEventCreate(&ctx->ev_render_end);
+  *out = ctx;
+  return FH_OK;
+}
+
+int fh_ctx_destroy(fh_ctx* ctx)
+{
+  if (!ctx) return FH_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  pool_release(ctx);
+  void* ptrs[] = {ctx->d_sobol, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
+                  ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(ctx->ev_render_begin);
+  (void)hipEventDestroy(ctx->ev_render_end);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return FH_OK;
+}
+
+const char* fh_last_error(fh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int fh_set_flags(fh_ctx* ctx, uint32_t flags)
+{
+  CTX_CHECK(ctx);
+  ctx->flags = flags;
+  return FH_OK;
+}
+
+int fh_scene_upload(fh_ctx* ctx, const fh_scene_desc* s)
+{
+  CTX_CHECK(ctx);
+  if (!s || !s->vertices || !s->normals || !s->texcoords || !s->indices || !s->material_ids || !s->materials || s->n_materials == 0)
+    return fail(ctx, FH_E_INVALID, "fh_scene_upload: missing arrays");
+  for (uint32_t i = 0; i < s->n_materials; ++i)
+    if (material_textured(s->materials[i])) return fail(ctx, FH_E_UNSUPPORTED, "fh_scene_upload: textured materials are not supported in this build (all *_texture_id must be -1)");
+  ctx->h_vertices.assign(s->vertices, s->vertices + 3ull * s->n_vertices);
+  ctx->h_normals.assign(s->normals, s->normals + 3ull * s->n_vertices);
+  ctx->h_texcoords.assign(s->texcoords, s->texcoords + 2ull * s->n_vertices);
+  ctx->h_indices.assign(s->indices, s->indices + 3ull * s->n_faces);
+  ctx->h_material_ids.assign(s->material_ids, s->material_ids + s->n_faces);
+  if (s->instance_ids) ctx->h_instance_ids.assign(s->instance_ids, s->instance_ids + s->n_faces);
+  else ctx->h_instance_ids.clear();
+  ctx->h_materials.assign(s->materials, s->materials + s->n_materials);
+  if (s->n_instances && s->object_to_world && s->world_to_object) {
+    ctx->h_o2w.assign(s->object_to_world, s->object_to_world + 12ull * s->n_instances);
+    ctx->h_w2o.assign(s->world_to_object, s->world_to_object + 12ull * s->n_instances);
+  } else {
+    ctx->h_o2w.assign(kIdentity12, kIdentity12 + 12);
+    ctx->h_w2o.assign(kIdentity12, kIdentity12 + 12);
+  }
+  const int rc = rebuild_device_scene(ctx);
+  if (rc) return rc;
+  ctx->scene_loaded = true;
+  return FH_OK;
+}
+
+int fh_set_transforms(fh_ctx* ctx, uint32_t n, const float* o2w, const float* w2o)
+{
+  CTX_CHECK(ctx);
+  if (!ctx->scene_loaded || !o2w || !w2o || n == 0) return fail(ctx, FH_E_INVALID, "fh_set_transforms: no scene / null arrays");
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->h_o2w.assign(o2w, o2w + 12ull * n);
+  ctx->h_w2o.assign(w2o, w2o + 12ull * n);
+  return rebuild_device_scene(ctx);
+}
+
+int fh_bvh_build(fh_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  if (!ctx->scene_loaded) return fail(ctx, FH_E_INVALID, "fh_bvh_build: no scene");
+  return bvh_build_device(ctx);
+}
+
+int fh_scene_n_lights(fh_ctx* ctx, uint32_t* out)
+{
+  CTX_CHECK(ctx);
+  if (!out) return FH_E_INVALID;
+  *out = ctx->n_lights;
+  return FH_OK;
+}
+
+int fh_set_directional_light(fh_ctx* ctx, const float* le, const float* dir, float angle)
+{
+  CTX_CHECK(ctx);
+  if (!le || !dir) return FH_E_INVALID;
+  const f3 d = normalize(mk3(dir[0], dir[1], dir[2]));  // renderer.h:560
+  ctx->has_dir = true;
+  for (int k = 0; k < 3; ++k) ctx->dir_le[k] = le[k];
+  ctx->dir_dir[0] = d.x; ctx->dir_dir[1] = d.y; ctx->dir_dir[2] = d.z;
+  ctx->sun_dir[0] = d.x; ctx->sun_dir[1] = d.y; ctx->sun_dir[2] = d.z;  // renderer.h:563
+  ctx->dir_angle = angle;
+  return FH_OK;
+}
+int fh_clear_directional_light(fh_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  ctx->has_dir = false;
+  return FH_OK;
+}
+int fh_set_sky_intensity(fh_ctx* ctx, float v)
+{
+  CTX_CHECK(ctx);
+  ctx->sky_intensity = v;
+  return FH_OK;
+}
+int fh_load_arhosek_sky(fh_ctx* ctx, float turbidity, float albedo)
+{
+  CTX_CHECK(ctx);
+  if (!(turbidity >= 1.0f && turbidity <= 10.0f)) return fail(ctx, FH_E_INVALID, "turbidity must be in [1,10]");
+  const float elevation = (float)(0.5f * 3.14159265358979323846 - fhe_acos(clampf(ctx->sun_dir[1], -1.0f, 1.0f)));  // renderer.h:592-601
+  ctx->hosek = hosek_cook(kHosekRgb, turbidity, albedo, elevation);
+  ctx->has_hosek = true;
+  return FH_OK;
+}
+int fh_clear_arhosek_sky(fh_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  ctx->has_hosek = false;
+  return FH_OK;
+}
+int fh_load_ibl(fh_ctx* ctx, const float*, uint32_t, uint32_t) { return fail(ctx, FH_E_UNSUPPORTED, "image-based lighting is not supported in this build"); }
+
+int fh_init_render_states(fh_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  if (!ctx->d_sample_count) return fail(ctx, FH_E_INVALID, "resolution not set");
+  FH_HIP(hipMemsetAsync(ctx->d_sample_count, 0, 4ull * ctx->width * ctx->height, ctx->stream));
+  return FH_OK;
+}
+
+int fh_set_resolution(fh_ctx* ctx, uint32_t w, uint32_t h)
+{
+  CTX_CHECK(ctx);
+  if (w == 0 || h == 0) return fail(ctx, FH_E_INVALID, "zero resolution");
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_sample_count) { (void)hipFree(ctx->d_sample_count); ctx->d_sample_count = nullptr; }
+  ctx->width = w; ctx->height = h;
+  FH_HIP(hipMalloc((void**)&ctx->d_sample_count, 4ull * w * h));
+  const int rc = rebuild_ownership(ctx);
+  if (rc) return rc;
+  return fh_init_render_states(ctx);
+}
+
+int fh_set_tile_shard(fh_ctx* ctx, uint32_t rank, uint32_t world, uint32_t tw, uint32_t th)
+{
+  CTX_CHECK(ctx);
+  if (world == 0 || rank >= world || tw == 0 || th == 0) return fail(ctx, FH_E_INVALID, "bad shard");
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->shard_rank = rank; ctx->shard_world = world; ctx->tile_w = tw; ctx->tile_h = th;
+  return rebuild_ownership(ctx);
+}
+
+int fh_owned_pixel_count(fh_ctx* ctx, uint32_t* out)
+{
+  CTX_CHECK(ctx);
+  if (!out) return FH_E_INVALID;
+  *out = ctx->n_owned;
+  return FH_OK;
+}
+
+int fh_pack_owned(fh_ctx* ctx, const float* layer, uint32_t fpp, float* packed)
+{
+  CTX_CHECK(ctx);
+  if (!layer || !packed || fpp == 0) return FH_E_INVALID;
+  if (ctx->n_owned) hipLaunchKernelGGL(k_pack, dim3((ctx->n_owned * fpp + 255) / 256), dim3(256), 0, ctx->stream, layer, ctx->d_owned, ctx->n_owned, fpp, packed);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+int fh_unpack_shard(fh_ctx* ctx, uint32_t rank, uint32_t world, const float* packed, uint32_t fpp, float* layer)
+{
+  CTX_CHECK(ctx);
+  if (!layer || !packed || fpp == 0 || world == 0 || rank >= world) return FH_E_INVALID;
+  // ownership list of (rank, world) with this context's tile size and resolution
+  fh_ctx tmp;
+  tmp.device = ctx->device; tmp.width = ctx->width; tmp.height = ctx->height; tmp.tile_w = ctx->tile_w; tmp.tile_h = ctx->tile_h; tmp.shard_rank = rank; tmp.shard_world = world;
+  const int rc = rebuild_ownership(&tmp);
+  if (rc) { ctx->err = tmp.err; return rc; }
+  if (tmp.n_owned) hipLaunchKernelGGL(k_unpack, dim3((tmp.n_owned * fpp + 255) / 256), dim3(256), 0, ctx->stream, packed, tmp.d_owned, tmp.n_owned, fpp, layer);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (tmp.d_owned) (void)hipFree(tmp.d_owned);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+int fh_render(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_render_layers* layers, uint32_t n_samples, uint32_t max_depth, uint32_t seed)
+{
+  CTX_CHECK(ctx);
+  if (!cam || !bg || !layers || !layers->beauty || !layers->position || !layers->depth || !layers->normal || !layers->texcoord || !layers->albedo)
+    return fail(ctx, FH_E_INVALID, "fh_render: null argument");
+  return render_submit(ctx, cam, bg, layers, n_samples, max_depth, seed);
+}
+
+int fh_sync(fh_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  if (ctx->render_pending) (void)hipEventRecord(ctx->ev_render_end, ctx->stream);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->render_pending) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev_render_begin, ctx->ev_render_end) == hipSuccess) ctx->stats.render_ms += ms;
+    ctx->render_pending = false;
+  }
+  for (auto& s : ctx->spans) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      if (s.kind == 0) ctx->stats.trace_closest_ms += ms;
+      else if (s.kind == 1) ctx->stats.trace_shadow_ms += ms;
+      else ctx->stats.shade_ms += ms;
+    }
+    ctx->event_pool.push_back(s.a);
+    ctx->event_pool.push_back(s.b);
+  }
+  ctx->spans.clear();
+  if (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) {
+    unsigned long long c[4];
+    FH_HIP(hipMemcpy(c, ctx->d_trace_counters, sizeof c, hipMemcpyDeviceToHost));
+    ctx->stats.nodes_closest = c[0]; ctx->stats.tris_closest = c[1]; ctx->stats.nodes_shadow = c[2]; ctx->stats.tris_shadow = c[3];
+  }
+  return FH_OK;
+}
+
+int fh_get_stats(fh_ctx* ctx, fh_stats* out)
+{
+  CTX_CHECK(ctx);
+  if (!out) return FH_E_INVALID;
+  *out = ctx->stats;
+  return FH_OK;
+}
+int fh_reset_stats(fh_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  const double build_ms = ctx->stats.bvh_build_ms;
+  const uint64_t nodes = ctx->stats.bvh_nodes, nb = ctx->stats.bvh_node_bytes, tb = ctx->stats.bvh_tri_bytes;
+  ctx->stats = fh_stats{};
+  ctx->stats.bvh_build_ms = build_ms; ctx->stats.bvh_nodes = nodes; ctx->stats.bvh_node_bytes = nb; ctx->stats.bvh_tri_bytes = tb;
+  FH_HIP(hipMemsetAsync(ctx->d_trace_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  return FH_OK;
+}
+
+int fh_post_process(fh_ctx* ctx, const float* in, float* hi, float* tmp, int w, int h, const fh_post_params* pp, float* out)
+{
+  CTX_CHECK(ctx);
+  if (!in || !hi || !tmp || !out || !pp || w <= 0 || h <= 0) return fail(ctx, FH_E_INVALID, "fh_post_process: bad argument");
+  return post_process_submit(ctx, in, hi, tmp, w, h, pp, out);
+}
+
+int fh_malloc(fh_ctx* ctx, uint64_t bytes, void** out)
+{
+  CTX_CHECK(ctx);
+  if (!out) return FH_E_INVALID;
+  FH_HIP(hipMalloc(out, bytes ? bytes : 16));
+  return FH_OK;
+}
+int fh_free(fh_ctx* ctx, void* p)
+{
+  CTX_CHECK(ctx);
+  FH_HIP(hipFree(p));
+  return FH_OK;
+}
+int fh_memset(fh_ctx* ctx, void* p, int v, uint64_t bytes)
+{
+  CTX_CHECK(ctx);
+  FH_HIP(hipMemsetAsync(p, v, bytes, ctx->stream));
+  return FH_OK;
+}
+int fh_copy_to_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+  CTX_CHECK(ctx);
+  FH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  return FH_OK;
+}
+int fh_copy_to_host(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+  CTX_CHECK(ctx);
+  FH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  return FH_OK;
+}
+void* fh_stream(fh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+}  // extern "C"

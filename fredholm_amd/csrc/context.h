@@ -1,0 +1,94 @@
+// context.h -- host-side state behind the opaque fh_ctx of include/fredholm_hip.h.
+// Plays the role of the reference's Renderer members (fredholm/include/fredholm/renderer.h:739-828):
+// scene buffers, acceleration structure, lights, environment state, sample-count buffer, stream.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/fredholm_hip.h"
+#include "fh_device.h"
+
+struct fh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  uint32_t flags = 0;
+
+  // constant tables
+  uint32_t* d_sobol = nullptr;
+  float* d_lut_refl = nullptr;
+  float* d_lut_sheen = nullptr;
+
+  // host copy of the flat scene (transforms can change: Renderer::set_time)
+  std::vector<float> h_vertices, h_normals, h_texcoords;
+  std::vector<uint32_t> h_indices, h_material_ids, h_instance_ids;
+  std::vector<fh_material> h_materials;
+  std::vector<float> h_o2w, h_w2o;  // 12 floats per instance
+  bool scene_loaded = false, bvh_valid = false;
+
+  // device scene
+  float4* d_face_rec = nullptr;
+  uint8_t* d_face_cls = nullptr;
+  fh::MaterialDev* d_materials = nullptr;
+  fh::AreaLightDev* d_lights = nullptr;
+  uint32_t n_faces = 0, n_lights = 0, n_materials = 0;
+  uint32_t n_classes = 0;
+  uint32_t class_lobes[fh::kMaxClasses] = {};
+
+  // BVH
+  float4* d_bvh2_nodes = nullptr;
+  float4* d_bvh2_tris = nullptr;
+  uint32_t bvh2_n_nodes = 0, bvh2_n_tris = 0;
+  uint4* d_bvh8_nodes = nullptr;
+  float4* d_bvh8_tris = nullptr;
+  uint32_t bvh8_n_nodes = 0, bvh8_n_tris = 0;
+  bool use_bvh8 = false;
+  double bvh_build_ms = 0.0;
+
+  // frame state
+  uint32_t width = 0, height = 0;
+  uint32_t* d_sample_count = nullptr;
+  uint32_t shard_rank = 0, shard_world = 1, tile_w = 32, tile_h = 32;
+  uint32_t* d_owned = nullptr;  // image indices of owned pixels, in tile order
+  uint32_t n_owned = 0;
+
+  // environment (renderer.h:819-827)
+  bool has_dir = false;
+  float dir_le[3] = {0, 0, 0}, dir_dir[3] = {0, 1, 0}, dir_angle = 0;
+  float sky_intensity = 1.0f;
+  float sun_dir[3] = {0.0f, 1.0f, 0.0f};
+  bool has_hosek = false;
+  fh::HosekSky hosek{};
+
+  // path pool
+  fh::PoolDev pool{};
+  std::vector<void*> pool_allocs;
+  uint32_t pool_target = 1u << 22;
+
+  // stats
+  fh_stats stats{};
+  unsigned long long* d_trace_counters = nullptr;  // nodes_closest, tris_closest, nodes_shadow, tris_shadow
+  struct TimedSpan { hipEvent_t a, b; int kind; };
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> event_pool;
+  hipEvent_t ev_render_begin = nullptr, ev_render_end = nullptr;
+  bool render_pending = false;
+};
+
+namespace fh {
+int fail(fh_ctx* ctx, int code, const std::string& msg);
+#define FH_HIP(call)                                                                                                   \
+  do {                                                                                                                 \
+    hipError_t e_ = (call);                                                                                            \
+    if (e_ != hipSuccess) return fh::fail(ctx, FH_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+SceneDev scene_dev(const fh_ctx* ctx);
+int bvh_build_device(fh_ctx* ctx);                 // bvh_build.hip
+int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_render_layers* layers, uint32_t n_samples, uint32_t max_depth, uint32_t seed);  // render.hip
+int pool_ensure(fh_ctx* ctx, uint32_t capacity);   // render.hip
+void pool_release(fh_ctx* ctx);
+int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int w, int h, const fh_post_params* pp, float* out);  // post.hip
+}  // namespace fh

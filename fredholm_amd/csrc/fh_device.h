@@ -1,0 +1,133 @@
+// fh_device.h -- device-visible data layout of the wavefront path tracer (all plain structs passed
+// to kernels by value as kernel arguments).
+//
+// HBM layout:
+//   face records   7 x float4 per face, face-indexed, world space (positions, inverse-transpose
+//                  normals, uvs, material id) -- what fill_surface_info (pt.cu:141-179) gathers
+//                  through three index/vertex/normal/texcoord arrays becomes one 112-byte record.
+//   BVH            wide nodes + leaf triangles in traversal order (fh_trace.h).
+//   path pool      structure-of-arrays indexed by path slot p (one slot per camera path of the pass).
+//   queues         uint32 path-slot lists with device-resident counters; no host readback inside a frame.
+#pragma once
+#include "fh_sky.h"
+#include "fh_vec.h"
+
+namespace fh {
+
+constexpr uint32_t kMaxClasses = 8;       // shading classes (distinct lobe masks) per scene
+constexpr uint32_t kMissClass = kMaxClasses;  // queue id used for primary misses
+constexpr uint32_t kNumQueues = kMaxClasses + 1;
+
+// secondary-ray slots per shaded path, in the reference's evaluation order (pt.cu:772-925)
+enum : uint32_t { SEC_DIR = 0, SEC_SKY = 1, SEC_AREA = 2, SEC_LIGHT = 3, SEC_COUNT = 4 };
+
+struct BsdfTables { const float* reflection; const float* sheen; };  // 16x16x2 and 16x16 floats (lut.cu:5-93, :917-955)
+
+struct MaterialDev {  // 180-byte reference record + derived words
+  float w[45];
+  uint32_t lobes;     // lobe mask of this material (fh_bsdf.h)
+  uint32_t emissive;  // has_emission (pt.cu:125-129)
+  uint32_t cls;       // shading class index
+};
+
+struct AreaLightDev { uint32_t face; uint32_t material; };
+
+struct Bvh2Dev {
+  const float4* nodes;  // 4 x float4 per node (two child boxes + two child refs)
+  const float4* tris;   // 3 x float4 per leaf triangle, traversal order; tris[3i].w = face id bits
+  uint32_t n_nodes;
+  uint32_t n_tris;
+};
+
+// wide BVH (8 children, quantised boxes), see fh_trace.h
+struct Bvh8Dev {
+  const uint4* nodes;   // 5 x uint4 (80 bytes) per node
+  const float4* tris;   // 3 x float4 per leaf triangle, grouped per node
+  uint32_t n_nodes;
+  uint32_t n_tris;
+};
+
+struct SceneDev {
+  const float4* face_rec;       // 7 per face
+  const uint8_t* face_cls;      // shading class of the face's material | 0x80 if emissive
+  const MaterialDev* materials;
+  const AreaLightDev* lights;
+  uint32_t n_faces, n_lights;
+  Bvh2Dev bvh2;
+  Bvh8Dev bvh8;
+  uint32_t use_bvh8;
+};
+
+struct FrameDev {
+  uint32_t width, height;
+  uint32_t seed_hash;  // xxhash32(seed), used as Sobol seed and CMJ scramble (pt.cu:388,393)
+  uint32_t max_depth;
+  uint32_t has_dir, has_hosek;
+  uint32_t n1, n2;     // Sobol dimensions / CMJ slots consumed per shaded bounce
+  // camera (camera.cu:24-53)
+  m34 cam_xf;
+  float cam_inv_tan, cam_F, cam_focus;
+  // environment
+  f3 bg;
+  float sky_intensity;
+  f3 sun_dir;
+  HosekSky hosek;
+  f3 dir_le, dir_dir;
+  float dir_disk_radius;  // 1e9 * tan(rad(angle/2)), pt.cu:333-335
+  // tables
+  const uint32_t* sobol;  // 1024 x 52
+  BsdfTables lut;
+};
+
+struct PoolDev {
+  uint32_t capacity;
+  float4* ray_o;  // origin.xyz, tmax
+  float4* ray_d;  // direction.xyz, -
+  float4* thr;    // throughput.xyz, -
+  float4* rad;    // radiance.xyz, -
+  float4* hit;    // t, u, v, face id bits (0xffffffff = miss)
+  uint32_t* pixel;
+  uint32_t* nspp;
+  uint32_t* flags;  // bit0: first-hit AOVs valid
+  // first-hit AOV staging (pt.cu:745-751)
+  float4* aov_position;
+  float4* aov_normal;
+  float4* aov_albedo;
+  float4* aov_texdepth;  // texcoord.xy, depth, -
+  // secondary rays, [slot * capacity + p]
+  float4* sec_o;  // origin.xyz, tmax
+  float4* sec_d;  // direction.xyz, active (1.0f) / inactive (0.0f)
+  float4* sec_c;  // contribution rgb if unoccluded
+  // BSDF-sampled light ray when the scene has emitters (needs the hit to finish the MIS weight)
+  float4* lp_a;   // throughput.xyz, |cos|
+  float4* lp_b;   // f.xyz, pdf
+  // queues
+  uint32_t* q_rad[2];            // radiance-ray queue, ping-pong per bounce
+  uint32_t* q_cls;               // kNumQueues x capacity: hits routed by shading class (+ primary misses)
+  uint32_t* q_sec;               // shaded paths with secondary rays
+  uint32_t* counters;            // [0..1] q_rad, [2] q_sec, [3 .. 3+kNumQueues) class queues, then work cursors
+};
+enum : uint32_t { CNT_RAD0 = 0, CNT_RAD1 = 1, CNT_SEC = 2, CNT_CLS = 3, CNT_CURSOR = CNT_CLS + kNumQueues, CNT_TOTAL = CNT_CURSOR + 4 };
+
+struct LayersDev {
+  float4* beauty; float4* position; float* depth; float4* normal; float4* texcoord; float4* albedo;
+  uint32_t* sample_count;
+};
+
+// traversal statistics (only written by the instrumented kernel variants)
+struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; };
+
+// ---- wave-aggregated queue append: one atomic per wave (ballot + popcount prefix)
+FH_D void queue_push(uint32_t* counter, uint32_t* queue, bool active, uint32_t value)
+{
+  const unsigned long long mask = __ballot(active);
+  if (mask == 0ull) return;
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (active) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+}  // namespace fh

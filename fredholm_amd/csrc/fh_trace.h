@@ -1,0 +1,146 @@
+// fh_trace.h -- ray / BVH traversal and ray / triangle intersection (device code).
+//
+// Replaces what the reference delegates to the closed-source OptiX runtime: optixTrace for the
+// three ray classes (fredholm/modules/pt.cu:82-123) over the GAS/IAS built in
+// fredholm/include/fredholm/renderer.h:434-552.  Semantics kept: tmin = 0, no culling, closest hit
+// for RADIANCE/LIGHT rays, first hit terminates SHADOW rays, hit attributes (u,v) weight v1,v2.
+//
+// Triangle test: watertight test of Woop, Benthin, Wald (JCGT 2013) -- OptiX's built-in triangle
+// test is watertight too.  Equal-t ties resolve to the lowest face id, which makes the closest
+// hit independent of BVH shape and traversal order (needed for seam-free multi-GPU tiling and for
+// exact comparison with the CPU checker, which uses a different BVH).  Box tests are conservative
+// (boxes padded at build time, far distance inflated), so no accepted triangle is ever culled.
+#pragma once
+#include "fh_device.h"
+
+namespace fh {
+
+struct RayPre {
+  f3 o;        // origin
+  f3 inv;      // 1 / direction (zero components replaced by +-1e-20)
+  float Sx, Sy, Sz;
+  int kx, ky, kz;
+};
+
+FH_D float comp(f3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+FH_D RayPre ray_prepare(f3 o, f3 d)
+{
+  RayPre r;
+  r.o = o;
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  r.kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+  r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0;
+  r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0;
+  if (comp(d, r.kz) < 0.0f) { const int t = r.kx; r.kx = r.ky; r.ky = t; }
+  const float dz = comp(d, r.kz);
+  r.Sx = comp(d, r.kx) / dz;
+  r.Sy = comp(d, r.ky) / dz;
+  r.Sz = 1.0f / dz;
+  r.inv = mk3(1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x), 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y),
+              1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z));
+  return r;
+}
+
+// returns true with t >= 0 and barycentrics (bu, bv) of v1, v2
+FH_D bool tri_test(const RayPre& r, f3 p0, f3 p1, f3 p2, float& t, float& bu, float& bv)
+{
+  const f3 A = p0 - r.o, B = p1 - r.o, C = p2 - r.o;
+  const float Akz = comp(A, r.kz), Bkz = comp(B, r.kz), Ckz = comp(C, r.kz);
+  const float Ax = fmaf(-r.Sx, Akz, comp(A, r.kx)), Ay = fmaf(-r.Sy, Akz, comp(A, r.ky));
+  const float Bx = fmaf(-r.Sx, Bkz, comp(B, r.kx)), By = fmaf(-r.Sy, Bkz, comp(B, r.ky));
+  const float Cx = fmaf(-r.Sx, Ckz, comp(C, r.kx)), Cy = fmaf(-r.Sy, Ckz, comp(C, r.ky));
+  float U = Cx * By - Cy * Bx;
+  float V = Ax * Cy - Ay * Cx;
+  float W = Bx * Ay - By * Ax;
+  if (U == 0.0f || V == 0.0f || W == 0.0f) {  // edge-on: redo the edge functions in fp64
+    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+  }
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+  const float det = U + V + W;
+  if (det == 0.0f) return false;
+  const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+  const float T = fmaf(W, Cz, fmaf(V, Bz, U * Az));
+  const float rcp = 1.0f / det;
+  t = T * rcp;
+  if (!(t >= 0.0f)) return false;
+  bu = V * rcp;
+  bv = W * rcp;
+  return true;
+}
+
+struct HitRec { float t, u, v; uint32_t prim; };
+
+// conservative slab test against (lo, hi); returns entry distance in tn
+FH_D bool slab_test(const RayPre& r, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmax, float& tn)
+{
+  float t0 = (lox - r.o.x) * r.inv.x, t1 = (hix - r.o.x) * r.inv.x;
+  float tnr = fminf(t0, t1), tf = fmaxf(t0, t1);
+  t0 = (loy - r.o.y) * r.inv.y; t1 = (hiy - r.o.y) * r.inv.y;
+  tnr = fmaxf(tnr, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  t0 = (loz - r.o.z) * r.inv.z; t1 = (hiz - r.o.z) * r.inv.z;
+  tnr = fmaxf(tnr, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  tf *= 1.000001f;
+  tn = tnr;
+  return tnr <= tf && tf >= 0.0f && tnr <= tmax;
+}
+
+// accept a candidate under the closest-hit order (t, then face id)
+FH_D bool closer(float t, uint32_t prim, const HitRec& best) { return t < best.t || (t == best.t && prim < best.prim); }
+
+// ---------------------------------------------------------------------------------------------
+// BVH2 (one 64-byte node = both child boxes + both child references).  Child reference >= 0:
+// inner node index; < 0: leaf, ~ref = (first_triangle << 3) | (count - 1).
+// ---------------------------------------------------------------------------------------------
+constexpr int kBvh2Stack = 96;
+
+template <bool ANY_HIT, bool COUNT>
+FH_D bool traverse_bvh2(const Bvh2Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris)
+{
+  best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu;
+  if (bvh.n_nodes == 0) return false;
+  const RayPre r = ray_prepare(o, d);
+  int stack[kBvh2Stack];
+  int sp = 0;
+  int cur = 0;
+  bool found = false;
+  for (;;) {
+    if (cur >= 0) {
+      const float4 n0 = bvh.nodes[4 * cur], n1 = bvh.nodes[4 * cur + 1], n2 = bvh.nodes[4 * cur + 2], n3 = bvh.nodes[4 * cur + 3];
+      if (COUNT) n_nodes++;
+      float ta, tb;
+      const bool ha = slab_test(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, best.t, ta);
+      const bool hb = slab_test(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, best.t, tb);
+      const int ca = __float_as_int(n3.x), cb = __float_as_int(n3.y);
+      if (ha && hb) {
+        const bool a_first = ta <= tb;
+        cur = a_first ? ca : cb;
+        if (sp < kBvh2Stack) stack[sp++] = a_first ? cb : ca;
+      } else if (ha) cur = ca;
+      else if (hb) cur = cb;
+      else { if (sp == 0) break; cur = stack[--sp]; }
+    } else {
+      const uint32_t ref = (uint32_t)~cur;
+      const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+      for (uint32_t i = first; i < first + count; ++i) {
+        const float4 a = bvh.tris[3 * i], b = bvh.tris[3 * i + 1], c = bvh.tris[3 * i + 2];
+        if (COUNT) n_tris++;
+        float t, bu, bv;
+        if (!tri_test(r, mk3(a), mk3(b), mk3(c), t, bu, bv)) continue;
+        if (t > tmax) continue;
+        const uint32_t prim = __float_as_uint(a.w);
+        if (found && !closer(t, prim, best)) continue;
+        best.t = t; best.u = bu; best.v = bv; best.prim = prim;
+        found = true;
+        if (ANY_HIT) return true;
+      }
+      if (sp == 0) break;
+      cur = stack[--sp];
+    }
+  }
+  return found;
+}
+
+}  // namespace fh

@@ -1,0 +1,311 @@
+// kat.hip -- batch entry points that evaluate, ON THE DEVICE, the same device functions the render
+// kernels use (hashes, samplers, warps, BSDF, sky, camera, traversal).  They exist so the parity
+// tests can compare each building block with the CPU checker through the C ABI; they are not on
+// the render path.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "context.h"
+#include "fh_bsdf.h"
+#include "fh_trace.h"
+
+namespace fh {
+namespace {
+
+template <typename T>
+struct Tmp {
+  T* p = nullptr;
+  size_t n = 0;
+  ~Tmp() { if (p) (void)hipFree(p); }
+  hipError_t up(const T* host, size_t count)
+  {
+    n = count;
+    hipError_t e = hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (host && count) e = hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+  }
+  hipError_t down(T* host) { return hipMemcpy(host, p, n * sizeof(T), hipMemcpyDeviceToHost); }
+};
+
+__global__ void k_hash(int kind, uint32_t n, const uint32_t* in, uint32_t* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t a = in[4 * i], b = in[4 * i + 1], c = in[4 * i + 2], d = in[4 * i + 3];
+  out[i] = kind == 0 ? xxhash32(a) : kind == 1 ? xxhash32(a, b, c) : kind == 2 ? xxhash32(a, b, c, d) : cmj_permute(a, b, c);
+}
+__global__ void k_cmj(uint32_t n, const uint32_t* in, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f2 r = cmj_draw(in[4 * i], in[4 * i + 1], in[4 * i + 2], xxhash32(in[4 * i + 3]));
+  out[2 * i] = r.x;
+  out[2 * i + 1] = r.y;
+}
+__global__ void k_sobol(uint32_t n, const uint32_t* in, const uint32_t* table, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t dim = in[4 * i + 1];
+  out[i] = sobol_draw(table + (dim & 1023u) * 52u, in[4 * i], dim, in[4 * i + 2]);
+}
+__global__ void k_elementary(int fn, uint32_t n, const float* x, const float* y, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r = 0.0f;
+  switch (fn) {
+    case 0: r = fhe_sin(x[i]); break;
+    case 1: r = fhe_cos(x[i]); break;
+    case 2: r = fhe_exp(x[i]); break;
+    case 3: r = fhe_log(x[i]); break;
+    case 4: r = fhe_pow(x[i], y[i]); break;
+    case 5: r = fhe_acos(x[i]); break;
+    case 6: r = fhe_atan2(x[i], y[i]); break;
+    case 7: r = fhe_log2(x[i]); break;
+  }
+  out[i] = r;
+}
+__global__ void k_warp(int kind, uint32_t n, const float* u, const float* wo, float ax, float ay, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f2 uu = mk2(u[2 * i], u[2 * i + 1]);
+  if (kind == 0) { const f2 r = concentric_disk(uu); out[2 * i] = r.x; out[2 * i + 1] = r.y; }
+  else if (kind == 1) { const f3 r = cosine_hemisphere(uu); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+  else if (kind == 2) { const f2 r = triangle_barycentric(uu); out[2 * i] = r.x; out[2 * i + 1] = r.y; }
+  else { const f3 r = sample_vndf(mk3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), ax, ay, uu); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+}
+
+FH_D MatParams params_of(const MaterialDev& m)
+{
+  MatParams p;
+  p.diffuse = m.w[0]; p.base_color = mk3(m.w[1], m.w[2], m.w[3]); p.diffuse_roughness = m.w[5];
+  p.specular = m.w[6]; p.specular_color = mk3(m.w[7], m.w[8], m.w[9]); p.specular_roughness = clampf(m.w[11], 0.01f, 1.0f);
+  p.metalness = m.w[13];
+  p.coat = clampf(m.w[16], 0.0f, 1.0f); p.coat_color = mk3(1.0f); p.coat_roughness = clampf(m.w[21], 0.0f, 1.0f);
+  p.transmission = m.w[23]; p.transmission_color = mk3(m.w[24], m.w[25], m.w[26]);
+  p.sheen = m.w[27]; p.sheen_color = mk3(m.w[28], m.w[29], m.w[30]); p.sheen_roughness = m.w[31];
+  p.subsurface = m.w[32]; p.subsurface_color = mk3(m.w[33], m.w[34], m.w[35]);
+  p.thin_walled = m.w[36];
+  return p;
+}
+
+template <uint32_t LOBES>
+__global__ void k_bsdf(MaterialDev mat, int entering, BsdfTables lut, uint32_t n, const float* wo, const float* wi, const float* u1, const float* u2, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f3 o = mk3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), in = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+  Bsdf<LOBES> b;
+  b.init(o, params_of(mat), entering != 0, lut);
+  const f3 e = b.eval(o, in);
+  f3 f;
+  float pdf;
+  const f3 s = b.sample(o, u1[i], mk2(u2[2 * i], u2[2 * i + 1]), f, pdf);
+  float* r = out + 18 * i;
+  r[0] = e.x; r[1] = e.y; r[2] = e.z; r[3] = b.eval_pdf(o, in);
+  r[4] = s.x; r[5] = s.y; r[6] = s.z; r[7] = f.x; r[8] = f.y; r[9] = f.z; r[10] = pdf;
+  for (int k = 0; k < 7; ++k) r[11 + k] = b.pmf(k);
+}
+
+__global__ void k_sky(HosekSky st, f3 sun, float intensity, uint32_t n, const float* d, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f3 r = hosek_radiance(st, sun, intensity, mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+  out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+
+__global__ void k_camera(m34 xf, float inv_tan, float F, float focus, uint32_t width, uint32_t height, uint32_t seed_hash, uint32_t n, const uint32_t* pix, const uint32_t* nspp, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t image_idx = pix[i], n_spp = nspp[i];
+  const uint32_t px = image_idx % width, py = image_idx / width;
+  f2 u = cmj_draw(n_spp, image_idx, 0u, seed_hash);
+  float uvx = (2.0f * (px + u.x) - width) / height;
+  const float uvy = (2.0f * (py + u.y) - height) / height;
+  uvx = -uvx;
+  u = cmj_draw(n_spp, image_idx, 1u, seed_hash);
+  const float f = inv_tan, b = focus;
+  const float a = 1.0f / (1.0f + f - 1.0f / b);
+  const float lens_radius = 2.0f * f / F;
+  const f3 p_sensor = mk3(uvx, uvy, 0.0f), p_lens_center = mk3(0.0f, 0.0f, f);
+  const f2 pd = lens_radius * concentric_disk(u);
+  const f3 p_lens = p_lens_center + mk3(pd.x, pd.y, 0.0f);
+  const f3 s2c = normalize(p_lens_center - p_sensor);
+  const f3 p_object = p_sensor + ((a + b) / s2c.z) * s2c;
+  const f3 org = xform_point(xf, p_lens);
+  f3 d = normalize(p_object - p_lens);
+  d.z *= -1.0f;
+  const f3 dir = xform_dir(xf, d);
+  out[6 * i] = org.x; out[6 * i + 1] = org.y; out[6 * i + 2] = org.z; out[6 * i + 3] = dir.x; out[6 * i + 4] = dir.y; out[6 * i + 5] = dir.z;
+}
+
+__global__ void k_offset(uint32_t n, const float* p, const float* nn, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f3 r = offset_origin(mk3(p[3 * i], p[3 * i + 1], p[3 * i + 2]), mk3(nn[3 * i], nn[3 * i + 1], nn[3 * i + 2]));
+  out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+
+__global__ void k_trace_batch(SceneDev sc, uint32_t n, const float* rays7, int any_hit, float* tuv, uint32_t* prim)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = rays7 + 7 * (size_t)i;
+  HitRec h;
+  uint32_t a = 0, b = 0;
+  const bool ok = any_hit ? traverse_bvh2<true, false>(sc.bvh2, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], h, a, b)
+                          : traverse_bvh2<false, false>(sc.bvh2, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], h, a, b);
+  tuv[3 * i] = ok ? h.t : 0.0f; tuv[3 * i + 1] = ok ? h.u : 0.0f; tuv[3 * i + 2] = ok ? h.v : 0.0f;
+  prim[i] = ok ? h.prim : 0xffffffffu;
+}
+
+uint32_t blocks(uint32_t n) { return (n + 255) / 256; }
+
+}  // namespace
+}  // namespace fh
+
+using namespace fh;
+
+#define KCTX(ctx)                  \
+  if (!(ctx)) return FH_E_INVALID; \
+  if (hipSetDevice((ctx)->device) != hipSuccess) return fh::fail(ctx, FH_E_HIP, "hipSetDevice failed")
+
+extern "C" {
+
+int fh_trace_rays(fh_ctx* ctx, uint32_t n, const float* rays7, int any_hit, float* tuv, uint32_t* prim)
+{
+  KCTX(ctx);
+  if (!ctx->scene_loaded || !ctx->bvh_valid) return fail(ctx, FH_E_INVALID, "fh_trace_rays: scene/BVH missing");
+  if (n == 0) return FH_OK;
+  Tmp<float> r, t;
+  Tmp<uint32_t> p;
+  FH_HIP(r.up(rays7, 7ull * n)); FH_HIP(t.up(nullptr, 3ull * n)); FH_HIP(p.up(nullptr, n));
+  hipLaunchKernelGGL(k_trace_batch, dim3(blocks(n)), dim3(256), 0, ctx->stream, scene_dev(ctx), n, r.p, any_hit, t.p, p.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(t.down(tuv)); FH_HIP(p.down(prim));
+  return FH_OK;
+}
+
+int fh_kat_hash(fh_ctx* ctx, int kind, uint32_t n, const uint32_t* in4, uint32_t* out)
+{
+  KCTX(ctx);
+  Tmp<uint32_t> a, o;
+  FH_HIP(a.up(in4, 4ull * n)); FH_HIP(o.up(nullptr, n));
+  hipLaunchKernelGGL(k_hash, dim3(blocks(n)), dim3(256), 0, ctx->stream, kind, n, a.p, o.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out));
+  return FH_OK;
+}
+int fh_kat_cmj(fh_ctx* ctx, uint32_t n, const uint32_t* in4, float* out2)
+{
+  KCTX(ctx);
+  Tmp<uint32_t> a;
+  Tmp<float> o;
+  FH_HIP(a.up(in4, 4ull * n)); FH_HIP(o.up(nullptr, 2ull * n));
+  hipLaunchKernelGGL(k_cmj, dim3(blocks(n)), dim3(256), 0, ctx->stream, n, a.p, o.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out2));
+  return FH_OK;
+}
+int fh_kat_sobol(fh_ctx* ctx, uint32_t n, const uint32_t* in4, float* out)
+{
+  KCTX(ctx);
+  Tmp<uint32_t> a;
+  Tmp<float> o;
+  FH_HIP(a.up(in4, 4ull * n)); FH_HIP(o.up(nullptr, n));
+  hipLaunchKernelGGL(k_sobol, dim3(blocks(n)), dim3(256), 0, ctx->stream, n, a.p, ctx->d_sobol, o.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out));
+  return FH_OK;
+}
+int fh_kat_elementary(fh_ctx* ctx, int fn, uint32_t n, const float* x, const float* y, float* out)
+{
+  KCTX(ctx);
+  Tmp<float> a, b, o;
+  FH_HIP(a.up(x, n)); FH_HIP(b.up(y ? y : x, n)); FH_HIP(o.up(nullptr, n));
+  hipLaunchKernelGGL(k_elementary, dim3(blocks(n)), dim3(256), 0, ctx->stream, fn, n, a.p, b.p, o.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out));
+  return FH_OK;
+}
+int fh_kat_warp(fh_ctx* ctx, int kind, uint32_t n, const float* u2, const float* wo3, const float* alpha2, float* out)
+{
+  KCTX(ctx);
+  const uint32_t width = (kind == 1 || kind == 3) ? 3u : 2u;
+  Tmp<float> u, w, o;
+  FH_HIP(u.up(u2, 2ull * n)); FH_HIP(w.up(wo3, wo3 ? 3ull * n : 0)); FH_HIP(o.up(nullptr, (size_t)width * n));
+  hipLaunchKernelGGL(k_warp, dim3(blocks(n)), dim3(256), 0, ctx->stream, kind, n, u.p, w.p, alpha2 ? alpha2[0] : 1.0f, alpha2 ? alpha2[1] : 1.0f, o.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out));
+  return FH_OK;
+}
+int fh_kat_bsdf(fh_ctx* ctx, const fh_material* material, int entering, uint32_t lobes_mask, uint32_t n, const float* wo3, const float* wi3, const float* u1, const float* u2, float* out18)
+{
+  KCTX(ctx);
+  if (!material) return FH_E_INVALID;
+  MaterialDev m{};
+  std::memcpy(m.w, material, 180);
+  const BsdfTables lut{ctx->d_lut_refl, ctx->d_lut_sheen};
+  Tmp<float> a, b, c, d, o;
+  FH_HIP(a.up(wo3, 3ull * n)); FH_HIP(b.up(wi3, 3ull * n)); FH_HIP(c.up(u1, n)); FH_HIP(d.up(u2, 2ull * n)); FH_HIP(o.up(nullptr, 18ull * n));
+  const dim3 g(blocks(n)), t(256);
+  switch (lobes_mask) {
+    case L_DIFF: hipLaunchKernelGGL(k_bsdf<L_DIFF>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+    case L_METAL: hipLaunchKernelGGL(k_bsdf<L_METAL>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+    case L_SPEC | L_DIFF: hipLaunchKernelGGL(k_bsdf<L_SPEC | L_DIFF>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+    case L_METAL | L_SPEC | L_DIFF: hipLaunchKernelGGL(k_bsdf<L_METAL | L_SPEC | L_DIFF>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+    default: hipLaunchKernelGGL(k_bsdf<L_ALL>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+  }
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out18));
+  return FH_OK;
+}
+int fh_kat_sky(fh_ctx* ctx, uint32_t n, const float* dirs3, float* out3)
+{
+  KCTX(ctx);
+  Tmp<float> a, o;
+  FH_HIP(a.up(dirs3, 3ull * n)); FH_HIP(o.up(nullptr, 3ull * n));
+  hipLaunchKernelGGL(k_sky, dim3(blocks(n)), dim3(256), 0, ctx->stream, ctx->hosek, mk3(ctx->sun_dir[0], ctx->sun_dir[1], ctx->sun_dir[2]), ctx->sky_intensity, n, a.p, o.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out3));
+  return FH_OK;
+}
+int fh_kat_hosek_state(fh_ctx* ctx, float* out30)
+{
+  KCTX(ctx);
+  std::memcpy(out30, &ctx->hosek, sizeof ctx->hosek);
+  return FH_OK;
+}
+int fh_kat_camera(fh_ctx* ctx, const fh_camera* cam, uint32_t width, uint32_t height, uint32_t seed, uint32_t n, const uint32_t* pixel_idx, const uint32_t* n_spp, float* out6)
+{
+  KCTX(ctx);
+  m34 xf;
+  for (int r = 0; r < 3; ++r) xf.r[r] = make_float4(cam->transform[4 * r], cam->transform[4 * r + 1], cam->transform[4 * r + 2], cam->transform[4 * r + 3]);
+  Tmp<uint32_t> a, b;
+  Tmp<float> o;
+  FH_HIP(a.up(pixel_idx, n)); FH_HIP(b.up(n_spp, n)); FH_HIP(o.up(nullptr, 6ull * n));
+  hipLaunchKernelGGL(k_camera, dim3(blocks(n)), dim3(256), 0, ctx->stream, xf, 1.0f / tanf(0.5f * cam->fov), cam->F, cam->focus, width, height, xxhash32(seed), n, a.p, b.p, o.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out6));
+  return FH_OK;
+}
+int fh_kat_offset_origin(fh_ctx* ctx, uint32_t n, const float* p3, const float* n3, float* out3)
+{
+  KCTX(ctx);
+  Tmp<float> a, b, o;
+  FH_HIP(a.up(p3, 3ull * n)); FH_HIP(b.up(n3, 3ull * n)); FH_HIP(o.up(nullptr, 3ull * n));
+  hipLaunchKernelGGL(k_offset, dim3(blocks(n)), dim3(256), 0, ctx->stream, n, a.p, b.p, o.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out3));
+  return FH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,659 @@
+// render.hip -- the wavefront path tracer: kernels + per-frame submission.
+//
+// Replaces Renderer::render -> optixLaunch of the megakernel in fredholm/modules/pt.cu
+// (__raygen__rg :418-502, __closesthit__radiance :680-944, __closesthit__light :952-999,
+// __miss__* :504-543).  One reference launch thread = one pixel looping over samples and bounces;
+// here a pass starts `B` samples for every owned pixel as independent path slots and advances all
+// of them one bounce at a time through five kernels:
+//
+//   k_generate        CMJ slots 0/1 -> thin-lens camera ray, throughput 1           (pt.cu:433-454)
+//   k_trace_closest   closest hit for the radiance-ray queue; routes each hit to the queue of its
+//                     material's shading class (BSDF-sorted shading), primary misses to the miss queue
+//   k_shade<LOBES>    surface + BSDF + NEE samples + light ray + next direction + Russian roulette for
+//                     the next bounce; emits secondary rays with their pre-weighted contributions
+//   k_miss_primary    sky / background for paths that leave the scene at depth 0      (pt.cu:504-523)
+//   k_trace_secondary any-hit shadow rays (and the BSDF-sampled light ray) of every shaded path, in
+//                     the reference's order; adds the contributions that turn out unoccluded
+//   k_accumulate      NaN guard + running mean of the 6 AOVs, sample_count += B       (pt.cu:474-501)
+//
+// Sampler slots are addressed absolutely (fh_sampler.h): at bounce b the Sobol' dimension base is
+// 1 + b*n1 and the CMJ slot base is 2 + b*n2 with n1 = 3 + [lights], n2 = 3 + [directional] + [lights],
+// which reproduces the draw order of SURVEY.md appendix A without per-path sampler state.
+#include <hip/hip_runtime.h>
+
+#include "context.h"
+#include "fh_bsdf.h"
+#include "fh_trace.h"
+
+namespace fh {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct SobolRows {  // rows of the generator matrices this kernel needs, staged in LDS (32 columns each)
+  uint32_t m[4][32];
+};
+
+FH_D void load_sobol_rows(SobolRows& rows, const uint32_t* table, const uint32_t dims[4])
+{
+  if (threadIdx.x < 128) {
+    const uint32_t r = threadIdx.x >> 5, c = threadIdx.x & 31;
+    rows.m[r][c] = table[(dims[r] & 1023u) * 52u + c];
+  }
+  __syncthreads();
+}
+
+FH_D f3 env_radiance(const FrameDev& fr, f3 d) { return fr.has_hosek ? hosek_radiance(fr.hosek, fr.sun_dir, fr.sky_intensity, d) : fr.bg; }
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, LayersDev layers, const uint32_t* owned, uint32_t n_owned, uint32_t n_paths)
+{
+  __shared__ SobolRows rows;
+  const uint32_t dims[4] = {1u, 1u, 1u, 1u};
+  load_sobol_rows(rows, fr.sobol, dims);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n_paths; base += stride) {
+    const uint32_t p = base + threadIdx.x;
+    const bool valid = p < n_paths;
+    bool alive = false;
+    if (valid) {
+      const uint32_t i = p % n_owned, k = p / n_owned;
+      const uint32_t image_idx = owned[i];
+      const uint32_t n_spp = layers.sample_count[image_idx] + k;
+      const uint32_t px = image_idx % fr.width, py = image_idx / fr.width;
+      f2 u = cmj_draw(n_spp, image_idx, 0u, fr.seed_hash);
+      float uvx = (2.0f * (px + u.x) - fr.width) / fr.height;
+      const float uvy = (2.0f * (py + u.y) - fr.height) / fr.height;
+      uvx = -uvx;
+      u = cmj_draw(n_spp, image_idx, 1u, fr.seed_hash);
+      // thin lens (camera.cu:24-53)
+      const float f = fr.cam_inv_tan;
+      const float b = fr.cam_focus;
+      const float a = 1.0f / (1.0f + f - 1.0f / b);
+      const float lens_radius = 2.0f * f / fr.cam_F;
+      const f3 p_sensor = mk3(uvx, uvy, 0.0f);
+      const f3 p_lens_center = mk3(0.0f, 0.0f, f);
+      const f2 pd = lens_radius * concentric_disk(u);
+      const f3 p_lens = p_lens_center + mk3(pd.x, pd.y, 0.0f);
+      const f3 s2c = normalize(p_lens_center - p_sensor);
+      const f3 p_object = p_sensor + ((a + b) / s2c.z) * s2c;
+      const f3 org = xform_point(fr.cam_xf, p_lens);
+      f3 d = normalize(p_object - p_lens);
+      d.z *= -1.0f;
+      const f3 dir = xform_dir(fr.cam_xf, d);
+      pool.ray_o[p] = mk4(org, 1e9f);
+      pool.ray_d[p] = mk4(dir, 0.0f);
+      pool.thr[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+      pool.rad[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      pool.pixel[p] = image_idx;
+      pool.nspp[p] = n_spp;
+      pool.flags[p] = 0u;
+      // Russian roulette of bounce 0 has probability 1 but still consumes (and can fail on) a draw, pt.cu:457-461
+      const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
+      const float rr = sobol_draw(rows.m[0], sidx, 1u, fr.seed_hash);
+      alive = fr.max_depth > 0 && !(rr >= 1.0f);
+    }
+    queue_push(&pool.counters[CNT_RAD0], pool.q_rad[0], alive, p);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_trace_closest(SceneDev sc, PoolDev pool, uint32_t qsel, uint32_t depth, uint32_t n_classes, TraceCounters tc)
+{
+  const uint32_t count = pool.counters[CNT_RAD0 + qsel];
+  const uint32_t* q = pool.q_rad[qsel];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t nn = 0, nt = 0;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < count;
+    uint32_t p = 0;
+    bool hit = false;
+    uint32_t cls = 0;
+    if (valid) {
+      p = q[i];
+      const float4 o = pool.ray_o[p], d = pool.ray_d[p];
+      HitRec h;
+      hit = traverse_bvh2<false, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+      pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+      if (hit) cls = sc.face_cls[h.prim] & 0x7fu;
+    }
+    for (uint32_t c = 0; c < n_classes; ++c) queue_push(&pool.counters[CNT_CLS + c], pool.q_cls + (size_t)c * pool.capacity, valid && hit && cls == c, p);
+    if (depth == 0) queue_push(&pool.counters[CNT_CLS + kMissClass], pool.q_cls + (size_t)kMissClass * pool.capacity, valid && !hit, p);
+  }
+  if (COUNT) {
+    atomicAdd(tc.nodes, (unsigned long long)nn);
+    atomicAdd(tc.tris, (unsigned long long)nt);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_miss_primary(FrameDev fr, PoolDev pool)
+{
+  const uint32_t count = pool.counters[CNT_CLS + kMissClass];
+  const uint32_t* q = pool.q_cls + (size_t)kMissClass * pool.capacity;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const uint32_t p = q[i];
+    const f3 T = mk3(pool.thr[p]);
+    const f3 d = mk3(pool.ray_d[p]);
+    const f3 r = mk3(pool.rad[p]) + T * env_radiance(fr, d);
+    pool.rad[p] = mk4(r, 0.0f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+FH_D MatParams load_params(const MaterialDev& m)
+{
+  MatParams p;
+  p.diffuse = m.w[0];
+  p.base_color = mk3(m.w[1], m.w[2], m.w[3]);
+  p.diffuse_roughness = m.w[5];
+  p.specular = m.w[6];
+  p.specular_color = mk3(m.w[7], m.w[8], m.w[9]);
+  p.specular_roughness = clampf(m.w[11], 0.01f, 1.0f);
+  p.metalness = m.w[13];
+  p.coat = clampf(m.w[16], 0.0f, 1.0f);
+  p.coat_color = mk3(1.0f, 1.0f, 1.0f);  // fill_shading_params never copies material.coat_color (pt.cu:238-255)
+  p.coat_roughness = clampf(m.w[21], 0.0f, 1.0f);
+  p.transmission = m.w[23];
+  p.transmission_color = mk3(m.w[24], m.w[25], m.w[26]);
+  p.sheen = m.w[27];
+  p.sheen_color = mk3(m.w[28], m.w[29], m.w[30]);
+  p.sheen_roughness = m.w[31];
+  p.subsurface = m.w[32];
+  p.subsurface_color = mk3(m.w[33], m.w[34], m.w[35]);
+  p.thin_walled = m.w[36];
+  return p;
+}
+
+FH_D void store_secondary(const PoolDev& pool, uint32_t slot, uint32_t p, f3 o, float tmax, f3 d, bool active, f3 c)
+{
+  const size_t k = (size_t)slot * pool.capacity + p;
+  pool.sec_o[k] = mk4(o, tmax);
+  pool.sec_d[k] = mk4(d, active ? 1.0f : 0.0f);
+  pool.sec_c[k] = mk4(c, 0.0f);
+}
+
+template <uint32_t LOBES>
+__global__ void __launch_bounds__(kBlock) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
+{
+  __shared__ SobolRows rows;
+  const uint32_t has_lights = sc.n_lights > 0 ? 1u : 0u;
+  const uint32_t dim0 = 1u + depth * fr.n1;              // this bounce's RR dimension (already consumed)
+  const uint32_t dim_area = dim0 + 1u;                   // only if has_lights
+  const uint32_t dim_light = dim0 + 1u + has_lights;
+  const uint32_t dim_next = dim_light + 1u;
+  const uint32_t dim_rr = 1u + (depth + 1u) * fr.n1;
+  const uint32_t dims[4] = {dim_area, dim_light, dim_next, dim_rr};
+  load_sobol_rows(rows, fr.sobol, dims);
+  const uint32_t slot0 = 2u + depth * fr.n2;
+  const uint32_t slot_dir = slot0;
+  const uint32_t slot_sky = slot0 + fr.has_dir;
+  const uint32_t slot_area = slot_sky + 1u;
+  const uint32_t slot_light = slot_sky + 1u + has_lights;
+  const uint32_t slot_next = slot_light + 1u;
+
+  const uint32_t count = pool.counters[CNT_CLS + cls];
+  const uint32_t* q = pool.q_cls + (size_t)cls * pool.capacity;
+  const uint32_t qnext = (depth + 1u) & 1u;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < count;
+    bool shaded = false, cont = false;
+    uint32_t p = 0;
+    if (valid) {
+      p = q[i];
+      const float4 hit = pool.hit[p];
+      const uint32_t prim = __float_as_uint(hit.w);
+      const float bu = hit.y, bv = hit.z;
+      const f3 rd = mk3(pool.ray_d[p]);
+      f3 T = mk3(pool.thr[p]);
+      f3 L = mk3(pool.rad[p]);
+      const uint32_t image_idx = pool.pixel[p], n_spp = pool.nspp[p];
+      const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
+
+      // surface (pt.cu:141-179) from the pre-transformed face record
+      const float4 r0 = sc.face_rec[7 * (size_t)prim], r1 = sc.face_rec[7 * (size_t)prim + 1], r2 = sc.face_rec[7 * (size_t)prim + 2];
+      const float4 r3 = sc.face_rec[7 * (size_t)prim + 3], r4 = sc.face_rec[7 * (size_t)prim + 4], r5 = sc.face_rec[7 * (size_t)prim + 5];
+      const float4 r6 = sc.face_rec[7 * (size_t)prim + 6];
+      const f3 p0 = mk3(r0), p1 = mk3(r1), p2 = mk3(r2);
+      const float bw = 1.0f - bu - bv;
+      const f3 x = bw * p0 + bu * p1 + bv * p2;
+      f3 ng = normalize(cross(p1 - p0, p2 - p0));
+      f3 ns = normalize(bw * mk3(r3) + bu * mk3(r4) + bv * mk3(r5));
+      const float tu = bw * r0.w + bu * r2.w + bv * r4.w;
+      const float tv = bw * r1.w + bu * r3.w + bv * r5.w;
+      const bool entering = dot(-rd, ng) > 0;
+      ns = entering ? ns : -ns;
+      ng = entering ? ng : -ng;
+      f3 tangent, bitangent;
+      onb(ns, tangent, bitangent);
+      const MaterialDev& mat = sc.materials[__float_as_uint(r6.x)];
+      const MatParams sp = load_params(mat);
+
+      bool done = false;
+      if (depth == 0) {  // first hit: AOVs and directly visible emitters (pt.cu:745-760)
+        pool.aov_position[p] = mk4(x, 0.0f);
+        pool.aov_normal[p] = mk4(ns, 0.0f);
+        pool.aov_albedo[p] = mk4(sp.base_color, 0.0f);
+        pool.aov_texdepth[p] = make_float4(tu, tv, hit.x, 0.0f);
+        pool.flags[p] = 1u;
+        if (mat.emissive) {
+          L += T * mk3(mat.w[38], mat.w[39], mat.w[40]);
+          pool.rad[p] = mk4(L, 0.0f);
+          done = true;
+        }
+      }
+      if (!done) {
+        shaded = true;
+        const f3 wo = to_local(-rd, tangent, ns, bitangent);
+        Bsdf<LOBES> bsdf;
+        bsdf.init(wo, sp, entering, fr.lut);
+        const f3 so = offset_origin(x, ng);
+
+        // directional light (pt.cu:772-793)
+        if (fr.has_dir) {
+          const f2 pdisk = concentric_disk(cmj_draw(n_spp, image_idx, slot_dir, fr.seed_hash));
+          f3 t, b;
+          onb(fr.dir_dir, t, b);
+          const f3 pl = 1e9f * fr.dir_dir + fr.dir_disk_radius * (t * pdisk.x + b * pdisk.y);
+          const f3 sd = normalize(pl - so);
+          const f3 wi = to_local(sd, tangent, ns, bitangent);
+          const f3 f = bsdf.eval(wo, wi);
+          const float pdf = 1.0f;
+          const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
+          const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * fr.dir_le;
+          store_secondary(pool, SEC_DIR, p, so, 1e9f - 0.001f, sd, true, c);
+        }
+        // sky / constant background (pt.cu:817-857)
+        {
+          const f3 wi = cosine_hemisphere(cmj_draw(n_spp, image_idx, slot_sky, fr.seed_hash));
+          const f3 sd = to_world(wi, tangent, ns, bitangent);
+          const f3 f = bsdf.eval(wo, wi);
+          const float pdf = abs_cos(wi) / kPi;
+          const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
+          const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, sd);
+          store_secondary(pool, SEC_SKY, p, so, 1e9f - 0.001f, sd, true, c);
+        }
+        // area lights (pt.cu:860-889, :282-322)
+        if (has_lights) {
+          const float u1 = sobol_draw(rows.m[0], sidx, dim_area, fr.seed_hash);
+          const f2 u2 = cmj_draw(n_spp, image_idx, slot_area, fr.seed_hash);
+          uint32_t li = (uint32_t)(u1 * sc.n_lights);
+          li = li < sc.n_lights - 1u ? li : sc.n_lights - 1u;
+          const AreaLightDev lt = sc.lights[li];
+          const f2 bc = triangle_barycentric(u2);
+          const float4 l0 = sc.face_rec[7 * (size_t)lt.face], l1 = sc.face_rec[7 * (size_t)lt.face + 1], l2 = sc.face_rec[7 * (size_t)lt.face + 2];
+          const float4 l3 = sc.face_rec[7 * (size_t)lt.face + 3], l4 = sc.face_rec[7 * (size_t)lt.face + 4], l5 = sc.face_rec[7 * (size_t)lt.face + 5];
+          const float lw = 1.0f - bc.x - bc.y;
+          const f3 lp = lw * mk3(l0) + bc.x * mk3(l1) + bc.y * mk3(l2);
+          const f3 ln = lw * mk3(l3) + bc.x * mk3(l4) + bc.y * mk3(l5);
+          const float area = 0.5f * length(cross(mk3(l1) - mk3(l0), mk3(l2) - mk3(l0)));
+          const MaterialDev& lm = sc.materials[lt.material];
+          const f3 le = mk3(lm.w[38], lm.w[39], lm.w[40]);
+          const float pdf_area = 1.0f / (sc.n_lights * area);
+          const f3 sd = normalize(lp - so);
+          const float r = length(lp - so);
+          const bool facing = dot(-sd, ln) > 0.0f;
+          const f3 wi = to_local(sd, tangent, ns, bitangent);
+          const f3 f = bsdf.eval(wo, wi);
+          const float pdf = r * r / fabsf(dot(-sd, ln)) * pdf_area;
+          const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
+          const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * le;
+          store_secondary(pool, SEC_AREA, p, so, r - 0.001f, sd, facing, c);
+        }
+        // BSDF-sampled light ray (pt.cu:893-925)
+        {
+          f3 f;
+          float pdf;
+          const float u1 = sobol_draw(rows.m[1], sidx, dim_light, fr.seed_hash);
+          const f2 u2 = cmj_draw(n_spp, image_idx, slot_light, fr.seed_hash);
+          const f3 wi = bsdf.sample(wo, u1, u2, f, pdf);
+          const f3 ld = to_world(wi, tangent, ns, bitangent);
+          const bool transmitted = dot(ld, ng) < 0;
+          const f3 lo = offset_origin(x, transmitted ? -ng : ng);
+          if (has_lights) {
+            // the MIS weight needs the hit (emitter or sky): finish it in k_trace_secondary
+            pool.lp_a[p] = mk4(T, abs_cos(wi));
+            pool.lp_b[p] = mk4(f, pdf);
+            store_secondary(pool, SEC_LIGHT, p, lo, 1e9f, ld, true, mk3(0.0f));
+          } else {
+            // no emitters: the ray contributes only if it escapes, with the sky's cosine pdf (pt.cu:917-919)
+            const float pdf_light = abs_cos(wi) / kPi;
+            const float w = pdf / (pdf + pdf_light);
+            const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, ld);
+            store_secondary(pool, SEC_LIGHT, p, lo, 1e9f, ld, true, c);
+          }
+        }
+        // next direction (pt.cu:928-943) and the next bounce's Russian roulette (pt.cu:457-471)
+        {
+          f3 f;
+          float pdf;
+          const float u1 = sobol_draw(rows.m[2], sidx, dim_next, fr.seed_hash);
+          const f2 u2 = cmj_draw(n_spp, image_idx, slot_next, fr.seed_hash);
+          const f3 wi = bsdf.sample(wo, u1, u2, f, pdf);
+          const f3 wd = to_world(wi, tangent, ns, bitangent);
+          T *= f * abs_cos(wi) / pdf;
+          const bool transmitted = dot(wd, ng) < 0;
+          const f3 no = offset_origin(x, transmitted ? -ng : ng);
+          if (!bad3(T) && depth + 1u < fr.max_depth) {
+            const float prr = clampf(lum(T), 0.0f, 1.0f);
+            const float u = sobol_draw(rows.m[3], sidx, dim_rr, fr.seed_hash);
+            if (!(u >= prr)) {
+              T = T / prr;
+              cont = true;
+              pool.ray_o[p] = mk4(no, 1e9f);
+              pool.ray_d[p] = mk4(wd, 0.0f);
+              pool.thr[p] = mk4(T, 0.0f);
+            }
+          }
+        }
+      }
+    }
+    queue_push(&pool.counters[CNT_SEC], pool.q_sec, shaded, p);
+    queue_push(&pool.counters[CNT_RAD0 + qnext], pool.q_rad[qnext], cont, p);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDev fr, PoolDev pool, TraceCounters tc)
+{
+  const uint32_t count = pool.counters[CNT_SEC];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const bool has_lights = sc.n_lights > 0;
+  uint32_t nn = 0, nt = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const uint32_t p = pool.q_sec[i];
+    f3 L = mk3(pool.rad[p]);
+    // shadow rays in the reference's order: directional, sky, area
+#pragma unroll
+    for (uint32_t slot = SEC_DIR; slot <= SEC_AREA; ++slot) {
+      if (slot == SEC_DIR && !fr.has_dir) continue;
+      if (slot == SEC_AREA && !has_lights) continue;
+      const size_t k = (size_t)slot * pool.capacity + p;
+      const float4 d = pool.sec_d[k];
+      if (d.w == 0.0f) continue;
+      const float4 o = pool.sec_o[k];
+      HitRec h;
+      const bool occluded = traverse_bvh2<true, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+      if (!occluded) L += mk3(pool.sec_c[k]);
+    }
+    {
+      const size_t k = (size_t)SEC_LIGHT * pool.capacity + p;
+      const float4 o = pool.sec_o[k], d = pool.sec_d[k];
+      HitRec h;
+      if (!has_lights) {
+        const bool occluded = traverse_bvh2<true, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+        if (!occluded) L += mk3(pool.sec_c[k]);
+      } else {
+        // closest hit decides between emitter radiance and sky radiance (pt.cu:952-999, :531-543, :910-924)
+        const bool hit = traverse_bvh2<false, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+        const float4 a = pool.lp_a[p], b = pool.lp_b[p];
+        const f3 T = mk3(a), f = mk3(b);
+        const float cosw = a.w, pdf = b.w;
+        const f3 ld = mk3(d);
+        f3 le = mk3(0.0f);
+        float pdf_light = cosw / kPi;
+        bool add = false;
+        if (hit) {
+          if (sc.face_cls[h.prim] & 0x80u) {
+            const size_t fb = 7 * (size_t)h.prim;
+            const float4 l0 = sc.face_rec[fb], l1 = sc.face_rec[fb + 1], l2 = sc.face_rec[fb + 2], l3 = sc.face_rec[fb + 3], l4 = sc.face_rec[fb + 4], l5 = sc.face_rec[fb + 5];
+            const float lw = 1.0f - h.u - h.v;
+            const f3 lp = lw * mk3(l0) + h.u * mk3(l1) + h.v * mk3(l2);
+            const f3 ln = lw * mk3(l3) + h.u * mk3(l4) + h.v * mk3(l5);
+            if (dot(-ld, ln) > 0.0f) {
+              const MaterialDev& lm = sc.materials[__float_as_uint(sc.face_rec[fb + 6].x)];
+              le = mk3(lm.w[38], lm.w[39], lm.w[40]);
+              const float area = 0.5f * length(cross(mk3(l1) - mk3(l0), mk3(l2) - mk3(l0)));
+              const f3 dl = lp - mk3(o);
+              const float r2 = dot(dl, dl);
+              const float pdf_area = 1.0f / (sc.n_lights * area);
+              pdf_light = r2 / fabsf(dot(-ld, ln)) * pdf_area;
+              add = true;
+            }
+          }
+        } else {
+          le = env_radiance(fr, ld);
+          add = true;
+        }
+        if (add) {
+          const float w = pdf / (pdf + pdf_light);
+          L += clamp01(T * w * f * cosw / pdf) * le;
+        }
+      }
+    }
+    pool.rad[p] = mk4(L, 0.0f);
+  }
+  if (COUNT) {
+    atomicAdd(tc.nodes, (unsigned long long)nn);
+    atomicAdd(tc.tris, (unsigned long long)nt);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_accumulate(PoolDev pool, LayersDev layers, const uint32_t* owned, uint32_t n_owned, uint32_t n_batch)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_owned; i += gridDim.x * blockDim.x) {
+    const uint32_t image_idx = owned[i];
+    uint32_t n_spp = layers.sample_count[image_idx];
+    f3 beauty = mk3(layers.beauty[image_idx]), position = mk3(layers.position[image_idx]), normal = mk3(layers.normal[image_idx]), albedo = mk3(layers.albedo[image_idx]);
+    float depth = layers.depth[image_idx];
+    const float4 tc4 = layers.texcoord[image_idx];
+    float tcx = tc4.x, tcy = tc4.y;
+    for (uint32_t k = 0; k < n_batch; ++k) {
+      const uint32_t p = k * n_owned + i;
+      const f3 L = mk3(pool.rad[p]);
+      const f3 radiance = bad3(L) ? mk3(0.0f) : L;
+      f3 apos = mk3(0.0f), anrm = mk3(0.0f), aalb = mk3(0.0f);
+      float au = 0.0f, av = 0.0f, ad = 0.0f;
+      if (pool.flags[p] & 1u) {
+        apos = mk3(pool.aov_position[p]);
+        anrm = mk3(pool.aov_normal[p]);
+        aalb = mk3(pool.aov_albedo[p]);
+        const float4 td = pool.aov_texdepth[p];
+        au = td.x; av = td.y; ad = td.z;
+      }
+      const float coef = 1.0f / (n_spp + 1.0f);
+      const float fn = (float)n_spp;
+      beauty = coef * (fn * beauty + radiance);
+      position = coef * (fn * position + apos);
+      normal = coef * (fn * normal + anrm);
+      depth = coef * (fn * depth + ad);
+      tcx = coef * (fn * tcx + au);
+      tcy = coef * (fn * tcy + av);
+      albedo = coef * (fn * albedo + aalb);
+      n_spp++;
+    }
+    layers.sample_count[image_idx] = n_spp;
+    layers.beauty[image_idx] = mk4(beauty, 1.0f);
+    layers.position[image_idx] = mk4(position, 1.0f);
+    layers.normal[image_idx] = mk4(normal, 1.0f);
+    layers.depth[image_idx] = depth;
+    layers.texcoord[image_idx] = make_float4(tcx, tcy, 0.0f, 1.0f);
+    layers.albedo[image_idx] = mk4(albedo, 1.0f);
+  }
+}
+
+uint32_t grid_for(uint32_t n) { const uint32_t b = (n + kBlock - 1) / kBlock; return b < 1 ? 1 : (b > 8192 ? 8192 : b); }
+
+template <uint32_t LOBES>
+void launch_shade(hipStream_t st, uint32_t grid, const SceneDev& sc, const FrameDev& fr, const PoolDev& pool, uint32_t cls, uint32_t depth)
+{
+  hipLaunchKernelGGL(k_shade<LOBES>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, cls, depth);
+}
+
+void dispatch_shade(hipStream_t st, uint32_t grid, uint32_t lobes, const SceneDev& sc, const FrameDev& fr, const PoolDev& pool, uint32_t cls, uint32_t depth)
+{
+  // compiled variants, most specific first; a variant is usable when it contains every lobe the class needs
+  if ((lobes & ~(uint32_t)L_DIFF) == 0) return launch_shade<L_DIFF>(st, grid, sc, fr, pool, cls, depth);
+  if ((lobes & ~(uint32_t)L_METAL) == 0) return launch_shade<L_METAL>(st, grid, sc, fr, pool, cls, depth);
+  if ((lobes & ~(uint32_t)(L_SPEC | L_DIFF)) == 0) return launch_shade<L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth);
+  if ((lobes & ~(uint32_t)(L_METAL | L_SPEC | L_DIFF)) == 0) return launch_shade<L_METAL | L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth);
+  return launch_shade<L_ALL>(st, grid, sc, fr, pool, cls, depth);
+}
+
+hipEvent_t take_event(fh_ctx* ctx)
+{
+  if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct Span {
+  fh_ctx* ctx; int kind; hipEvent_t a = nullptr, b = nullptr; bool on;
+  Span(fh_ctx* c, int k) : ctx(c), kind(k), on((c->flags & FH_FLAG_TIME_KERNELS) != 0)
+  {
+    if (on) { a = take_event(ctx); b = take_event(ctx); (void)hipEventRecord(a, ctx->stream); }
+  }
+  ~Span()
+  {
+    if (on) { (void)hipEventRecord(b, ctx->stream); ctx->spans.push_back({a, b, kind}); }
+  }
+};
+
+}  // namespace
+
+SceneDev scene_dev(const fh_ctx* ctx)
+{
+  SceneDev s{};
+  s.face_rec = ctx->d_face_rec;
+  s.face_cls = ctx->d_face_cls;
+  s.materials = ctx->d_materials;
+  s.lights = ctx->d_lights;
+  s.n_faces = ctx->n_faces;
+  s.n_lights = ctx->n_lights;
+  s.bvh2.nodes = ctx->d_bvh2_nodes;
+  s.bvh2.tris = ctx->d_bvh2_tris;
+  s.bvh2.n_nodes = ctx->bvh2_n_nodes;
+  s.bvh2.n_tris = ctx->bvh2_n_tris;
+  s.bvh8.nodes = ctx->d_bvh8_nodes;
+  s.bvh8.tris = ctx->d_bvh8_tris;
+  s.bvh8.n_nodes = ctx->bvh8_n_nodes;
+  s.bvh8.n_tris = ctx->bvh8_n_tris;
+  s.use_bvh8 = ctx->use_bvh8 ? 1u : 0u;
+  return s;
+}
+
+void pool_release(fh_ctx* ctx)
+{
+  for (void* p : ctx->pool_allocs) (void)hipFree(p);
+  ctx->pool_allocs.clear();
+  ctx->pool = PoolDev{};
+}
+
+int pool_ensure(fh_ctx* ctx, uint32_t capacity)
+{
+  if (ctx->pool.capacity >= capacity) return FH_OK;
+  pool_release(ctx);
+  PoolDev& P = ctx->pool;
+  auto alloc = [&](auto*& ptr, size_t count) -> hipError_t {
+    void* raw = nullptr;
+    const hipError_t e = hipMalloc(&raw, count * sizeof(*ptr));
+    if (e == hipSuccess) { ctx->pool_allocs.push_back(raw); ptr = (decltype(ptr))raw; }
+    return e;
+  };
+  const size_t n = capacity;
+  FH_HIP(alloc(P.ray_o, n)); FH_HIP(alloc(P.ray_d, n)); FH_HIP(alloc(P.thr, n)); FH_HIP(alloc(P.rad, n)); FH_HIP(alloc(P.hit, n));
+  FH_HIP(alloc(P.pixel, n)); FH_HIP(alloc(P.nspp, n)); FH_HIP(alloc(P.flags, n));
+  FH_HIP(alloc(P.aov_position, n)); FH_HIP(alloc(P.aov_normal, n)); FH_HIP(alloc(P.aov_albedo, n)); FH_HIP(alloc(P.aov_texdepth, n));
+  FH_HIP(alloc(P.sec_o, n * SEC_COUNT)); FH_HIP(alloc(P.sec_d, n * SEC_COUNT)); FH_HIP(alloc(P.sec_c, n * SEC_COUNT));
+  FH_HIP(alloc(P.lp_a, n)); FH_HIP(alloc(P.lp_b, n));
+  FH_HIP(alloc(P.q_rad[0], n)); FH_HIP(alloc(P.q_rad[1], n)); FH_HIP(alloc(P.q_cls, n * kNumQueues)); FH_HIP(alloc(P.q_sec, n));
+  FH_HIP(alloc(P.counters, (size_t)CNT_TOTAL));
+  P.capacity = capacity;
+  return FH_OK;
+}
+
+int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_render_layers* layers, uint32_t n_samples, uint32_t max_depth, uint32_t seed)
+{
+  if (!ctx->scene_loaded || !ctx->bvh_valid) return fail(ctx, FH_E_INVALID, "fh_render: scene not uploaded or BVH not built");
+  if (ctx->width == 0 || ctx->height == 0 || !ctx->d_sample_count) return fail(ctx, FH_E_INVALID, "fh_render: resolution not set");
+  if (ctx->n_owned == 0 || n_samples == 0) return FH_OK;
+  hipStream_t st = ctx->stream;
+
+  uint32_t target = ctx->pool_target > ctx->n_owned ? ctx->pool_target : ctx->n_owned;
+  uint32_t batch = target / ctx->n_owned;
+  if (batch > n_samples) batch = n_samples;
+  if (batch < 1) batch = 1;
+  { const int rc = pool_ensure(ctx, ctx->n_owned * batch); if (rc) return rc; }
+
+  FrameDev fr{};
+  fr.width = ctx->width; fr.height = ctx->height;
+  fr.seed_hash = xxhash32(seed);
+  fr.max_depth = max_depth;
+  fr.has_dir = ctx->has_dir ? 1u : 0u;
+  fr.has_hosek = ctx->has_hosek ? 1u : 0u;
+  const uint32_t has_lights = ctx->n_lights > 0 ? 1u : 0u;
+  fr.n1 = 3u + has_lights;
+  fr.n2 = 3u + fr.has_dir + has_lights;
+  for (int r = 0; r < 3; ++r) fr.cam_xf.r[r] = make_float4(cam->transform[4 * r], cam->transform[4 * r + 1], cam->transform[4 * r + 2], cam->transform[4 * r + 3]);
+  fr.cam_inv_tan = 1.0f / tanf(0.5f * cam->fov);
+  fr.cam_F = cam->F; fr.cam_focus = cam->focus;
+  fr.bg = mk3(bg[0], bg[1], bg[2]);
+  fr.sky_intensity = ctx->sky_intensity;
+  fr.sun_dir = mk3(ctx->sun_dir[0], ctx->sun_dir[1], ctx->sun_dir[2]);
+  fr.hosek = ctx->hosek;
+  fr.dir_le = mk3(ctx->dir_le[0], ctx->dir_le[1], ctx->dir_le[2]);
+  fr.dir_dir = mk3(ctx->dir_dir[0], ctx->dir_dir[1], ctx->dir_dir[2]);
+  fr.dir_disk_radius = 1e9f * tanf(0.5f * ctx->dir_angle * kPi / 180.0f);
+  fr.sobol = ctx->d_sobol;
+  fr.lut.reflection = ctx->d_lut_refl;
+  fr.lut.sheen = ctx->d_lut_sheen;
+
+  LayersDev L{};
+  L.beauty = (float4*)layers->beauty; L.position = (float4*)layers->position; L.depth = layers->depth;
+  L.normal = (float4*)layers->normal; L.texcoord = (float4*)layers->texcoord; L.albedo = (float4*)layers->albedo;
+  L.sample_count = ctx->d_sample_count;
+
+  const SceneDev sc = scene_dev(ctx);
+  const PoolDev& pool = ctx->pool;
+  const bool count = (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) != 0;
+  TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1};
+  TraceCounters tc_shadow{ctx->d_trace_counters + 2, ctx->d_trace_counters + 3};
+
+  if (!ctx->render_pending) { (void)hipEventRecord(ctx->ev_render_begin, st); ctx->render_pending = true; }
+
+  for (uint32_t done = 0; done < n_samples; done += batch) {
+    const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
+    const uint32_t n_paths = ctx->n_owned * nb;
+    const uint32_t grid = grid_for(n_paths);
+    FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * CNT_TOTAL, st));
+    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, fr, pool, L, ctx->d_owned, ctx->n_owned, n_paths);
+    ctx->stats.paths += n_paths;
+    for (uint32_t depth = 0; depth < max_depth; ++depth) {
+      const uint32_t qsel = depth & 1u;
+      // counters written by this bounce: class queues, secondary queue, next radiance queue
+      FH_HIP(hipMemsetAsync(pool.counters + CNT_CLS, 0, sizeof(uint32_t) * kNumQueues, st));
+      FH_HIP(hipMemsetAsync(pool.counters + CNT_SEC, 0, sizeof(uint32_t), st));
+      FH_HIP(hipMemsetAsync(pool.counters + CNT_RAD0 + (qsel ^ 1u), 0, sizeof(uint32_t), st));
+      {
+        Span sp(ctx, 0);
+        if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, st, sc, pool, qsel, depth, ctx->n_classes, tc_closest);
+        else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, st, sc, pool, qsel, depth, ctx->n_classes, tc_closest);
+        ctx->stats.n_closest_launches++;
+      }
+      {
+        Span sp(ctx, 2);
+        for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pool, c, depth);
+        if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pool);
+      }
+      {
+        Span sp(ctx, 1);
+        if (count) hipLaunchKernelGGL(k_trace_secondary<true>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, tc_shadow);
+        else hipLaunchKernelGGL(k_trace_secondary<false>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, tc_shadow);
+        ctx->stats.n_shadow_launches++;
+      }
+    }
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb);
+  }
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+}  // namespace fh

@@ -1,0 +1,310 @@
+"""Python mirror of the reference's host interface for the render path.
+
+`Renderer`, `Camera`, `RenderLayer` and `PostProcessParams` keep the names, argument meaning and
+call order of fredholm::Renderer (fredholm/include/fredholm/renderer.h:29-846), fredholm::Camera
+(fredholm/include/fredholm/camera.h:22-135), RenderLayer (fredholm/include/fredholm/shared.h:201-208)
+and PostProcessParams (fredholm/kernels/include/kernels/post-process.h:4-10); every method forwards
+to the C ABI of libfredholm_hip.so.  Errors surface as FredholmError, the analogue of the
+std::runtime_error the reference throws from CUDA_CHECK / OPTIX_CHECK.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import native as N
+
+
+def look_at_transform(origin, forward=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0)):
+    """camera-to-world 3x4 rows = inverse(lookAt(origin, origin + 0.01 forward, up)) (camera.h:51-69)."""
+    o = np.asarray(origin, dtype=np.float64)
+    f = np.asarray(forward, dtype=np.float64)
+    f = f / np.linalg.norm(f)
+    r = np.cross(f, np.asarray(up, dtype=np.float64))
+    r = r / np.linalg.norm(r)
+    u = np.cross(r, f)
+    m = np.zeros((3, 4), dtype=np.float32)
+    m[:, 0] = r
+    m[:, 1] = u
+    m[:, 2] = -f
+    m[:, 3] = o
+    return m
+
+
+class Camera:
+    """fredholm::Camera: m_transform (camera-to-world), m_fov (radians), m_F, m_focus (camera.h:22-69)."""
+
+    def __init__(self, origin=(0.0, 0.0, 0.0), fov=0.5 * math.pi, F=8.0, focus=10000.0, forward=(0.0, 0.0, -1.0)):
+        self.m_origin = tuple(float(v) for v in origin)
+        self.m_forward = tuple(float(v) for v in forward)
+        self.m_fov = float(fov)
+        self.m_F = float(F)
+        self.m_focus = float(focus)
+        self.m_transform = look_at_transform(self.m_origin, self.m_forward)
+
+    def set_origin(self, origin):
+        self.m_origin = tuple(float(v) for v in origin)
+        self.m_transform = look_at_transform(self.m_origin, self.m_forward)
+
+    def params(self):
+        """the 15 floats of CameraParams (shared.h:59-64)"""
+        return np.concatenate([np.asarray(self.m_transform, dtype=np.float32).reshape(12), np.asarray([self.m_fov, self.m_F, self.m_focus], dtype=np.float32)])
+
+    def as_c(self):
+        c = N.CameraC()
+        flat = np.asarray(self.m_transform, dtype=np.float32).reshape(12)
+        for i in range(12):
+            c.transform[i] = float(flat[i])
+        c.fov, c.F, c.focus = self.m_fov, self.m_F, self.m_focus
+        return c
+
+
+class PostProcessParams:
+    def __init__(self, use_bloom=False, bloom_threshold=2.0, bloom_sigma=5.0, ISO=80.0, chromatic_aberration=1.0):
+        self.use_bloom, self.bloom_threshold, self.bloom_sigma, self.ISO, self.chromatic_aberration = use_bloom, bloom_threshold, bloom_sigma, ISO, chromatic_aberration
+
+    def as_c(self):
+        return N.PostParamsC(int(bool(self.use_bloom)), self.bloom_threshold, self.bloom_sigma, self.ISO, self.chromatic_aberration)
+
+
+class DeviceBuffer:
+    """Owning device allocation (role of cwl::CUDABuffer, cwl/include/cwl/buffer.h:18-85)."""
+
+    def __init__(self, renderer, nbytes):
+        self._r = renderer
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        N.check(renderer._ctx, N.lib().fh_malloc(renderer._ctx, C.c_uint64(self.nbytes), C.byref(p)), "fh_malloc")
+        self.ptr = p.value
+
+    def clear(self, value=0):
+        N.check(self._r._ctx, N.lib().fh_memset(self._r._ctx, C.c_void_p(self.ptr), int(value), C.c_uint64(self.nbytes)), "fh_memset")
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        assert a.nbytes <= self.nbytes
+        N.check(self._r._ctx, N.lib().fh_copy_to_device(self._r._ctx, C.c_void_p(self.ptr), N.ptr(a), C.c_uint64(a.nbytes)), "fh_copy_to_device")
+
+    def download(self, dtype=np.float32, shape=None):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        N.check(self._r._ctx, N.lib().fh_copy_to_host(self._r._ctx, N.ptr(out), C.c_void_p(self.ptr), C.c_uint64(self.nbytes)), "fh_copy_to_host")
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr and self._r._ctx:
+            N.lib().fh_free(self._r._ctx, C.c_void_p(self.ptr))
+        self.ptr = None
+
+
+class RenderLayer:
+    """Six AOV buffers owned by the caller (shared.h:201-208; allocated by the apps, controller.cpp:80-107).
+
+    Either allocated here through the C ABI, or wrapping external device pointers (e.g. torch tensors)."""
+
+    NAMES = ("beauty", "position", "depth", "normal", "texcoord", "albedo")
+
+    def __init__(self, renderer, width, height, pointers=None):
+        self.width, self.height = int(width), int(height)
+        self._bufs = {}
+        self.ptrs = {}
+        for name in self.NAMES:
+            comps = 1 if name == "depth" else 4
+            if pointers is not None:
+                self.ptrs[name] = int(pointers[name])
+            else:
+                b = DeviceBuffer(renderer, self.width * self.height * comps * 4)
+                b.clear()
+                self._bufs[name] = b
+                self.ptrs[name] = b.ptr
+
+    def clear(self):
+        for b in self._bufs.values():
+            b.clear()
+
+    def download(self, name):
+        comps = 1 if name == "depth" else 4
+        shape = (self.height, self.width) if comps == 1 else (self.height, self.width, 4)
+        return self._bufs[name].download(np.float32, shape)
+
+    def as_c(self):
+        return N.LayersC(*(C.c_void_p(self.ptrs[n]) for n in self.NAMES))
+
+    def free(self):
+        for b in self._bufs.values():
+            b.free()
+        self._bufs = {}
+
+
+class Renderer:
+    """Drop-in for the method surface of fredholm::Renderer that the apps use on the render path.
+
+    The OptiX pipeline-construction calls of the reference (create_module / create_program_group /
+    create_pipeline / create_sbt, renderer.h:124-352) are accepted and ignored: there is no OptiX
+    pipeline, the HIP kernels are compiled into the library."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        L = N.load_library()
+        rc = L.fh_ctx_create(int(device), C.byref(self._ctx))
+        if rc != N.FH_OK:
+            msg = L.fh_last_error(None)
+            self._ctx = None
+            raise N.FredholmError(f"fh_ctx_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.m_width = self.m_height = 0
+        self.seed = 1  # params.seed = 1 (renderer.h:664)
+        self._keep = None
+
+    # -- OptiX plumbing kept for call-compatibility
+    def create_module(self, filepath=None):
+        return None
+
+    def create_program_group(self):
+        return None
+
+    def create_pipeline(self):
+        return None
+
+    def create_sbt(self):
+        return None
+
+    def close(self):
+        if self._ctx:
+            N.lib().fh_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        N.check(self._ctx, rc, what)
+
+    def set_flags(self, flags):
+        self._ck(N.lib().fh_set_flags(self._ctx, C.c_uint32(flags)), "fh_set_flags")
+
+    # -- scene (renderer.h:354-432)
+    def load_scene(self, scene, clear=True):
+        """scene: dict of flat arrays as produced by fredholm_amd.scenes (the layout Scene exposes, scene.h:103-135)."""
+        v = np.ascontiguousarray(scene["vertices"], dtype=np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(scene["normals"], dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(scene["texcoords"], dtype=np.float32).reshape(-1, 2)
+        idx = np.ascontiguousarray(scene["indices"], dtype=np.uint32).reshape(-1, 3)
+        mid = np.ascontiguousarray(scene["material_ids"], dtype=np.uint32)
+        mats = np.ascontiguousarray(scene["materials"])
+        assert mats.dtype.itemsize == 180
+        inst = scene.get("instance_ids")
+        inst = None if inst is None else np.ascontiguousarray(inst, dtype=np.uint32)
+        o2w = scene.get("object_to_world")
+        w2o = scene.get("world_to_object")
+        d = N.SceneDesc()
+        d.n_vertices = v.shape[0]
+        d.vertices, d.normals, d.texcoords = N.ptr(v), N.ptr(n), N.ptr(t)
+        d.n_faces = idx.shape[0]
+        d.indices, d.material_ids, d.instance_ids = N.ptr(idx), N.ptr(mid), N.ptr(inst)
+        d.n_materials = mats.shape[0]
+        d.materials = N.ptr(mats)
+        if o2w is not None:
+            o2w = np.ascontiguousarray(o2w, dtype=np.float32).reshape(-1, 12)
+            w2o = np.ascontiguousarray(w2o, dtype=np.float32).reshape(-1, 12)
+            d.n_instances = o2w.shape[0]
+            d.object_to_world, d.world_to_object = N.ptr(o2w), N.ptr(w2o)
+        self._keep = (v, n, t, idx, mid, mats, inst, o2w, w2o)
+        self._ck(N.lib().fh_scene_upload(self._ctx, C.byref(d)), "fh_scene_upload")
+
+    def build_gas(self):
+        """renderer.h:434-496; the whole acceleration structure is built by build_ias' counterpart"""
+        return None
+
+    def build_ias(self):
+        """renderer.h:498-552 -> on-device BVH build"""
+        self._ck(N.lib().fh_bvh_build(self._ctx), "fh_bvh_build")
+
+    def build_accel(self):
+        self.build_ias()
+
+    def set_transforms(self, object_to_world, world_to_object):
+        o = np.ascontiguousarray(object_to_world, dtype=np.float32).reshape(-1, 12)
+        w = np.ascontiguousarray(world_to_object, dtype=np.float32).reshape(-1, 12)
+        self._ck(N.lib().fh_set_transforms(self._ctx, C.c_uint32(o.shape[0]), N.ptr(o), N.ptr(w)), "fh_set_transforms")
+
+    def n_lights(self):
+        out = C.c_uint32()
+        self._ck(N.lib().fh_scene_n_lights(self._ctx, C.byref(out)), "fh_scene_n_lights")
+        return out.value
+
+    # -- environment (renderer.h:554-612)
+    def set_directional_light(self, le, direction, angle):
+        le = np.asarray(le, dtype=np.float32)
+        d = np.asarray(direction, dtype=np.float32)
+        self._ck(N.lib().fh_set_directional_light(self._ctx, N.ptr(le), N.ptr(d), C.c_float(angle)), "fh_set_directional_light")
+
+    def clear_directional_light(self):
+        self._ck(N.lib().fh_clear_directional_light(self._ctx), "fh_clear_directional_light")
+
+    def set_sky_intensity(self, v):
+        self._ck(N.lib().fh_set_sky_intensity(self._ctx, C.c_float(v)), "fh_set_sky_intensity")
+
+    def load_arhosek_sky(self, turbidity, albedo):
+        self._ck(N.lib().fh_load_arhosek_sky(self._ctx, C.c_float(turbidity), C.c_float(albedo)), "fh_load_arhosek_sky")
+
+    def clear_arhosek_sky(self):
+        self._ck(N.lib().fh_clear_arhosek_sky(self._ctx), "fh_clear_arhosek_sky")
+
+    # -- frame state (renderer.h:642-655)
+    def set_resolution(self, width, height):
+        self.m_width, self.m_height = int(width), int(height)
+        self._ck(N.lib().fh_set_resolution(self._ctx, C.c_uint32(width), C.c_uint32(height)), "fh_set_resolution")
+
+    def init_render_states(self):
+        self._ck(N.lib().fh_init_render_states(self._ctx), "fh_init_render_states")
+
+    def set_tile_shard(self, rank, world, tile_w=32, tile_h=32):
+        self._ck(N.lib().fh_set_tile_shard(self._ctx, C.c_uint32(rank), C.c_uint32(world), C.c_uint32(tile_w), C.c_uint32(tile_h)), "fh_set_tile_shard")
+
+    def owned_pixel_count(self):
+        out = C.c_uint32()
+        self._ck(N.lib().fh_owned_pixel_count(self._ctx, C.byref(out)), "fh_owned_pixel_count")
+        return out.value
+
+    def pack_owned(self, layer_ptr, floats_per_pixel, packed_ptr):
+        self._ck(N.lib().fh_pack_owned(self._ctx, C.c_void_p(layer_ptr), C.c_uint32(floats_per_pixel), C.c_void_p(packed_ptr)), "fh_pack_owned")
+
+    def unpack_shard(self, rank, world, packed_ptr, floats_per_pixel, layer_ptr):
+        self._ck(N.lib().fh_unpack_shard(self._ctx, C.c_uint32(rank), C.c_uint32(world), C.c_void_p(packed_ptr), C.c_uint32(floats_per_pixel), C.c_void_p(layer_ptr)), "fh_unpack_shard")
+
+    # -- the hot path (renderer.h:657-736)
+    def render(self, camera, bg_color, render_layer, n_samples, max_depth):
+        cam = camera.as_c()
+        bg = np.asarray(bg_color, dtype=np.float32)
+        layers = render_layer.as_c()
+        self._ck(N.lib().fh_render(self._ctx, C.byref(cam), N.ptr(bg), C.byref(layers), C.c_uint32(n_samples), C.c_uint32(max_depth), C.c_uint32(self.seed)), "fh_render")
+
+    def wait_for_completion(self):
+        self._ck(N.lib().fh_sync(self._ctx), "fh_sync")
+
+    def stats(self):
+        s = N.StatsC()
+        self._ck(N.lib().fh_get_stats(self._ctx, C.byref(s)), "fh_get_stats")
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._ck(N.lib().fh_reset_stats(self._ctx), "fh_reset_stats")
+
+    def stream(self):
+        return N.lib().fh_stream(self._ctx)
+
+    # -- post chain (kernels/post-process.h:126-128)
+    def post_process(self, beauty_in_ptr, high_ptr, temp_ptr, width, height, params, beauty_out_ptr):
+        pp = params.as_c()
+        self._ck(N.lib().fh_post_process(self._ctx, C.c_void_p(beauty_in_ptr), C.c_void_p(high_ptr), C.c_void_p(temp_ptr), int(width), int(height), C.byref(pp), C.c_void_p(beauty_out_ptr)),
+                 "fh_post_process")
+
+    # -- parity-test hooks
+    def trace_rays(self, rays7, any_hit=False):
+        r = np.ascontiguousarray(rays7, dtype=np.float32).reshape(-1, 7)
+        tuv = np.zeros((r.shape[0], 3), dtype=np.float32)
+        prim = np.zeros(r.shape[0], dtype=np.uint32)
+        self._ck(N.lib().fh_trace_rays(self._ctx, C.c_uint32(r.shape[0]), N.ptr(r), int(any_hit), N.ptr(tuv), N.ptr(prim)), "fh_trace_rays")
+        return tuv, prim

@@ -1,0 +1,180 @@
+/* fredholm_hip.h -- C ABI of libfredholm_hip.so, the MI355X (gfx950) replacement for the render
+ * loop of yumcyaWiz/fredholm.
+ *
+ * The reference has no FFI: applications call the header-only C++ class fredholm::Renderer
+ * (fredholm/include/fredholm/renderer.h) directly.  Each entry point below is what one of its
+ * methods forwards to in the drop-in facade (include/fredholm/renderer.h in this repo); the
+ * reference method it replaces is cited as file:line.  All arguments are plain pointers and
+ * sizes; device pointers are HIP device addresses owned by the caller unless stated otherwise.
+ *
+ * Error convention: every function returns FH_OK (0) or a negative FH_E_* code and records a
+ * message retrievable with fh_last_error(); the C++ facade turns non-zero into
+ * std::runtime_error, matching the reference's CUDA_CHECK / OPTIX_CHECK behaviour
+ * (cwl/include/cwl/util.h:11-34, optwl/include/optwl/optwl.h:11-35).
+ * Threading: one host thread drives a context (reference: gui thread / rtcamp8 render thread);
+ * fh_render is asynchronous on the context's private HIP stream, fh_sync blocks.
+ */
+#ifndef FREDHOLM_HIP_H
+#define FREDHOLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FH_OK 0
+#define FH_E_INVALID -1      /* bad argument / state */
+#define FH_E_HIP -2          /* a HIP runtime call failed */
+#define FH_E_UNSUPPORTED -3  /* feature present in the reference but not in this build (textures, IBL) */
+
+typedef struct fh_ctx fh_ctx;
+
+/* 180-byte material record, field-for-field the reference's Material (fredholm/include/fredholm/shared.h:100-142) */
+typedef struct fh_material {
+  float diffuse; float base_color[3]; int32_t base_color_texture_id; float diffuse_roughness;
+  float specular; float specular_color[3]; int32_t specular_color_texture_id; float specular_roughness; int32_t specular_roughness_texture_id;
+  float metalness; int32_t metalness_texture_id; int32_t metallic_roughness_texture_id;
+  float coat; int32_t coat_texture_id; float coat_color[3]; float coat_roughness; int32_t coat_roughness_texture_id;
+  float transmission; float transmission_color[3];
+  float sheen; float sheen_color[3]; float sheen_roughness;
+  float subsurface; float subsurface_color[3];
+  float thin_walled;
+  float emission; float emission_color[3]; int32_t emission_texture_id;
+  int32_t heightmap_texture_id; int32_t normalmap_texture_id; int32_t alpha_texture_id;
+} fh_material;
+
+/* Host-side flat scene, exactly the arrays Renderer::load_scene uploads (renderer.h:361-421; Scene members scene.h:103-135).
+ * transforms are 3x4 row-major object_to_world / world_to_object per instance (renderer.h:404-421); NULL / 0 = one identity. */
+typedef struct fh_scene_desc {
+  uint32_t n_vertices;
+  const float* vertices;  /* float3[n_vertices] */
+  const float* normals;   /* float3[n_vertices] */
+  const float* texcoords; /* float2[n_vertices] */
+  uint32_t n_faces;
+  const uint32_t* indices;      /* uint3[n_faces] */
+  const uint32_t* material_ids; /* uint[n_faces]  */
+  const uint32_t* instance_ids; /* uint[n_faces], may be NULL (all 0) */
+  uint32_t n_materials;
+  const fh_material* materials;
+  uint32_t n_instances;
+  const float* object_to_world; /* float[12] per instance, may be NULL */
+  const float* world_to_object; /* float[12] per instance, may be NULL */
+} fh_scene_desc;
+
+/* CameraParams (shared.h:59-64): camera-to-world 3x4 rows, vertical fov in radians, F-number, focus distance */
+typedef struct fh_camera {
+  float transform[12];
+  float fov, F, focus;
+} fh_camera;
+
+/* RenderLayer (shared.h:201-208): six caller-owned device buffers of width*height elements */
+typedef struct fh_render_layers {
+  float* beauty;   /* float4 */
+  float* position; /* float4 */
+  float* depth;    /* float  */
+  float* normal;   /* float4 */
+  float* texcoord; /* float4 */
+  float* albedo;   /* float4 */
+} fh_render_layers;
+
+/* PostProcessParams (fredholm/kernels/include/kernels/post-process.h:4-10) */
+typedef struct fh_post_params {
+  int32_t use_bloom;
+  float bloom_threshold, bloom_sigma, ISO, chromatic_aberration;
+} fh_post_params;
+
+/* counters / timers of the last fh_render .. fh_sync interval, see fh_get_stats */
+typedef struct fh_stats {
+  double render_ms;        /* HIP-event time of the whole fh_render submission on the context stream */
+  double trace_closest_ms; /* summed HIP-event time of the closest-hit traversal kernel launches */
+  double trace_shadow_ms;  /* summed time of the any-hit / secondary traversal kernel launches */
+  double shade_ms;         /* summed time of the shade kernels */
+  uint64_t n_closest_launches, n_shadow_launches;
+  uint64_t rays_closest, rays_shadow;          /* rays submitted to the two traversal kernels */
+  uint64_t nodes_closest, tris_closest;        /* node visits / triangle tests (only when FH_FLAG_COUNT_TRAVERSAL) */
+  uint64_t nodes_shadow, tris_shadow;
+  uint64_t paths;                              /* camera paths started */
+  double bvh_build_ms;
+  uint64_t bvh_nodes, bvh_node_bytes, bvh_tri_bytes;
+} fh_stats;
+
+#define FH_FLAG_TIME_KERNELS 1u    /* bracket traversal/shade launches with HIP events (fh_stats *_ms) */
+#define FH_FLAG_COUNT_TRAVERSAL 2u /* instrumented traversal kernels: count node visits / triangle tests */
+
+/* -- context: replaces optwl::Context + Renderer ctor/dtor (optwl.h:41-81, renderer.h:32-122) */
+int fh_ctx_create(int device, fh_ctx** out);
+int fh_ctx_destroy(fh_ctx* ctx);
+const char* fh_last_error(fh_ctx* ctx); /* ctx may be NULL for creation errors */
+int fh_set_flags(fh_ctx* ctx, uint32_t flags);
+
+/* -- scene: Renderer::load_scene upload + AreaLight extraction (renderer.h:354-432) */
+int fh_scene_upload(fh_ctx* ctx, const fh_scene_desc* scene);
+/* Renderer::build_gas + build_ias (renderer.h:434-552): on-device LBVH build + wide-BVH collapse */
+int fh_bvh_build(fh_ctx* ctx);
+/* Renderer::set_time's transform re-upload + IAS rebuild (renderer.h:614-640); call fh_bvh_build afterwards */
+int fh_set_transforms(fh_ctx* ctx, uint32_t n_instances, const float* object_to_world, const float* world_to_object);
+int fh_scene_n_lights(fh_ctx* ctx, uint32_t* out);
+
+/* -- environment: renderer.h:554-612.  le/dir are float[3]; angle in degrees. */
+int fh_set_directional_light(fh_ctx* ctx, const float* le, const float* dir, float angle);
+int fh_clear_directional_light(fh_ctx* ctx);
+int fh_set_sky_intensity(fh_ctx* ctx, float intensity);
+int fh_load_arhosek_sky(fh_ctx* ctx, float turbidity, float albedo); /* renderer.h:588-607 */
+int fh_clear_arhosek_sky(fh_ctx* ctx);                               /* renderer.h:609-612 */
+int fh_load_ibl(fh_ctx* ctx, const float* rgba, uint32_t w, uint32_t h); /* renderer.h:574-581: FH_E_UNSUPPORTED in this round */
+
+/* -- frame state: renderer.h:642-655 */
+int fh_set_resolution(fh_ctx* ctx, uint32_t width, uint32_t height); /* also resets the sample counters */
+int fh_init_render_states(fh_ctx* ctx);                              /* sample_count = 0 */
+/* pixel-tile sharding for multi-GPU rendering: this context renders only the tiles t with t % world == rank
+ * (tiles of tile_w x tile_h pixels, row-major tile order).  world = 1 renders everything (default). */
+int fh_set_tile_shard(fh_ctx* ctx, uint32_t rank, uint32_t world, uint32_t tile_w, uint32_t tile_h);
+/* number of pixels this context owns, and pack/unpack of owned pixels for the framebuffer gather */
+int fh_owned_pixel_count(fh_ctx* ctx, uint32_t* out);
+int fh_pack_owned(fh_ctx* ctx, const float* layer, uint32_t floats_per_pixel, float* packed);
+int fh_unpack_shard(fh_ctx* ctx, uint32_t rank, uint32_t world, const float* packed, uint32_t floats_per_pixel, float* layer);
+
+/* -- THE hot path: Renderer::render (renderer.h:657-734) -> __raygen__rg & friends (fredholm/modules/pt.cu:418-999).
+ * Adds n_samples samples per owned pixel to the running means in `layers`; equivalent to n_samples consecutive
+ * reference launches with n_samples = 1 (the reference's only well-defined mode). seed: reference uses 1. */
+int fh_render(fh_ctx* ctx, const fh_camera* camera, const float* bg_color, const fh_render_layers* layers, uint32_t n_samples, uint32_t max_depth, uint32_t seed);
+int fh_sync(fh_ctx* ctx); /* Renderer::wait_for_completion (renderer.h:736) */
+int fh_get_stats(fh_ctx* ctx, fh_stats* out);
+int fh_reset_stats(fh_ctx* ctx);
+
+/* -- post chain: post_process_kernel_launch (fredholm/kernels/src/post-process.cu:5-35); all device pointers, float4 images */
+int fh_post_process(fh_ctx* ctx, const float* beauty_in, float* beauty_high_luminance, float* beauty_temp, int width, int height, const fh_post_params* params, float* beauty_out);
+
+/* -- device memory helpers (stand in for cwl::CUDABuffer, cwl/include/cwl/buffer.h:18-85) */
+int fh_malloc(fh_ctx* ctx, uint64_t bytes, void** out);
+int fh_free(fh_ctx* ctx, void* ptr);
+int fh_memset(fh_ctx* ctx, void* ptr, int value, uint64_t bytes);
+int fh_copy_to_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int fh_copy_to_host(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+void* fh_stream(fh_ctx* ctx); /* hipStream_t of the context */
+
+/* -- batch queries used by the parity tests (device evaluation of the same code the kernels run) */
+/* rays7: o.xyz d.xyz tmax per ray (host memory).  tuv: 3 floats, prim: face id or 0xffffffff (host memory). */
+int fh_trace_rays(fh_ctx* ctx, uint32_t n, const float* rays7, int any_hit, float* tuv, uint32_t* prim);
+/* kind 0: xxhash32(a) ; 1: xxhash32(a,b,c) ; 2: xxhash32(a,b,c,d) ; 3: cmj_permute(a,b,c); in: uint32[4] per item */
+int fh_kat_hash(fh_ctx* ctx, int kind, uint32_t n, const uint32_t* in4, uint32_t* out);
+/* CMJ 2-D draws: in = (n_spp, image_idx, slot, seed) per item, out 2 floats */
+int fh_kat_cmj(fh_ctx* ctx, uint32_t n, const uint32_t* in4, float* out2);
+/* Owen-Sobol draws: in = (index32, dimension, seed_hash, unused) per item, out 1 float */
+int fh_kat_sobol(fh_ctx* ctx, uint32_t n, const uint32_t* in4, float* out);
+/* elementary functions of include/fh_elementary.h evaluated on the device; fn as in the checker */
+int fh_kat_elementary(fh_ctx* ctx, int fn, uint32_t n, const float* x, const float* y, float* out);
+/* warps: kind 0 disk, 1 cosine hemisphere, 2 triangle, 3 vndf(wo, alpha) */
+int fh_kat_warp(fh_ctx* ctx, int kind, uint32_t n, const float* u2, const float* wo3, const float* alpha2, float* out);
+/* BSDF: 18 floats per item {eval.rgb, pdf, sample.wi, sample.f, sample.pdf, lobe weights-as-pmf[7]} */
+int fh_kat_bsdf(fh_ctx* ctx, const fh_material* material, int entering, uint32_t lobes_mask, uint32_t n, const float* wo3, const float* wi3, const float* u1, const float* u2, float* out18);
+int fh_kat_sky(fh_ctx* ctx, uint32_t n, const float* dirs3, float* out3);          /* uses the context's Hosek state */
+int fh_kat_hosek_state(fh_ctx* ctx, float* out30);                                  /* cooked cfg[3][9] + rad[3] */
+int fh_kat_camera(fh_ctx* ctx, const fh_camera* cam, uint32_t width, uint32_t height, uint32_t seed, uint32_t n, const uint32_t* pixel_idx, const uint32_t* n_spp, float* out6);
+int fh_kat_offset_origin(fh_ctx* ctx, uint32_t n, const float* p3, const float* n3, float* out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -807,7 +807,7 @@ void orc_warp(int kind, int n, const float* u, const float* wo, const float* alp
   }
 }
 // BSDF known answers for one material: per sample i, wo[i], wi[i], u1[i], u2[i] ->
-//   out[i] = { eval.rgb, eval_pdf, sample.wi.xyz, sample.f.rgb, sample.pdf, weights[7] } (18 floats)
+//   out[i] = { eval.rgb, eval_pdf, sample.wi.xyz, sample.f.rgb, sample.pdf, lobe pmf[7] } (18 floats)
 void orc_bsdf(const void* material180, int entering, int n, const float* wo, const float* wi, const float* u1, const float* u2, float* out)
 {
   const ShadingParams sp = shading_params(*(const Material*)material180);
@@ -820,7 +820,7 @@ void orc_bsdf(const void* material180, int entering, int n, const float* wo, con
     float* r = out + 18 * i;
     r[0] = e.x; r[1] = e.y; r[2] = e.z; r[3] = b.eval_pdf(o, in);
     r[4] = swi.x; r[5] = swi.y; r[6] = swi.z; r[7] = f.x; r[8] = f.y; r[9] = f.z; r[10] = pdf;
-    for (int k = 0; k < 7; ++k) r[11 + k] = b.weights[k];
+    for (int k = 0; k < 7; ++k) r[11 + k] = b.dist.pmf(k);
   }
 }
 void orc_hosek_cook(float turbidity, float albedo, const float* sun_dir, float* out30)
