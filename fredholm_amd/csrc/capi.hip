@@ -232,6 +232,16 @@ int fh_set_flags(fh_ctx* ctx, uint32_t flags)
   return FH_OK;
 }
 
+int fh_set_path_pool(fh_ctx* ctx, uint32_t target)
+{
+  CTX_CHECK(ctx);
+  if (target == 0) return fail(ctx, FH_E_INVALID, "fh_set_path_pool: zero");
+  (void)hipStreamSynchronize(ctx->stream);
+  pool_release(ctx);
+  ctx->pool_target = target;
+  return FH_OK;
+}
+
 int fh_scene_upload(fh_ctx* ctx, const fh_scene_desc* s)
 {
   CTX_CHECK(ctx);

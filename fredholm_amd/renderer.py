@@ -184,6 +184,9 @@ class Renderer:
     def set_flags(self, flags):
         self._ck(N.lib().fh_set_flags(self._ctx, C.c_uint32(flags)), "fh_set_flags")
 
+    def set_path_pool(self, target_paths):
+        self._ck(N.lib().fh_set_path_pool(self._ctx, C.c_uint32(target_paths)), "fh_set_path_pool")
+
     # -- scene (renderer.h:354-432)
     def load_scene(self, scene, clear=True):
         """scene: dict of flat arrays as produced by fredholm_amd.scenes (the layout Scene exposes, scene.h:103-135)."""

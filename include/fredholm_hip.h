@@ -107,6 +107,9 @@ int fh_ctx_create(int device, fh_ctx** out);
 int fh_ctx_destroy(fh_ctx* ctx);
 const char* fh_last_error(fh_ctx* ctx); /* ctx may be NULL for creation errors */
 int fh_set_flags(fh_ctx* ctx, uint32_t flags);
+/* target number of camera paths in flight per pass (path-pool slots); a pass starts floor(target / owned pixels) >= 1
+ * samples per pixel.  Results do not depend on it.  Default 4 Mi paths. */
+int fh_set_path_pool(fh_ctx* ctx, uint32_t target_paths);
 
 /* -- scene: Renderer::load_scene upload + AreaLight extraction (renderer.h:354-432) */
 int fh_scene_upload(fh_ctx* ctx, const fh_scene_desc* scene);

@@ -1,0 +1,304 @@
+"""CPU tests of the checker (oracle/): anchors recorded from the reference, algebraic properties of
+the published algorithms it restates, and self-consistency of its BVH.
+
+The reference ships no tests or golden vectors and cannot be built here
+(needs CUDA + OptiX), so the only reference-derived pins are the values the survey observed when
+it ran the reference's own device functions (SURVEY.md 8(c) "Anchor values").
+"""
+import numpy as np
+import pytest
+
+from fredholm_amd import scenes
+from fredholm_amd.native import MATERIAL_DTYPE, default_materials
+from fredholm_amd.renderer import Camera
+
+
+# ---------------------------------------------------------------- anchors from SURVEY.md 8(c)
+def test_anchor_xxhash32(oracle):
+    assert oracle.xxhash32(1) == 2491795611
+
+
+def test_anchor_cmj_permute(oracle):
+    assert oracle.cmj_permute(7, 16, 0xDEADBEEF) == 1
+
+
+def test_anchor_cmj_2d(oracle):
+    got = oracle.cmj_2d(n_spp=5, scramble=oracle.xxhash32(1), depth=0, image_idx=12345, count=2)
+    want = np.array([[0.349114656, 0.525536358], [0.702345967, 0.0134506952]], dtype=np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_anchor_sobol_owen(oracle):
+    got = oracle.sobol_owen(12345 + 5 * 1920 * 1080, 1, oracle.xxhash32(1), count=2)
+    want = np.array([0.75995481, 0.892689586], dtype=np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_anchor_struct_sizes():
+    assert MATERIAL_DTYPE.itemsize == 180  # Material, shared.h:100-142
+
+
+# ---------------------------------------------------------------- published-algorithm properties
+def test_cmj_permute_is_a_permutation(oracle):
+    for l in (4, 16, 7, 100):
+        for p in (0, 1, 0xDEADBEEF, 0x12345678):
+            vals = sorted(oracle.cmj_permute(i, l, p) for i in range(l))
+            assert vals == list(range(l))
+
+
+def test_cmj_pattern_is_stratified(oracle):
+    # Kensler 2013: the 16 samples of one pattern hit every cell of the 4x4 grid and every 1/16 column and row once
+    for scramble in (1, 99, 0xABCDEF01):
+        for image_idx in (0, 77):
+            pts = np.array([oracle.cmj_2d(n, scramble, 3, image_idx)[0] for n in range(16)])
+            assert ((pts >= 0) & (pts < 1)).all()
+            cells = set((int(x * 4), int(y * 4)) for x, y in pts)
+            assert len(cells) == 16
+            assert sorted(int(x * 16) for x in pts[:, 0]) == list(range(16))
+            assert sorted(int(y * 16) for y in pts[:, 1]) == list(range(16))
+
+
+def test_sobol_dimension0_is_van_der_corput(oracle):
+    for i in (1, 2, 3, 12345, 0xFFFFFFFF):
+        want = int(format(i & 0xFFFFFFFF, "032b")[::-1], 2)
+        assert oracle.sobol_raw(i, 0) == want
+
+
+def test_sobol_is_a_digital_net(oracle):
+    # every dimension: the first 2^k points fall in distinct 2^-k intervals, and XOR-linearity holds
+    for dim in (1, 2, 5, 17, 64):
+        v = np.array([oracle.sobol_raw(i, dim) for i in range(256)], dtype=np.uint64)
+        assert len(set((v >> 24).tolist())) == 256
+        assert oracle.sobol_raw(5 ^ 9, dim) == oracle.sobol_raw(5, dim) ^ oracle.sobol_raw(9, dim)
+
+
+def test_owen_scramble_keeps_stratification(oracle):
+    seed = oracle.xxhash32(1)
+    for dim in (1, 2, 3):
+        # 256 consecutive Sobol' points (after the index scramble these are a permutation of a 2^8 block)
+        base = 256 * 1234
+        vals = np.array([oracle.sobol_owen(base + i, dim, seed)[0] for i in range(256)])
+        assert ((vals >= 0) & (vals <= 1)).all()
+        assert len(set(np.floor(vals.astype(np.float64) * 256).astype(int).tolist())) == 256
+
+
+def test_sobol_index_truncated_to_32_bits(oracle):
+    # sobol.cu:10733-10735 passes the 64-bit index through an `unsigned int` parameter
+    seed = oracle.xxhash32(1)
+    assert oracle.sobol_owen((1 << 32) + 17, 3, seed)[0] == oracle.sobol_owen(17, 3, seed)[0]
+
+
+def test_offset_origin_moves_along_normal(oracle):
+    p = np.array([0.5, -2.0, 0.001], np.float32)
+    n = np.array([0.0, -1.0, 1.0], np.float32) / np.sqrt(2).astype(np.float32)
+    q = oracle.offset_origin(p, n)
+    assert q[0] == p[0] and q[1] < p[1] and q[2] > p[2]
+    assert abs(q[1] - p[1]) < 1e-4 and abs(q[2] - p[2]) < 1e-4
+
+
+# ---------------------------------------------------------------- shared elementary functions vs float64 libm
+def _ulp_err(got, want64):
+    want32 = want64.astype(np.float32)
+    ulp = np.spacing(np.abs(want32)).astype(np.float64)
+    return np.abs(got.astype(np.float64) - want64) / np.maximum(ulp, 1e-45)
+
+
+def test_elementary_accuracy(oracle):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-7.0, 7.0, 200000).astype(np.float32)
+    assert _ulp_err(oracle.elementary("sin", x), np.sin(x.astype(np.float64)))[np.abs(np.sin(x)) > 1e-3].max() < 2.5
+    assert _ulp_err(oracle.elementary("cos", x), np.cos(x.astype(np.float64)))[np.abs(np.cos(x)) > 1e-3].max() < 2.5
+    assert np.abs(oracle.elementary("sin", x) - np.sin(x.astype(np.float64))).max() < 2e-7
+    e = rng.uniform(-80, 80, 200000).astype(np.float32)
+    assert _ulp_err(oracle.elementary("exp", e), np.exp(e.astype(np.float64))).max() < 2.0
+    p = rng.uniform(1e-6, 50.0, 200000).astype(np.float32)
+    assert _ulp_err(oracle.elementary("log", p), np.log(p.astype(np.float64)))[np.abs(np.log(p)) > 1e-3].max() < 1.0
+    y = rng.uniform(-8, 8, 200000).astype(np.float32)
+    assert _ulp_err(oracle.elementary("pow", p, y), np.power(p.astype(np.float64), y.astype(np.float64))).max() < 1.0
+    c = rng.uniform(-1, 1, 200000).astype(np.float32)
+    assert _ulp_err(oracle.elementary("acos", c), np.arccos(c.astype(np.float64))).max() < 3.0
+    a, b = rng.normal(size=100000).astype(np.float32), rng.normal(size=100000).astype(np.float32)
+    assert np.abs(oracle.elementary("atan2", a, b) - np.arctan2(a.astype(np.float64), b.astype(np.float64))).max() < 1e-6
+
+
+def test_elementary_special_cases(oracle):
+    assert np.isnan(oracle.elementary("acos", [1.0000001])[0])  # dot(sun, dir) may exceed 1: pt.cu:355 has no clamp
+    assert oracle.elementary("pow", [0.0], [2.5])[0] == 0.0
+    assert oracle.elementary("pow", [3.0], [0.0])[0] == 1.0
+    assert np.isnan(oracle.elementary("pow", [-0.5], [1.5])[0])
+    assert oracle.elementary("exp", [-200.0])[0] == 0.0 and np.isinf(oracle.elementary("exp", [100.0])[0])
+
+
+# ---------------------------------------------------------------- warps
+def test_warps_land_where_they_should(oracle):
+    rng = np.random.default_rng(3)
+    u = rng.uniform(0, 1, (5000, 2)).astype(np.float32)
+    d = oracle.warp(0, u)
+    assert (np.linalg.norm(d, axis=1) <= 1.0 + 1e-6).all()
+    h = oracle.warp(1, u)
+    assert np.allclose(np.linalg.norm(h, axis=1), 1.0, atol=1e-5) and (h[:, 1] >= 0).all()
+    t = oracle.warp(2, u)
+    assert ((t >= 0).all()) and ((t.sum(axis=1) <= 1 + 1e-6).all())
+    wo = np.tile(np.array([0.3, 0.8, -0.52], np.float32), (5000, 1))
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    nh = oracle.warp(3, u, wo=wo, alpha=np.array([0.04, 0.04], np.float32))
+    assert np.allclose(np.linalg.norm(nh, axis=1), 1.0, atol=1e-5) and (nh[:, 1] >= 0).all()
+    assert ((nh * wo).sum(axis=1) > -1e-4).all()  # visible normals face the viewer
+
+
+# ---------------------------------------------------------------- BSDF restatement sanity
+def _dirs(rng, n, up=True):
+    v = rng.normal(size=(n, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    if up:
+        v[:, 1] = np.abs(v[:, 1]) + 1e-3
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return v
+
+
+def test_bsdf_pmf_sums_to_one_and_sampled_pdf_matches(oracle):
+    rng = np.random.default_rng(5)
+    m = default_materials(1)
+    m["metalness"] = 0.3
+    m["coat"] = 0.5
+    m["sheen"] = 0.4
+    n = 2000
+    wo, wi = _dirs(rng, n), _dirs(rng, n)
+    out = oracle.bsdf(m, True, wo, wi, rng.uniform(0, 1, n).astype(np.float32), rng.uniform(0, 1, (n, 2)).astype(np.float32))
+    assert np.allclose(out[:, 11:18].sum(axis=1), 1.0, atol=1e-5)
+    assert (out[:, 0:3] >= 0).all() and (out[:, 3] >= 0).all()
+    assert np.isfinite(out[:, :11]).all()
+
+
+def test_bsdf_backface_of_opaque_material_is_nan_weighted(oracle):
+    # bsdf.cu:56-62 zeroes every reflective lobe from inside -> 0/0 lobe table (sampling.cu:116-128)
+    m = default_materials(1)
+    wo = np.array([[0.2, 0.9, 0.1]], np.float32)
+    out = oracle.bsdf(m, False, wo, wo, [0.5], [[0.3, 0.6]])
+    assert np.isnan(out[0, 3]) and np.isnan(out[0, 10]) and np.isnan(out[0, 11:18]).all()
+    assert (out[0, 0:3] == 0).all()
+
+
+def test_diffuse_only_bsdf_is_lambert_at_zero_roughness(oracle):
+    m = default_materials(1)
+    m["specular"] = 0.0
+    m["base_color"][0] = (0.5, 0.25, 0.75)
+    rng = np.random.default_rng(7)
+    wo, wi = _dirs(rng, 500), _dirs(rng, 500)
+    out = oracle.bsdf(m, True, wo, wi, np.full(500, 0.5, np.float32), rng.uniform(0, 1, (500, 2)).astype(np.float32))
+    assert np.allclose(out[:, 0:3], np.array([0.5, 0.25, 0.75]) / np.pi, rtol=1e-6)
+    assert np.allclose(out[:, 3], np.abs(wi[:, 1]) / np.pi, rtol=1e-6)
+
+
+# ---------------------------------------------------------------- sky
+def test_hosek_sky_is_positive_above_horizon_and_nan_below(oracle):
+    sun = np.array(scenes.SOUP_SUN, np.float32)
+    sun /= np.linalg.norm(sun)
+    st = oracle.hosek_cook(3.0, 0.3, sun)
+    assert np.isfinite(st).all() and (st[27:30] > 0).all()
+    up = _dirs(np.random.default_rng(1), 1000)
+    rad = oracle.hosek_radiance(st, sun, 1.0, up)
+    assert np.isfinite(rad).all() and (rad > 0).all()
+    down = up.copy()
+    down[:, 1] = -np.abs(down[:, 1]) - 0.05
+    down /= np.linalg.norm(down, axis=1, keepdims=True)
+    assert np.isnan(oracle.hosek_radiance(st, sun, 1.0, down)).all()  # sqrt(cos(theta)) of arhosek.cu:113
+
+
+# ---------------------------------------------------------------- geometry
+def test_bvh_matches_brute_force(oracle):
+    sc = scenes.triangle_soup(3000, 0.15)
+    S = oracle.Scene(sc)
+    rng = np.random.default_rng(11)
+    n = 4000
+    o = rng.uniform(-1.3, 1.3, (n, 3)).astype(np.float32)
+    d = _dirs(rng, n, up=False)
+    rays = np.concatenate([o, d, np.full((n, 1), 1e9, np.float32)], axis=1)
+    tuv_a, prim_a = S.trace(rays)
+    tuv_b, prim_b = S.trace(rays, brute=True)
+    assert np.array_equal(prim_a, prim_b)
+    assert np.array_equal(tuv_a.view(np.uint32), tuv_b.view(np.uint32))
+    occ_a = S.trace(rays, any_hit=True)[1] != 0xFFFFFFFF
+    assert np.array_equal(occ_a, prim_b != 0xFFFFFFFF)
+    assert 0.2 < (prim_a != 0xFFFFFFFF).mean() < 0.999
+
+
+def test_cornell_box_is_closed_and_wound_inwards(oracle):
+    sc = scenes.cornell_box()
+    assert sc["indices"].shape[0] == 36
+    S = oracle.Scene(sc)
+    assert S.n_lights() == 2
+    rng = np.random.default_rng(2)
+    n = 5000
+    o = np.tile(np.array([0.0, 1.0, 0.9], np.float32), (n, 1))
+    d = _dirs(rng, n, up=False)
+    d[:, 2] = -np.abs(d[:, 2])  # into the room: every ray must hit something
+    rays = np.concatenate([o, d, np.full((n, 1), 1e9, np.float32)], axis=1)
+    tuv, prim = S.trace(rays)
+    assert (prim != 0xFFFFFFFF).all()
+    # front faces only: geometric normal opposes the ray
+    v = sc["vertices"].reshape(-1, 3, 3)[prim]
+    ng = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    assert ((ng * d).sum(axis=1) < 0).all()
+
+
+# ---------------------------------------------------------------- integrator behaviour
+def test_progressive_launches_accumulate_running_mean(oracle):
+    sc = scenes.cornell_box(diffuse_only=True)
+    S = oracle.Scene(sc)
+    cam = Camera(**scenes.CORNELL_CAMERA).params()
+    w = h = 24
+    a = S.new_layers(w, h)
+    for _ in range(3):
+        S.render(cam, w, h, a, 1, 4)
+    assert (a["sample_count"] == 3).all()
+    # the same three samples, kept separately, average to the same beauty (up to float rounding of the recurrence)
+    singles = []
+    for k in range(3):
+        b = S.new_layers(w, h)
+        b["sample_count"][:] = k
+        S.render(cam, w, h, b, 1, 4)
+        singles.append(b["beauty"] * np.float32(k + 1))  # empty history: coef * (k * 0 + radiance)
+    assert np.allclose(a["beauty"][..., :3], np.mean(singles, axis=0)[..., :3], rtol=1e-5, atol=1e-6)
+    assert (a["beauty"][..., 3] == 1).all() and np.isfinite(a["beauty"]).all()
+    assert (a["depth"] > 0).mean() > 0.9
+
+
+def test_multisample_launch_keeps_reference_firsthit_quirk(oracle):
+    # pt.cu:432 declares the payload outside the spp loop: after the first hitting sample of a launch,
+    # directly visible emitters are no longer added.  The checker reproduces it.
+    sc = scenes.cornell_box(diffuse_only=True)
+    S = oracle.Scene(sc)
+    cam = Camera(origin=(0.0, 1.2, 0.0), fov=0.5 * np.pi, F=100.0, focus=1e4, forward=(0.0, 1.0, -0.001)).params()
+    w = h = 8
+    one = S.new_layers(w, h)
+    for _ in range(4):
+        S.render(cam, w, h, one, 1, 3)
+    four = S.new_layers(w, h)
+    S.render(cam, w, h, four, 4, 3)
+    lit = one["beauty"][..., 0] > 1.0                             # pixels where some sample looks straight at the light (Le.r = 17)
+    assert lit.sum() >= 2
+    assert (four["beauty"][..., 0][lit] < 0.5 * one["beauty"][..., 0][lit]).all()
+    assert np.array_equal(four["beauty"][~lit], one["beauty"][~lit])  # everything else is unaffected by the quirk
+
+
+def test_energy_is_bounded_in_a_furnace_like_room(oracle):
+    # closed diffuse room, no emitter, constant background never seen: radiance must be exactly 0
+    sc = scenes.cornell_box(diffuse_only=True)
+    sc["materials"]["emission_color"][:] = 0
+    S = oracle.Scene(sc)
+    cam = Camera(**scenes.CORNELL_CAMERA).params()
+    L = S.new_layers(16, 16)
+    S.render(cam, 16, 16, L, 2, 4, bg=(0.0, 0.0, 0.0))
+    assert (L["beauty"][..., :3] == 0).all()
+
+
+def test_post_process_floor_division_quirk(oracle):
+    rng = np.random.default_rng(9)
+    img = rng.uniform(0, 4, (40, 50, 4)).astype(np.float32)
+    out = oracle.post_process(img, True, 2.0, 5.0, 80.0, 1.0)
+    assert (out[32:, :, :] == 0).all() and (out[:, 48:, :] == 0).all()  # rows/cols past the last full 16x16 block are never written
+    inner = out[:32, :48, :3]
+    assert (inner >= 0).all() and (inner <= 1.0001).all() and (out[:32, :48, 3] == 1).all()
+    plain = oracle.post_process(img, False, 2.0, 5.0, 80.0, 1.0)
+    assert (plain[:32, :48, :3] <= inner + 1e-6).all()  # bloom only adds light
