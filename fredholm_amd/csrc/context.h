@@ -69,7 +69,7 @@ struct fh_ctx {
 
   // stats
   fh_stats stats{};
-  unsigned long long* d_trace_counters = nullptr;  // nodes_closest, tris_closest, nodes_shadow, tris_shadow
+  unsigned long long* d_trace_counters = nullptr;  // nodes, tris, rays of the closest-hit kernel, then of the secondary kernel
   struct TimedSpan { hipEvent_t a, b; int kind; };
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> event_pool;

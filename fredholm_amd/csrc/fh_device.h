@@ -115,7 +115,7 @@ struct LayersDev {
 };
 
 // traversal statistics (only written by the instrumented kernel variants)
-struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; };
+struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; unsigned long long* rays; };
 
 // ---- wave-aggregated queue append: one atomic per wave (ballot + popcount prefix)
 FH_D void queue_push(uint32_t* counter, uint32_t* queue, bool active, uint32_t value)

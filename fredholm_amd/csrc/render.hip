@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(SceneDev sc, PoolDev p
   const uint32_t count = pool.counters[CNT_RAD0 + qsel];
   const uint32_t* q = pool.q_rad[qsel];
   const uint32_t stride = gridDim.x * blockDim.x;
-  uint32_t nn = 0, nt = 0;
+  uint32_t nn = 0, nt = 0, nr = 0;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
     const uint32_t i = base + threadIdx.x;
     const bool valid = i < count;
@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(SceneDev sc, PoolDev p
     uint32_t cls = 0;
     if (valid) {
       p = q[i];
+      if (COUNT) nr++;
       const float4 o = pool.ray_o[p], d = pool.ray_d[p];
       HitRec h;
       hit = traverse_bvh2<false, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
@@ -126,6 +127,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(SceneDev sc, PoolDev p
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
+    atomicAdd(tc.rays, (unsigned long long)nr);
   }
 }
 
@@ -365,7 +367,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDe
   const uint32_t count = pool.counters[CNT_SEC];
   const uint32_t stride = gridDim.x * blockDim.x;
   const bool has_lights = sc.n_lights > 0;
-  uint32_t nn = 0, nt = 0;
+  uint32_t nn = 0, nt = 0, nr = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
     const uint32_t p = pool.q_sec[i];
     f3 L = mk3(pool.rad[p]);
@@ -379,6 +381,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDe
       if (d.w == 0.0f) continue;
       const float4 o = pool.sec_o[k];
       HitRec h;
+      if (COUNT) nr++;
       const bool occluded = traverse_bvh2<true, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
       if (!occluded) L += mk3(pool.sec_c[k]);
     }
@@ -386,6 +389,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDe
       const size_t k = (size_t)SEC_LIGHT * pool.capacity + p;
       const float4 o = pool.sec_o[k], d = pool.sec_d[k];
       HitRec h;
+      if (COUNT) nr++;
       if (!has_lights) {
         const bool occluded = traverse_bvh2<true, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
         if (!occluded) L += mk3(pool.sec_c[k]);
@@ -432,6 +436,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDe
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
+    atomicAdd(tc.rays, (unsigned long long)nr);
   }
 }
 
@@ -614,8 +619,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const SceneDev sc = scene_dev(ctx);
   const PoolDev& pool = ctx->pool;
   const bool count = (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) != 0;
-  TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1};
-  TraceCounters tc_shadow{ctx->d_trace_counters + 2, ctx->d_trace_counters + 3};
+  TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2};
+  TraceCounters tc_shadow{ctx->d_trace_counters + 3, ctx->d_trace_counters + 4, ctx->d_trace_counters + 5};
 
   if (!ctx->render_pending) { (void)hipEventRecord(ctx->ev_render_begin, st); ctx->render_pending = true; }
 

@@ -91,7 +91,7 @@ typedef struct fh_stats {
   double trace_shadow_ms;  /* summed time of the any-hit / secondary traversal kernel launches */
   double shade_ms;         /* summed time of the shade kernels */
   uint64_t n_closest_launches, n_shadow_launches;
-  uint64_t rays_closest, rays_shadow;          /* rays submitted to the two traversal kernels */
+  uint64_t rays_closest, rays_shadow;          /* rays traced by the two traversal kernels (only when FH_FLAG_COUNT_TRAVERSAL) */
   uint64_t nodes_closest, tris_closest;        /* node visits / triangle tests (only when FH_FLAG_COUNT_TRAVERSAL) */
   uint64_t nodes_shadow, tris_shadow;
   uint64_t paths;                              /* camera paths started */
