@@ -18,6 +18,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <chrono>
+#include <cstdlib>
 
 #include "context.h"
 #include "fh_trace.h"
@@ -220,6 +221,176 @@ __global__ void k_emit_tris(const float4* face_rec, const uint32_t* sorted_face,
   tris[3 * i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// BVH8 collapse.  One thread per wide node: starting from the two children of a radix-tree node it
+// repeatedly opens the child with the largest surface area (among those holding more than
+// kLeafMax8 triangles) until eight children exist, assigns children to slots so that slot bits
+// agree with the octant of (child centre - node centre), quantises the boxes and hands the inner
+// children to the next level.  Levels are processed breadth first; node and triangle blocks are
+// allocated with atomics (the traversal result does not depend on their order, fh_trace.h).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kLeafMax8 = 3;
+
+struct Work8 { int bnode; uint32_t wnode; };
+
+__device__ __forceinline__ float box_area(const float4& lo, const float4& hi)
+{
+  const float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+  return ex * ey + ey * ez + ez * ex;
+}
+
+__device__ __forceinline__ uint32_t ref_count(int ref, const int2* ranges) { return ref < 0 ? 1u : (uint32_t)(ranges[ref].y - ranges[ref].x + 1); }
+__device__ __forceinline__ uint32_t ref_first(int ref, const int2* ranges) { return ref < 0 ? (uint32_t)(~ref) : (uint32_t)ranges[ref].x; }
+
+// smallest biased exponent E with 255 * 2^(E-127) >= extent
+__device__ __forceinline__ uint32_t quant_exponent(float extent)
+{
+  if (!(extent > 0.0f)) return 1u;
+  const float s = extent / 255.0f;
+  uint32_t bits = __float_as_uint(s);
+  uint32_t e = (bits >> 23) & 0xffu;
+  if (bits & 0x7fffffu) e += 1u;  // round the scale up to a power of two
+  if (e < 1u) e = 1u;
+  if (e > 254u) e = 254u;
+  // guard against rounding in the division above
+  while (e < 254u && __uint_as_float(e << 23) * 255.0f < extent) e += 1u;
+  return e;
+}
+
+__global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* children, const int2* ranges, const float4* node_lo, const float4* node_hi, const float4* leaf_lo,
+                            const float4* leaf_hi, float pad, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_map, Work8* next_items, uint32_t* next_count)
+{
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_items) return;
+  const Work8 it = items[w];
+  int ref[8];
+  float4 lo[8], hi[8];
+  int n = 0;
+  {
+    const int2 ch = children[it.bnode];
+    ref[0] = ch.x; ref[1] = ch.y; n = 2;
+    child_box(ch.x, node_lo, node_hi, leaf_lo, leaf_hi, lo[0], hi[0]);
+    child_box(ch.y, node_lo, node_hi, leaf_lo, leaf_hi, lo[1], hi[1]);
+  }
+  while (n < 8) {
+    int best = -1;
+    float best_area = -1.0f;
+    for (int i = 0; i < n; ++i) {
+      if (ref[i] < 0 || ref_count(ref[i], ranges) <= kLeafMax8) continue;
+      const float a = box_area(lo[i], hi[i]);
+      if (a > best_area) { best_area = a; best = i; }
+    }
+    if (best < 0) break;
+    const int2 ch = children[ref[best]];
+    ref[best] = ch.x;
+    child_box(ch.x, node_lo, node_hi, leaf_lo, leaf_hi, lo[best], hi[best]);
+    ref[n] = ch.y;
+    child_box(ch.y, node_lo, node_hi, leaf_lo, leaf_hi, lo[n], hi[n]);
+    ++n;
+  }
+  // node box = union of the padded child boxes
+  float nlo[3] = {3e38f, 3e38f, 3e38f}, nhi[3] = {-3e38f, -3e38f, -3e38f};
+  for (int i = 0; i < n; ++i) {
+    lo[i].x -= pad; lo[i].y -= pad; lo[i].z -= pad; hi[i].x += pad; hi[i].y += pad; hi[i].z += pad;
+    nlo[0] = fminf(nlo[0], lo[i].x); nlo[1] = fminf(nlo[1], lo[i].y); nlo[2] = fminf(nlo[2], lo[i].z);
+    nhi[0] = fmaxf(nhi[0], hi[i].x); nhi[1] = fmaxf(nhi[1], hi[i].y); nhi[2] = fmaxf(nhi[2], hi[i].z);
+  }
+  const float cx = 0.5f * (nlo[0] + nhi[0]), cy = 0.5f * (nlo[1] + nhi[1]), cz = 0.5f * (nlo[2] + nhi[2]);
+  // greedy octant assignment: repeatedly take the (child, slot) pair with the largest projection
+  int slot_of[8], child_in[8];
+  for (int i = 0; i < 8; ++i) { slot_of[i] = -1; child_in[i] = -1; }
+  for (int round = 0; round < n; ++round) {
+    float bestv = -3e38f;
+    int bc = -1, bs = -1;
+    for (int i = 0; i < n; ++i) {
+      if (slot_of[i] >= 0) continue;
+      const float dx = 0.5f * (lo[i].x + hi[i].x) - cx, dy = 0.5f * (lo[i].y + hi[i].y) - cy, dz = 0.5f * (lo[i].z + hi[i].z) - cz;
+      for (int sl = 0; sl < 8; ++sl) {
+        if (child_in[sl] >= 0) continue;
+        const float v = ((sl & 4) ? dx : -dx) + ((sl & 2) ? dy : -dy) + ((sl & 1) ? dz : -dz);
+        if (v > bestv) { bestv = v; bc = i; bs = sl; }
+      }
+    }
+    slot_of[bc] = bs;
+    child_in[bs] = bc;
+  }
+  // count inner children / triangles, allocate blocks
+  uint32_t n_inner = 0, n_tris = 0;
+  for (int sl = 0; sl < 8; ++sl) {
+    const int c = child_in[sl];
+    if (c < 0) continue;
+    const uint32_t cnt = ref_count(ref[c], ranges);
+    if (ref[c] >= 0 && cnt > kLeafMax8) n_inner++; else n_tris += cnt;
+  }
+  const uint32_t child_base = n_inner ? atomicAdd(node_counter, n_inner) : 0u;
+  const uint32_t tri_base = n_tris ? atomicAdd(tri_counter, n_tris) : 0u;
+  const uint32_t ex = quant_exponent(nhi[0] - nlo[0]), ey = quant_exponent(nhi[1] - nlo[1]), ez = quant_exponent(nhi[2] - nlo[2]);
+  const float isx = 1.0f / __uint_as_float(ex << 23), isy = 1.0f / __uint_as_float(ey << 23), isz = 1.0f / __uint_as_float(ez << 23);
+  uint32_t imask = 0, meta[2] = {0, 0}, q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  uint32_t inner_seen = 0, tri_off = 0;
+  uint32_t next_base = 0;
+  if (n_inner) next_base = atomicAdd(next_count, n_inner);
+  for (int sl = 0; sl < 8; ++sl) {
+    const int c = child_in[sl];
+    if (c < 0) continue;
+    const uint32_t cnt = ref_count(ref[c], ranges);
+    uint32_t m;
+    if (ref[c] >= 0 && cnt > kLeafMax8) {
+      imask |= 1u << sl;
+      m = 0x20u | (24u + (uint32_t)sl);
+      next_items[next_base + inner_seen] = Work8{ref[c], child_base + inner_seen};
+      inner_seen++;
+    } else {
+      const uint32_t first = ref_first(ref[c], ranges);
+      for (uint32_t k = 0; k < cnt; ++k) tri_map[tri_base + tri_off + k] = first + k;
+      m = (((1u << cnt) - 1u) << 5) | tri_off;
+      tri_off += cnt;
+    }
+    meta[sl >> 2] |= m << (8 * (sl & 3));
+    const float v[6] = {floorf((lo[c].x - nlo[0]) * isx), floorf((lo[c].y - nlo[1]) * isy), floorf((lo[c].z - nlo[2]) * isz),
+                        ceilf((hi[c].x - nlo[0]) * isx), ceilf((hi[c].y - nlo[1]) * isy), ceilf((hi[c].z - nlo[2]) * isz)};
+    for (int k = 0; k < 6; ++k) {
+      const float cl = fminf(fmaxf(v[k], 0.0f), 255.0f);
+      q[k][sl >> 2] |= ((uint32_t)cl) << (8 * (sl & 3));
+    }
+  }
+  uint4* out = nodes + 5 * (size_t)it.wnode;
+  out[0] = make_uint4(__float_as_uint(nlo[0]), __float_as_uint(nlo[1]), __float_as_uint(nlo[2]), ex | (ey << 8) | (ez << 16) | (imask << 24));
+  out[1] = make_uint4(child_base, tri_base, meta[0], meta[1]);
+  out[2] = make_uint4(q[0][0], q[0][1], q[1][0], q[1][1]);
+  out[3] = make_uint4(q[2][0], q[2][1], q[3][0], q[3][1]);
+  out[4] = make_uint4(q[4][0], q[4][1], q[5][0], q[5][1]);
+}
+
+// scenes with <= kLeafMax8 faces: a root whose slot 0 is the only leaf
+__global__ void k_collapse8_tiny(int n, const float4* face_lo, const float4* face_hi, float pad, uint4* nodes, uint32_t* tri_map)
+{
+  float l[3] = {3e38f, 3e38f, 3e38f}, h[3] = {-3e38f, -3e38f, -3e38f};
+  for (int f = 0; f < n; ++f) {
+    l[0] = fminf(l[0], face_lo[f].x - pad); l[1] = fminf(l[1], face_lo[f].y - pad); l[2] = fminf(l[2], face_lo[f].z - pad);
+    h[0] = fmaxf(h[0], face_hi[f].x + pad); h[1] = fmaxf(h[1], face_hi[f].y + pad); h[2] = fmaxf(h[2], face_hi[f].z + pad);
+    tri_map[f] = (uint32_t)f;
+  }
+  const uint32_t ex = quant_exponent(h[0] - l[0]), ey = quant_exponent(h[1] - l[1]), ez = quant_exponent(h[2] - l[2]);
+  nodes[0] = make_uint4(__float_as_uint(l[0]), __float_as_uint(l[1]), __float_as_uint(l[2]), ex | (ey << 8) | (ez << 16));
+  nodes[1] = make_uint4(0u, 0u, (((1u << n) - 1u) << 5), 0u);
+  nodes[2] = make_uint4(0u, 0u, 0u, 0u);
+  nodes[3] = make_uint4(0u, 0u, 0xffu, 0u);
+  nodes[4] = make_uint4(0xffu, 0u, 0xffu, 0u);
+}
+
+__global__ void k_emit_tris8(const float4* face_rec, const uint32_t* sorted_face, const uint32_t* tri_map, uint32_t n, float4* tris)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = sorted_face[tri_map[i]];
+  const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
+  tris[3 * (size_t)i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
+  tris[3 * (size_t)i + 1] = make_float4(b.x, b.y, b.z, 0.0f);
+  tris[3 * (size_t)i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -236,7 +407,10 @@ int bvh_build_device(fh_ctx* ctx)
   const uint32_t n = ctx->n_faces;
   if (ctx->d_bvh2_nodes) { (void)hipFree(ctx->d_bvh2_nodes); ctx->d_bvh2_nodes = nullptr; }
   if (ctx->d_bvh2_tris) { (void)hipFree(ctx->d_bvh2_tris); ctx->d_bvh2_tris = nullptr; }
-  ctx->bvh2_n_nodes = ctx->bvh2_n_tris = 0;
+  if (ctx->d_bvh8_nodes) { (void)hipFree(ctx->d_bvh8_nodes); ctx->d_bvh8_nodes = nullptr; }
+  if (ctx->d_bvh8_tris) { (void)hipFree(ctx->d_bvh8_tris); ctx->d_bvh8_tris = nullptr; }
+  ctx->bvh2_n_nodes = ctx->bvh2_n_tris = ctx->bvh8_n_nodes = ctx->bvh8_n_tris = 0;
+  ctx->use_bvh8 = false;
   ctx->bvh_valid = false;
   if (n == 0) { ctx->bvh_valid = true; return FH_OK; }
 
@@ -272,6 +446,18 @@ int bvh_build_device(fh_ctx* ctx)
     hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, vals_a.p, n, ctx->d_bvh2_tris);
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh2_n_nodes = 1;
+    if (n <= kLeafMax8) {
+      DevBuf<uint32_t> tri_map;
+      FH_HIP(tri_map.alloc(n));
+      FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * 5));
+      FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n));
+      hipLaunchKernelGGL(k_collapse8_tiny, dim3(1), dim3(1), 0, st, (int)n, face_lo.p, face_hi.p, pad, ctx->d_bvh8_nodes, tri_map.p);
+      hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, vals_a.p, tri_map.p, n, ctx->d_bvh8_tris);
+      FH_HIP(hipStreamSynchronize(st));
+      ctx->bvh8_n_nodes = 1;
+      ctx->bvh8_n_tris = n;
+      ctx->use_bvh8 = true;
+    }
   } else {
     FH_HIP(keys_a.alloc(n)); FH_HIP(keys_b.alloc(n)); FH_HIP(vals_a.alloc(n)); FH_HIP(vals_b.alloc(n));
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, st, face_lo.p, face_hi.p, n, bounds.p, keys_a.p, vals_a.p);
@@ -295,13 +481,46 @@ int bvh_build_device(fh_ctx* ctx)
     FH_HIP(hipGetLastError());
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh2_n_nodes = n_inner;
+
+    // ---- collapse to BVH8, breadth first
+    DevBuf<Work8> work_a, work_b;
+    DevBuf<uint32_t> counters, tri_map;  // [0] node counter, [1] triangle counter, [2] next-level item count
+    FH_HIP(work_a.alloc(n_inner)); FH_HIP(work_b.alloc(n_inner)); FH_HIP(counters.alloc(3)); FH_HIP(tri_map.alloc(n));
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * 5ull * n_inner));
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n));
+    const Work8 root{0, 0u};
+    const uint32_t init_counters[3] = {1u, 0u, 0u};
+    FH_HIP(hipMemcpyAsync(work_a.p, &root, sizeof root, hipMemcpyHostToDevice, st));
+    FH_HIP(hipMemcpyAsync(counters.p, init_counters, sizeof init_counters, hipMemcpyHostToDevice, st));
+    uint32_t level_count = 1;
+    Work8* cur = work_a.p;
+    Work8* nxt = work_b.p;
+    for (int level = 0; level < 64 && level_count > 0; ++level) {
+      FH_HIP(hipMemsetAsync(counters.p + 2, 0, 4, st));
+      hipLaunchKernelGGL(k_collapse8, dim3((level_count + 63) / 64), dim3(64), 0, st, cur, level_count, children.p, ranges.p, node_lo.p, node_hi.p, leaf_lo.p, leaf_hi.p, pad,
+                         ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2);
+      FH_HIP(hipMemcpyAsync(&level_count, counters.p + 2, 4, hipMemcpyDeviceToHost, st));
+      FH_HIP(hipStreamSynchronize(st));
+      Work8* t = cur; cur = nxt; nxt = t;
+    }
+    uint32_t final_counters[2] = {0, 0};
+    FH_HIP(hipMemcpyAsync(final_counters, counters.p, 8, hipMemcpyDeviceToHost, st));
+    FH_HIP(hipStreamSynchronize(st));
+    if (final_counters[1] != n) return fail(ctx, FH_E_INVALID, "BVH8 collapse lost triangles");
+    hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, vals_b.p, tri_map.p, n, ctx->d_bvh8_tris);
+    FH_HIP(hipGetLastError());
+    FH_HIP(hipStreamSynchronize(st));
+    ctx->bvh8_n_nodes = final_counters[0];
+    ctx->bvh8_n_tris = n;
+    ctx->use_bvh8 = true;
   }
   ctx->bvh_valid = true;
   ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
-  ctx->stats.bvh_nodes = ctx->bvh2_n_nodes;
-  ctx->stats.bvh_node_bytes = 64ull * ctx->bvh2_n_nodes;
-  ctx->stats.bvh_tri_bytes = 48ull * ctx->bvh2_n_tris;
+  if (getenv("FH_BVH2")) ctx->use_bvh8 = false;  // developer switch: traverse the binary layout instead of the wide one
+  ctx->stats.bvh_nodes = ctx->use_bvh8 ? ctx->bvh8_n_nodes : ctx->bvh2_n_nodes;
+  ctx->stats.bvh_node_bytes = ctx->use_bvh8 ? 80ull * ctx->bvh8_n_nodes : 64ull * ctx->bvh2_n_nodes;
+  ctx->stats.bvh_tri_bytes = 48ull * n;
   return FH_OK;
 }
 

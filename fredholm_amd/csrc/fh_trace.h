@@ -143,4 +143,133 @@ FH_D bool traverse_bvh2(const Bvh2Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
   return found;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// BVH8: 80-byte nodes with eight children whose boxes are quantised to 8 bits per plane relative
+// to the node's origin and per-axis power-of-two scale (layout after Ylitie, Karras, Laine,
+// "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017):
+//   n0 = origin.xyz (float bits), ex | ey<<8 | ez<<16 | imask<<24     (e* = biased exponent of the scale)
+//   n1 = first inner-child node index, first triangle index, meta[0..3], meta[4..7]
+//   n2 = qlo_x[0..7], qlo_y[0..7]    n3 = qlo_z[0..7], qhi_x[0..7]    n4 = qhi_y[0..7], qhi_z[0..7]
+// meta byte of child slot i: 0 = empty; inner child: 0x20 | (24 + i); leaf of k <= 3 triangles:
+// (unary k: 1,3,7) << 5 | offset of its first triangle in the node's triangle block (0..23).
+// A node test yields a 32-bit mask: bits 24..31 inner children ordered by the ray octant, bits 0..23
+// one bit per leaf triangle.  One node = five 16-byte loads and replaces ~3 levels of a binary tree.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBvh8Stack = 48;
+
+struct Ray8 {
+  f3 o, inv;       // origin, safe reciprocal direction
+  uint32_t oct4;   // octant inversion mask replicated in 4 bytes
+  bool nx, ny, nz; // direction signs
+};
+
+FH_D uint32_t byte_of(uint32_t w, int j) { return (w >> (8 * j)) & 0xffu; }
+
+FH_D uint32_t node8_test(const Ray8& r, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, const uint4 n4, float tmax)
+{
+  const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
+  const float sx = __uint_as_float((n0.w & 0xffu) << 23) * r.inv.x;
+  const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * r.inv.y;
+  const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * r.inv.z;
+  const float ox = (px - r.o.x) * r.inv.x, oy = (py - r.o.y) * r.inv.y, oz = (pz - r.o.z) * r.inv.z;
+  uint32_t hitmask = 0;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const uint32_t meta4 = half ? n1.w : n1.z;
+    const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+    const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+    const uint32_t bit_index4 = (meta4 ^ (r.oct4 & inner_mask4)) & 0x1f1f1f1fu;
+    const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+    const uint32_t qlx = half ? n2.y : n2.x, qly = half ? n2.w : n2.z, qlz = half ? n3.y : n3.x;
+    const uint32_t qhx = half ? n3.w : n3.z, qhy = half ? n4.y : n4.x, qhz = half ? n4.w : n4.z;
+    const uint32_t nearx = r.nx ? qhx : qlx, farx = r.nx ? qlx : qhx;
+    const uint32_t neary = r.ny ? qhy : qly, fary = r.ny ? qly : qhy;
+    const uint32_t nearz = r.nz ? qhz : qlz, farz = r.nz ? qlz : qhz;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t0x = fmaf((float)byte_of(nearx, j), sx, ox), t1x = fmaf((float)byte_of(farx, j), sx, ox);
+      const float t0y = fmaf((float)byte_of(neary, j), sy, oy), t1y = fmaf((float)byte_of(fary, j), sy, oy);
+      const float t0z = fmaf((float)byte_of(nearz, j), sz, oz), t1z = fmaf((float)byte_of(farz, j), sz, oz);
+      const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
+      const float tf = fminf(fminf(t1x, t1y), t1z) * 1.000001f;
+      if (tn <= tf && tn <= tmax) hitmask |= byte_of(child_bits4, j) << byte_of(bit_index4, j);
+    }
+  }
+  return hitmask;
+}
+
+FH_D Ray8 ray8_prepare(const RayPre& rp, f3 d)
+{
+  Ray8 r;
+  r.o = rp.o;
+  r.inv = rp.inv;
+  (void)d;
+  r.nx = r.inv.x < 0.0f; r.ny = r.inv.y < 0.0f; r.nz = r.inv.z < 0.0f;  // sign of the reciprocal actually used (-0.0 components count as negative)
+  r.oct4 = ((r.nx ? 0u : 4u) | (r.ny ? 0u : 2u) | (r.nz ? 0u : 1u)) * 0x01010101u;
+  return r;
+}
+
+template <bool ANY_HIT, bool COUNT>
+FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris)
+{
+  best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu;
+  if (bvh.n_nodes == 0) return false;
+  const RayPre rp = ray_prepare(o, d);
+  const Ray8 r = ray8_prepare(rp, d);
+  uint2 stack[kBvh8Stack];
+  int sp = 0;
+  uint2 group = make_uint2(0u, 0x80000000u);
+  bool found = false;
+  for (;;) {
+    uint2 tg = make_uint2(0u, 0u);
+    if (group.y & 0xff000000u) {
+      const uint32_t hits_imask = group.y;
+      const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
+      group.y &= ~(1u << bit);
+      if ((group.y & 0xff000000u) && sp < kBvh8Stack) stack[sp++] = group;
+      const uint32_t slot = (bit - 24u) ^ (r.oct4 & 7u);
+      const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+      const uint32_t ni = group.x + rel;
+      const uint4 n0 = bvh.nodes[5 * (size_t)ni], n1 = bvh.nodes[5 * (size_t)ni + 1], n2 = bvh.nodes[5 * (size_t)ni + 2], n3 = bvh.nodes[5 * (size_t)ni + 3],
+                  n4 = bvh.nodes[5 * (size_t)ni + 4];
+      if (COUNT) n_nodes++;
+      const uint32_t hm = node8_test(r, n0, n1, n2, n3, n4, best.t);
+      group = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
+      tg = make_uint2(n1.y, hm & 0x00ffffffu);
+    } else {
+      tg = group;
+      group = make_uint2(0u, 0u);
+    }
+    while (tg.y) {
+      const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
+      tg.y &= tg.y - 1u;
+      const size_t ti = 3 * (size_t)(tg.x + b);
+      const float4 a = bvh.tris[ti], bb = bvh.tris[ti + 1], c = bvh.tris[ti + 2];
+      if (COUNT) n_tris++;
+      float t, bu, bv;
+      if (!tri_test(rp, mk3(a), mk3(bb), mk3(c), t, bu, bv)) continue;
+      if (t > tmax) continue;
+      const uint32_t prim = __float_as_uint(a.w);
+      if (found && !closer(t, prim, best)) continue;
+      best.t = t; best.u = bu; best.v = bv; best.prim = prim;
+      found = true;
+      if (ANY_HIT) return true;
+    }
+    if ((group.y & 0xff000000u) == 0u) {
+      if (sp == 0) break;
+      group = stack[--sp];
+    }
+  }
+  return found;
+}
+
+// dispatch on the layout the scene was built with
+template <bool ANY_HIT, bool COUNT>
+FH_D bool traverse(const SceneDev& sc, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris)
+{
+  if (sc.use_bvh8) return traverse_bvh8<ANY_HIT, COUNT>(sc.bvh8, o, d, tmax, best, n_nodes, n_tris);
+  return traverse_bvh2<ANY_HIT, COUNT>(sc.bvh2, o, d, tmax, best, n_nodes, n_tris);
+}
+
 }  // namespace fh

@@ -161,8 +161,8 @@ __global__ void k_trace_batch(SceneDev sc, uint32_t n, const float* rays7, int a
   const float* r = rays7 + 7 * (size_t)i;
   HitRec h;
   uint32_t a = 0, b = 0;
-  const bool ok = any_hit ? traverse_bvh2<true, false>(sc.bvh2, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], h, a, b)
-                          : traverse_bvh2<false, false>(sc.bvh2, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], h, a, b);
+  const bool ok = any_hit ? traverse<true, false>(sc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], h, a, b)
+                          : traverse<false, false>(sc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], h, a, b);
   tuv[3 * i] = ok ? h.t : 0.0f; tuv[3 * i + 1] = ok ? h.u : 0.0f; tuv[3 * i + 2] = ok ? h.v : 0.0f;
   prim[i] = ok ? h.prim : 0xffffffffu;
 }

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(SceneDev sc, PoolDev p
       if (COUNT) nr++;
       const float4 o = pool.ray_o[p], d = pool.ray_d[p];
       HitRec h;
-      hit = traverse_bvh2<false, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+      hit = traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
       pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
       if (hit) cls = sc.face_cls[h.prim] & 0x7fu;
     }
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDe
       const float4 o = pool.sec_o[k];
       HitRec h;
       if (COUNT) nr++;
-      const bool occluded = traverse_bvh2<true, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+      const bool occluded = traverse<true, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
       if (!occluded) L += mk3(pool.sec_c[k]);
     }
     {
@@ -391,11 +391,11 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDe
       HitRec h;
       if (COUNT) nr++;
       if (!has_lights) {
-        const bool occluded = traverse_bvh2<true, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+        const bool occluded = traverse<true, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
         if (!occluded) L += mk3(pool.sec_c[k]);
       } else {
         // closest hit decides between emitter radiance and sky radiance (pt.cu:952-999, :531-543, :910-924)
-        const bool hit = traverse_bvh2<false, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+        const bool hit = traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
         const float4 a = pool.lp_a[p], b = pool.lp_b[p];
         const f3 T = mk3(a), f = mk3(b);
         const float cosw = a.w, pdf = b.w;
