@@ -15,8 +15,7 @@
 namespace fh {
 
 constexpr uint32_t kMaxClasses = 8;       // shading classes (distinct lobe masks) per scene
-constexpr uint32_t kMissClass = kMaxClasses;  // queue id used for primary misses
-constexpr uint32_t kNumQueues = kMaxClasses + 1;
+constexpr uint32_t kNumQueues = kMaxClasses;
 
 // secondary-ray slots per shaded path, in the reference's evaluation order (pt.cu:772-925)
 enum : uint32_t { SEC_DIR = 0, SEC_SKY = 1, SEC_AREA = 2, SEC_LIGHT = 3, SEC_COUNT = 4 };
@@ -88,7 +87,7 @@ struct PoolDev {
   float4* hit;    // t, u, v, face id bits (0xffffffff = miss)
   uint32_t* pixel;
   uint32_t* nspp;
-  uint32_t* flags;  // bit0: first-hit AOVs valid
+  uint32_t* flags;  // bit0: first-hit AOVs valid, bit1: path ended before its first ray (Russian roulette draw of 1.0)
   // first-hit AOV staging (pt.cu:745-751)
   float4* aov_position;
   float4* aov_normal;
@@ -103,11 +102,21 @@ struct PoolDev {
   float4* lp_b;   // f.xyz, pdf
   // queues
   uint32_t* q_rad[2];            // radiance-ray queue, ping-pong per bounce
-  uint32_t* q_cls;               // kNumQueues x capacity: hits routed by shading class (+ primary misses)
+  uint32_t* q_cls;               // kNumQueues x capacity: hits routed by shading class
   uint32_t* q_sec;               // shaded paths with secondary rays
-  uint32_t* counters;            // [0..1] q_rad, [2] q_sec, [3 .. 3+kNumQueues) class queues, then work cursors
+  uint32_t* counters;            // kCounterStride words per bounce, zeroed once per pass
 };
-enum : uint32_t { CNT_RAD0 = 0, CNT_RAD1 = 1, CNT_SEC = 2, CNT_CLS = 3, CNT_CURSOR = CNT_CLS + kNumQueues, CNT_TOTAL = CNT_CURSOR + 4 };
+// per-bounce counter block: everything a bounce produces or consumes has its own word, so one
+// memset per pass replaces per-bounce resets
+enum : uint32_t {
+  CNT_RAD = 0,        // entries of the radiance queue consumed by this bounce
+  CNT_SEC = 1,        // shaded paths with secondary rays
+  CNT_CUR_CLOSEST = 2,  // work cursor of the persistent closest-hit kernel
+  CNT_CUR_SEC = 3,      // work cursor of the persistent secondary kernel
+  CNT_CLS = 4,        // kMaxClasses class-queue counts
+  kCounterStride = 16,
+};
+static_assert(CNT_CLS + kMaxClasses <= kCounterStride, "counter block too small");
 
 struct LayersDev {
   float4* beauty; float4* position; float* depth; float4* normal; float4* texcoord; float4* albedo;

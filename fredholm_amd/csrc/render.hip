@@ -7,19 +7,26 @@
 // of them one bounce at a time through five kernels:
 //
 //   k_generate        CMJ slots 0/1 -> thin-lens camera ray, throughput 1           (pt.cu:433-454)
-//   k_trace_closest   closest hit for the radiance-ray queue; routes each hit to the queue of its
-//                     material's shading class (BSDF-sorted shading), primary misses to the miss queue
+//   k_trace_closest   closest hit for the radiance-ray queue.  Persistent waves: every wave pulls
+//                     chunks of the queue from a device cursor and refills idle lanes (dynamic
+//                     fetch) while the others keep traversing the 8-wide BVH
+//   k_route           sorts the hits into one queue per shading class (BSDF-sorted shading) with
+//                     block-aggregated appends: ballot + popcount per wave, LDS prefix per block,
+//                     one atomic per block and class
 //   k_shade<LOBES>    surface + BSDF + NEE samples + light ray + next direction + Russian roulette for
 //                     the next bounce; emits secondary rays with their pre-weighted contributions
 //   k_miss_primary    sky / background for paths that leave the scene at depth 0      (pt.cu:504-523)
 //   k_trace_secondary any-hit shadow rays (and the BSDF-sampled light ray) of every shaded path, in
-//                     the reference's order; adds the contributions that turn out unoccluded
+//                     the reference's order; adds the contributions that turn out unoccluded.
+//                     Persistent waves with dynamic fetch, like k_trace_closest
 //   k_accumulate      NaN guard + running mean of the 6 AOVs, sample_count += B       (pt.cu:474-501)
 //
 // Sampler slots are addressed absolutely (fh_sampler.h): at bounce b the Sobol' dimension base is
 // 1 + b*n1 and the CMJ slot base is 2 + b*n2 with n1 = 3 + [lights], n2 = 3 + [directional] + [lights],
 // which reproduces the draw order of SURVEY.md appendix A without per-path sampler state.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "context.h"
 #include "fh_bsdf.h"
@@ -56,8 +63,8 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
   for (uint32_t base = blockIdx.x * blockDim.x; base < n_paths; base += stride) {
     const uint32_t p = base + threadIdx.x;
     const bool valid = p < n_paths;
-    bool alive = false;
     if (valid) {
+      bool alive = false;
       const uint32_t i = p % n_owned, k = p / n_owned;
       const uint32_t image_idx = owned[i];
       const uint32_t n_spp = layers.sample_count[image_idx] + k;
@@ -88,41 +95,75 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
       pool.rad[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       pool.pixel[p] = image_idx;
       pool.nspp[p] = n_spp;
-      pool.flags[p] = 0u;
       // Russian roulette of bounce 0 has probability 1 but still consumes (and can fail on) a draw, pt.cu:457-461
       const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
       const float rr = sobol_draw(rows.m[0], sidx, 1u, fr.seed_hash);
       alive = fr.max_depth > 0 && !(rr >= 1.0f);
+      pool.flags[p] = alive ? 0u : 2u;
+      if (!alive) pool.ray_o[p] = mk4(org, -1.0f);  // negative tmax: the traversal reports a miss without work
+      pool.q_rad[0][p] = p;                         // bounce 0 consumes every slot: no compaction, no atomics
     }
-    queue_push(&pool.counters[CNT_RAD0], pool.q_rad[0], alive, p);
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) pool.counters[CNT_RAD] = n_paths;
 }
 
 // ------------------------------------------------------------------------------------------------
+// closest hit, binary-BVH fallback (tiny scenes / FH_BVH2): static grid-stride
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(SceneDev sc, PoolDev pool, uint32_t qsel, uint32_t depth, uint32_t n_classes, TraceCounters tc)
+__global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc)
 {
-  const uint32_t count = pool.counters[CNT_RAD0 + qsel];
-  const uint32_t* q = pool.q_rad[qsel];
-  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t* cnt = pool.counters + depth * kCounterStride;
+  const uint32_t count = cnt[CNT_RAD];
+  const uint32_t* q = pool.q_rad[depth & 1u];
   uint32_t nn = 0, nt = 0, nr = 0;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
-    const uint32_t i = base + threadIdx.x;
-    const bool valid = i < count;
-    uint32_t p = 0;
-    bool hit = false;
-    uint32_t cls = 0;
-    if (valid) {
-      p = q[i];
-      if (COUNT) nr++;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const uint32_t p = q[i];
+    if (COUNT) nr++;
+    const float4 o = pool.ray_o[p], d = pool.ray_d[p];
+    HitRec h;
+    traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
+    pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+  }
+  if (COUNT) {
+    atomicAdd(tc.nodes, (unsigned long long)nn);
+    atomicAdd(tc.tris, (unsigned long long)nt);
+    atomicAdd(tc.rays, (unsigned long long)nr);
+  }
+}
+
+// closest hit over the 8-wide BVH: persistent waves with dynamic fetch
+constexpr uint32_t kRefill = 20;  // refill a wave's idle lanes once this many are idle
+
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_trace_closest(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc)
+{
+  uint32_t* cnt = pool.counters + depth * kCounterStride;
+  const uint32_t count = cnt[CNT_RAD];
+  const uint32_t* q = pool.q_rad[depth & 1u];
+  uint32_t nn = 0, nt = 0, nr = 0;
+  WaveFeeder feed;
+  Trav8 tr;
+  bool active = false;
+  uint32_t p = 0;
+  for (;;) {
+    const uint32_t idx = feed.fetch(&cnt[CNT_CUR_CLOSEST], count, !active);
+    if (idx != 0xffffffffu) {
+      p = q[idx];
       const float4 o = pool.ray_o[p], d = pool.ray_d[p];
-      HitRec h;
-      hit = traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
-      pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
-      if (hit) cls = sc.face_cls[h.prim] & 0x7fu;
+      tr.init(mk3(o), mk3(d), o.w);
+      active = true;
+      if (COUNT) nr++;
     }
-    for (uint32_t c = 0; c < n_classes; ++c) queue_push(&pool.counters[CNT_CLS + c], pool.q_cls + (size_t)c * pool.capacity, valid && hit && cls == c, p);
-    if (depth == 0) queue_push(&pool.counters[CNT_CLS + kMissClass], pool.q_cls + (size_t)kMissClass * pool.capacity, valid && !hit, p);
+    if (__ballot(active) == 0ull) break;
+    const uint32_t limit = feed.exhausted ? 64u : kRefill;
+    uint32_t idle;
+    do {
+      if (active && tr.template step<false, COUNT>(sc.bvh8, nn, nt)) {
+        pool.hit[p] = make_float4(tr.best.t, tr.best.u, tr.best.v, __uint_as_float(tr.best.prim));
+        active = false;
+      }
+      idle = (uint32_t)__popcll(__ballot(!active));
+    } while (idle < limit);
   }
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
@@ -132,12 +173,49 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(SceneDev sc, PoolDev p
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_miss_primary(FrameDev fr, PoolDev pool)
+// Sort the hits of this bounce into per-class queues.  Appends are aggregated per block: wave
+// ballot + popcount, a prefix over the block's waves in LDS, one atomic per block and class.
+__global__ void __launch_bounds__(kBlock) k_route(SceneDev sc, PoolDev pool, uint32_t depth, uint32_t n_classes)
 {
-  const uint32_t count = pool.counters[CNT_CLS + kMissClass];
-  const uint32_t* q = pool.q_cls + (size_t)kMissClass * pool.capacity;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-    const uint32_t p = q[i];
+  __shared__ uint32_t wave_cnt[kMaxClasses][kBlock / 64];
+  __shared__ uint32_t block_base[kMaxClasses];
+  uint32_t* cnt = pool.counters + depth * kCounterStride;
+  const uint32_t count = cnt[CNT_RAD];
+  const uint32_t* q = pool.q_rad[depth & 1u];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    uint32_t p = 0, cls = 0xffu;
+    if (i < count) {
+      p = q[i];
+      const uint32_t prim = __float_as_uint(pool.hit[p].w);
+      if (prim != 0xffffffffu) cls = sc.face_cls[prim] & 0x7fu;
+    }
+    uint32_t my_rank = 0;
+    for (uint32_t c = 0; c < n_classes; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (lane == 0) wave_cnt[c][wave] = (uint32_t)__popcll(m);
+      if (cls == c) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x < n_classes) {
+      uint32_t total = 0;
+      for (uint32_t w = 0; w < kBlock / 64; ++w) { const uint32_t v = wave_cnt[threadIdx.x][w]; wave_cnt[threadIdx.x][w] = total; total += v; }
+      block_base[threadIdx.x] = total ? atomicAdd(&cnt[CNT_CLS + threadIdx.x], total) : 0u;
+    }
+    __syncthreads();
+    if (cls < n_classes) pool.q_cls[(size_t)cls * pool.capacity + block_base[cls] + wave_cnt[cls][wave] + my_rank] = p;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// paths that leave the scene at depth 0 see the environment directly (pt.cu:504-523)
+__global__ void __launch_bounds__(kBlock) k_miss_primary(FrameDev fr, PoolDev pool, uint32_t n_paths)
+{
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_paths; p += gridDim.x * blockDim.x) {
+    if (__float_as_uint(pool.hit[p].w) != 0xffffffffu) continue;
+    if (pool.flags[p] & 2u) continue;  // never traced
     const f3 T = mk3(pool.thr[p]);
     const f3 d = mk3(pool.ray_d[p]);
     const f3 r = mk3(pool.rad[p]) + T * env_radiance(fr, d);
@@ -197,7 +275,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev sc, FrameDev fr, Pool
   const uint32_t slot_light = slot_sky + 1u + has_lights;
   const uint32_t slot_next = slot_light + 1u;
 
-  const uint32_t count = pool.counters[CNT_CLS + cls];
+  uint32_t* cnt = pool.counters + depth * kCounterStride;
+  uint32_t* cnt_next = cnt + kCounterStride;
+  const uint32_t count = cnt[CNT_CLS + cls];
   const uint32_t* q = pool.q_cls + (size_t)cls * pool.capacity;
   const uint32_t qnext = (depth + 1u) & 1u;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -242,7 +322,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev sc, FrameDev fr, Pool
         pool.aov_normal[p] = mk4(ns, 0.0f);
         pool.aov_albedo[p] = mk4(sp.base_color, 0.0f);
         pool.aov_texdepth[p] = make_float4(tu, tv, hit.x, 0.0f);
-        pool.flags[p] = 1u;
+        pool.flags[p] |= 1u;
         if (mat.emissive) {
           L += T * mk3(mat.w[38], mat.w[39], mat.w[40]);
           pool.rad[p] = mk4(L, 0.0f);
@@ -355,25 +435,61 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev sc, FrameDev fr, Pool
         }
       }
     }
-    queue_push(&pool.counters[CNT_SEC], pool.q_sec, shaded, p);
-    queue_push(&pool.counters[CNT_RAD0 + qnext], pool.q_rad[qnext], cont, p);
+    queue_push(&cnt[CNT_SEC], pool.q_sec, shaded, p);
+    queue_push(&cnt_next[CNT_RAD], pool.q_rad[qnext], cont, p);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDev fr, PoolDev pool, TraceCounters tc)
+// Finish the BSDF-sampled light ray of a scene with emitters once its closest hit is known
+// (pt.cu:952-999 closest-hit light, :531-543 miss light, :910-924 MIS weight).
+FH_D f3 resolve_light_ray(const SceneDev& sc, const FrameDev& fr, const PoolDev& pool, uint32_t p, f3 ro, f3 ld, bool hit, const HitRec& h)
 {
-  const uint32_t count = pool.counters[CNT_SEC];
-  const uint32_t stride = gridDim.x * blockDim.x;
+  const float4 a = pool.lp_a[p], b = pool.lp_b[p];
+  const f3 T = mk3(a), f = mk3(b);
+  const float cosw = a.w, pdf = b.w;
+  f3 le = mk3(0.0f);
+  float pdf_light = cosw / kPi;
+  bool add = false;
+  if (hit) {
+    if (sc.face_cls[h.prim] & 0x80u) {
+      const size_t fb = 7 * (size_t)h.prim;
+      const float4 l0 = sc.face_rec[fb], l1 = sc.face_rec[fb + 1], l2 = sc.face_rec[fb + 2], l3 = sc.face_rec[fb + 3], l4 = sc.face_rec[fb + 4], l5 = sc.face_rec[fb + 5];
+      const float lw = 1.0f - h.u - h.v;
+      const f3 lp = lw * mk3(l0) + h.u * mk3(l1) + h.v * mk3(l2);
+      const f3 ln = lw * mk3(l3) + h.u * mk3(l4) + h.v * mk3(l5);
+      if (dot(-ld, ln) > 0.0f) {
+        const MaterialDev& lm = sc.materials[__float_as_uint(sc.face_rec[fb + 6].x)];
+        le = mk3(lm.w[38], lm.w[39], lm.w[40]);
+        const float area = 0.5f * length(cross(mk3(l1) - mk3(l0), mk3(l2) - mk3(l0)));
+        const f3 dl = lp - ro;
+        const float r2 = dot(dl, dl);
+        const float pdf_area = 1.0f / (sc.n_lights * area);
+        pdf_light = r2 / fabsf(dot(-ld, ln)) * pdf_area;
+        add = true;
+      }
+    }
+  } else {
+    le = env_radiance(fr, ld);
+    add = true;
+  }
+  if (!add) return mk3(0.0f);
+  const float w = pdf / (pdf + pdf_light);
+  return clamp01(T * w * f * cosw / pdf) * le;
+}
+
+// secondary rays, binary-BVH fallback: one thread per shaded path, its rays in the reference's order
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc)
+{
+  const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
   const bool has_lights = sc.n_lights > 0;
   uint32_t nn = 0, nt = 0, nr = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const uint32_t p = pool.q_sec[i];
     f3 L = mk3(pool.rad[p]);
-    // shadow rays in the reference's order: directional, sky, area
 #pragma unroll
-    for (uint32_t slot = SEC_DIR; slot <= SEC_AREA; ++slot) {
+    for (uint32_t slot = SEC_DIR; slot <= SEC_LIGHT; ++slot) {
       if (slot == SEC_DIR && !fr.has_dir) continue;
       if (slot == SEC_AREA && !has_lights) continue;
       const size_t k = (size_t)slot * pool.capacity + p;
@@ -382,56 +498,85 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDe
       const float4 o = pool.sec_o[k];
       HitRec h;
       if (COUNT) nr++;
-      const bool occluded = traverse<true, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
-      if (!occluded) L += mk3(pool.sec_c[k]);
-    }
-    {
-      const size_t k = (size_t)SEC_LIGHT * pool.capacity + p;
-      const float4 o = pool.sec_o[k], d = pool.sec_d[k];
-      HitRec h;
-      if (COUNT) nr++;
-      if (!has_lights) {
+      if (slot == SEC_LIGHT && has_lights) {
+        const bool hit = traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
+        L += resolve_light_ray(sc, fr, pool, p, mk3(o), mk3(d), hit, h);
+      } else {
         const bool occluded = traverse<true, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
         if (!occluded) L += mk3(pool.sec_c[k]);
-      } else {
-        // closest hit decides between emitter radiance and sky radiance (pt.cu:952-999, :531-543, :910-924)
-        const bool hit = traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
-        const float4 a = pool.lp_a[p], b = pool.lp_b[p];
-        const f3 T = mk3(a), f = mk3(b);
-        const float cosw = a.w, pdf = b.w;
-        const f3 ld = mk3(d);
-        f3 le = mk3(0.0f);
-        float pdf_light = cosw / kPi;
-        bool add = false;
-        if (hit) {
-          if (sc.face_cls[h.prim] & 0x80u) {
-            const size_t fb = 7 * (size_t)h.prim;
-            const float4 l0 = sc.face_rec[fb], l1 = sc.face_rec[fb + 1], l2 = sc.face_rec[fb + 2], l3 = sc.face_rec[fb + 3], l4 = sc.face_rec[fb + 4], l5 = sc.face_rec[fb + 5];
-            const float lw = 1.0f - h.u - h.v;
-            const f3 lp = lw * mk3(l0) + h.u * mk3(l1) + h.v * mk3(l2);
-            const f3 ln = lw * mk3(l3) + h.u * mk3(l4) + h.v * mk3(l5);
-            if (dot(-ld, ln) > 0.0f) {
-              const MaterialDev& lm = sc.materials[__float_as_uint(sc.face_rec[fb + 6].x)];
-              le = mk3(lm.w[38], lm.w[39], lm.w[40]);
-              const float area = 0.5f * length(cross(mk3(l1) - mk3(l0), mk3(l2) - mk3(l0)));
-              const f3 dl = lp - mk3(o);
-              const float r2 = dot(dl, dl);
-              const float pdf_area = 1.0f / (sc.n_lights * area);
-              pdf_light = r2 / fabsf(dot(-ld, ln)) * pdf_area;
-              add = true;
-            }
-          }
-        } else {
-          le = env_radiance(fr, ld);
-          add = true;
-        }
-        if (add) {
-          const float w = pdf / (pdf + pdf_light);
-          L += clamp01(T * w * f * cosw / pdf) * le;
-        }
       }
     }
     pool.rad[p] = mk4(L, 0.0f);
+  }
+  if (COUNT) {
+    atomicAdd(tc.nodes, (unsigned long long)nn);
+    atomicAdd(tc.tris, (unsigned long long)nt);
+    atomicAdd(tc.rays, (unsigned long long)nr);
+  }
+}
+
+// secondary rays over the 8-wide BVH: persistent waves, a lane owns one shaded path at a time and
+// walks its secondary-ray slots in order, so the additions into the path's radiance keep the
+// reference's order (directional, sky, area, BSDF-sampled) without atomics.
+template <bool COUNT, bool LIGHTS>
+__global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc)
+{
+  uint32_t* cnt = pool.counters + depth * kCounterStride;
+  const uint32_t count = cnt[CNT_SEC];
+  constexpr bool has_lights = LIGHTS;  // scenes without emitters never need the closest hit of the light ray
+  uint32_t nn = 0, nt = 0, nr = 0;
+  WaveFeeder feed;
+  Trav8 tr;
+  bool active = false;     // lane owns a path
+  bool tracing = false;    // lane has a ray in flight
+  uint32_t p = 0, slot = 0;
+  f3 L = mk3(0.0f);
+  for (;;) {
+    const uint32_t idx = feed.fetch(&cnt[CNT_CUR_SEC], count, !active);
+    if (idx != 0xffffffffu) {
+      p = pool.q_sec[idx];
+      L = mk3(pool.rad[p]);
+      slot = SEC_DIR;
+      active = true;
+      tracing = false;
+    }
+    if (__ballot(active) == 0ull) break;
+    const uint32_t limit = feed.exhausted ? 64u : kRefill;
+    uint32_t idle;
+    do {
+      if (active) {
+        if (!tracing) {
+          // advance to the next enabled, active slot of this path
+          while (slot <= SEC_LIGHT) {
+            const bool enabled = !(slot == SEC_DIR && !fr.has_dir) && !(slot == SEC_AREA && !has_lights);
+            if (enabled && pool.sec_d[(size_t)slot * pool.capacity + p].w != 0.0f) break;
+            ++slot;
+          }
+          if (slot > SEC_LIGHT) {
+            pool.rad[p] = mk4(L, 0.0f);
+            active = false;
+          } else {
+            const size_t k = (size_t)slot * pool.capacity + p;
+            const float4 o = pool.sec_o[k], d = pool.sec_d[k];
+            tr.init(mk3(o), mk3(d), o.w);
+            tracing = true;
+            if (COUNT) nr++;
+          }
+        }
+        if (tracing) {
+          const bool closest = (slot == SEC_LIGHT) && has_lights;
+          const bool done = closest ? tr.template step<false, COUNT>(sc.bvh8, nn, nt) : tr.template step<true, COUNT>(sc.bvh8, nn, nt);
+          if (done) {
+            const size_t k = (size_t)slot * pool.capacity + p;
+            if (closest) L += resolve_light_ray(sc, fr, pool, p, tr.rp.o, mk3(pool.sec_d[k]), tr.found, tr.best);
+            else if (!tr.found) L += mk3(pool.sec_c[k]);
+            tracing = false;
+            ++slot;
+          }
+        }
+      }
+      idle = (uint32_t)__popcll(__ballot(!active));
+    } while (idle < limit);
   }
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
@@ -570,7 +715,7 @@ int pool_ensure(fh_ctx* ctx, uint32_t capacity)
   FH_HIP(alloc(P.sec_o, n * SEC_COUNT)); FH_HIP(alloc(P.sec_d, n * SEC_COUNT)); FH_HIP(alloc(P.sec_c, n * SEC_COUNT));
   FH_HIP(alloc(P.lp_a, n)); FH_HIP(alloc(P.lp_b, n));
   FH_HIP(alloc(P.q_rad[0], n)); FH_HIP(alloc(P.q_rad[1], n)); FH_HIP(alloc(P.q_cls, n * kNumQueues)); FH_HIP(alloc(P.q_sec, n));
-  FH_HIP(alloc(P.counters, (size_t)CNT_TOTAL));
+  FH_HIP(alloc(P.counters, (size_t)kCounterStride * 66));  // up to 65 bounces per pass
   P.capacity = capacity;
   return FH_OK;
 }
@@ -624,34 +769,49 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
 
   if (!ctx->render_pending) { (void)hipEventRecord(ctx->ev_render_begin, st); ctx->render_pending = true; }
 
+  if (max_depth > 64) return fail(ctx, FH_E_INVALID, "fh_render: max_depth > 64 is not supported");
+  hipDeviceProp_t prop;
+  FH_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  const uint32_t persistent_grid = (uint32_t)prop.multiProcessorCount * 8u;  // 8 blocks of 4 waves per CU: every wave resident
+  const bool wide = sc.use_bvh8 != 0 && getenv("FH_PERSISTENT") != nullptr;  // experimental persistent/dynamic-fetch kernels
+
   for (uint32_t done = 0; done < n_samples; done += batch) {
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
     const uint32_t n_paths = ctx->n_owned * nb;
     const uint32_t grid = grid_for(n_paths);
-    FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * CNT_TOTAL, st));
+    FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
     hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, fr, pool, L, ctx->d_owned, ctx->n_owned, n_paths);
     ctx->stats.paths += n_paths;
     for (uint32_t depth = 0; depth < max_depth; ++depth) {
-      const uint32_t qsel = depth & 1u;
-      // counters written by this bounce: class queues, secondary queue, next radiance queue
-      FH_HIP(hipMemsetAsync(pool.counters + CNT_CLS, 0, sizeof(uint32_t) * kNumQueues, st));
-      FH_HIP(hipMemsetAsync(pool.counters + CNT_SEC, 0, sizeof(uint32_t), st));
-      FH_HIP(hipMemsetAsync(pool.counters + CNT_RAD0 + (qsel ^ 1u), 0, sizeof(uint32_t), st));
       {
         Span sp(ctx, 0);
-        if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, st, sc, pool, qsel, depth, ctx->n_classes, tc_closest);
-        else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, st, sc, pool, qsel, depth, ctx->n_classes, tc_closest);
+        if (wide) {
+          if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+          else hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+        } else {
+          if (count) hipLaunchKernelGGL(k_trace_closest_static<true>, dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+          else hipLaunchKernelGGL(k_trace_closest_static<false>, dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+        }
         ctx->stats.n_closest_launches++;
       }
       {
         Span sp(ctx, 2);
+        hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, ctx->n_classes);
         for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pool, c, depth);
-        if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pool);
+        if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pool, n_paths);
       }
       {
         Span sp(ctx, 1);
-        if (count) hipLaunchKernelGGL(k_trace_secondary<true>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, tc_shadow);
-        else hipLaunchKernelGGL(k_trace_secondary<false>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, tc_shadow);
+        if (wide) {
+          const bool lights = sc.n_lights > 0;
+          if (count && lights) hipLaunchKernelGGL((k_trace_secondary<true, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
+          else if (count) hipLaunchKernelGGL((k_trace_secondary<true, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
+          else if (lights) hipLaunchKernelGGL((k_trace_secondary<false, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
+          else hipLaunchKernelGGL((k_trace_secondary<false, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
+        } else {
+          if (count) hipLaunchKernelGGL(k_trace_secondary_static<true>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
+          else hipLaunchKernelGGL(k_trace_secondary_static<false>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
+        }
         ctx->stats.n_shadow_launches++;
       }
     }
