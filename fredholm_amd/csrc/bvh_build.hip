@@ -230,7 +230,7 @@ __global__ void k_emit_tris(const float4* face_rec, const uint32_t* sorted_face,
 // children to the next level.  Levels are processed breadth first; node and triangle blocks are
 // allocated with atomics (the traversal result does not depend on their order, fh_trace.h).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kLeafMax8 = 3;
+constexpr uint32_t kLeafMax8 = 3;  // upper bound (3 bits of unary count per leaf child)
 
 struct Work8 { int bnode; uint32_t wnode; };
 
@@ -259,7 +259,7 @@ __device__ __forceinline__ uint32_t quant_exponent(float extent)
 }
 
 __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* children, const int2* ranges, const float4* node_lo, const float4* node_hi, const float4* leaf_lo,
-                            const float4* leaf_hi, float pad, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_map, Work8* next_items, uint32_t* next_count)
+                            const float4* leaf_hi, float pad, uint32_t leaf_max, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_map, Work8* next_items, uint32_t* next_count)
 {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_items) return;
@@ -277,7 +277,7 @@ __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* ch
     int best = -1;
     float best_area = -1.0f;
     for (int i = 0; i < n; ++i) {
-      if (ref[i] < 0 || ref_count(ref[i], ranges) <= kLeafMax8) continue;
+      if (ref[i] < 0 || ref_count(ref[i], ranges) <= leaf_max) continue;
       const float a = box_area(lo[i], hi[i]);
       if (a > best_area) { best_area = a; best = i; }
     }
@@ -321,7 +321,7 @@ __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* ch
     const int c = child_in[sl];
     if (c < 0) continue;
     const uint32_t cnt = ref_count(ref[c], ranges);
-    if (ref[c] >= 0 && cnt > kLeafMax8) n_inner++; else n_tris += cnt;
+    if (ref[c] >= 0 && cnt > leaf_max) n_inner++; else n_tris += cnt;
   }
   const uint32_t child_base = n_inner ? atomicAdd(node_counter, n_inner) : 0u;
   const uint32_t tri_base = n_tris ? atomicAdd(tri_counter, n_tris) : 0u;
@@ -336,7 +336,7 @@ __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* ch
     if (c < 0) continue;
     const uint32_t cnt = ref_count(ref[c], ranges);
     uint32_t m;
-    if (ref[c] >= 0 && cnt > kLeafMax8) {
+    if (ref[c] >= 0 && cnt > leaf_max) {
       imask |= 1u << sl;
       m = 0x20u | (24u + (uint32_t)sl);
       next_items[next_base + inner_seen] = Work8{ref[c], child_base + inner_seen};
@@ -432,6 +432,7 @@ int bvh_build_device(fh_ctx* ctx)
   float maxabs = 0.0f;
   for (int k = 0; k < 6; ++k) maxabs = fmaxf(maxabs, fabsf(order_float(hb[k])));
   const float pad = fmaxf(maxabs, 1e-3f) * (1.0f / 65536.0f);
+  for (int k = 0; k < 3; ++k) { ctx->scene_lo[k] = order_float(hb[k]) - 2.0f * pad; ctx->scene_hi[k] = order_float(hb[3 + k]) + 2.0f * pad; }
 
   FH_HIP(hipMalloc((void**)&ctx->d_bvh2_tris, sizeof(float4) * 3ull * n));
   ctx->bvh2_n_tris = n;
@@ -488,6 +489,8 @@ int bvh_build_device(fh_ctx* ctx)
     FH_HIP(work_a.alloc(n_inner)); FH_HIP(work_b.alloc(n_inner)); FH_HIP(counters.alloc(3)); FH_HIP(tri_map.alloc(n));
     FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * 5ull * n_inner));
     FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n));
+    uint32_t leaf_max8 = 1;  // one triangle per leaf child: box tests are ~4x cheaper than triangle tests (profiles/README.md)
+    if (const char* e = getenv("FH_LEAF8")) { const int v = atoi(e); if (v >= 1 && v <= (int)kLeafMax8) leaf_max8 = (uint32_t)v; }
     const Work8 root{0, 0u};
     const uint32_t init_counters[3] = {1u, 0u, 0u};
     FH_HIP(hipMemcpyAsync(work_a.p, &root, sizeof root, hipMemcpyHostToDevice, st));
@@ -498,7 +501,7 @@ int bvh_build_device(fh_ctx* ctx)
     for (int level = 0; level < 64 && level_count > 0; ++level) {
       FH_HIP(hipMemsetAsync(counters.p + 2, 0, 4, st));
       hipLaunchKernelGGL(k_collapse8, dim3((level_count + 63) / 64), dim3(64), 0, st, cur, level_count, children.p, ranges.p, node_lo.p, node_hi.p, leaf_lo.p, leaf_hi.p, pad,
-                         ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2);
+                         leaf_max8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2);
       FH_HIP(hipMemcpyAsync(&level_count, counters.p + 2, 4, hipMemcpyDeviceToHost, st));
       FH_HIP(hipStreamSynchronize(st));
       Work8* t = cur; cur = nxt; nxt = t;

@@ -193,11 +193,11 @@ int fh_ctx_create(int device, fh_ctx** out)
   if (hipMalloc((void**)&ctx->d_sobol, kSobolMatricesBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_refl, kLutReflectionBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_sheen, kLutSheenBytes) != hipSuccess) return bail("hipMalloc failed");
-  if (hipMalloc((void**)&ctx->d_trace_counters, 6 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
+  if (hipMalloc((void**)&ctx->d_trace_counters, 10 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
   if (hipMemcpy(ctx->d_sobol, kSobolMatrices, kSobolMatricesBytes, hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
   (void)hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
-  (void)hipMemset(ctx->d_trace_counters, 0, 6 * sizeof(unsigned long long));
+  (void)hipMemset(ctx->d_trace_counters, 0, 10 * sizeof(unsigned long long));
   (void)hipEventCreate(&ctx->ev_render_begin);
   (void)hipEventCreate(&ctx->ev_render_end);
   *out = ctx;
@@ -429,8 +429,9 @@ int fh_sync(fh_ctx* ctx)
   }
   ctx->spans.clear();
   if (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) {
-    unsigned long long c[6];
+    unsigned long long c[10];
     FH_HIP(hipMemcpy(c, ctx->d_trace_counters, sizeof c, hipMemcpyDeviceToHost));
+    ctx->stats.wave_node_steps_closest = c[6]; ctx->stats.wave_tri_steps_closest = c[7]; ctx->stats.wave_node_steps_shadow = c[8]; ctx->stats.wave_tri_steps_shadow = c[9];
     ctx->stats.nodes_closest = c[0]; ctx->stats.tris_closest = c[1]; ctx->stats.rays_closest = c[2];
     ctx->stats.nodes_shadow = c[3]; ctx->stats.tris_shadow = c[4]; ctx->stats.rays_shadow = c[5];
   }
@@ -451,7 +452,7 @@ int fh_reset_stats(fh_ctx* ctx)
   const uint64_t nodes = ctx->stats.bvh_nodes, nb = ctx->stats.bvh_node_bytes, tb = ctx->stats.bvh_tri_bytes;
   ctx->stats = fh_stats{};
   ctx->stats.bvh_build_ms = build_ms; ctx->stats.bvh_nodes = nodes; ctx->stats.bvh_node_bytes = nb; ctx->stats.bvh_tri_bytes = tb;
-  FH_HIP(hipMemsetAsync(ctx->d_trace_counters, 0, 6 * sizeof(unsigned long long), ctx->stream));
+  FH_HIP(hipMemsetAsync(ctx->d_trace_counters, 0, 10 * sizeof(unsigned long long), ctx->stream));
   return FH_OK;
 }
 

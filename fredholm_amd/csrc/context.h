@@ -46,6 +46,7 @@ struct fh_ctx {
   uint32_t bvh8_n_nodes = 0, bvh8_n_tris = 0;
   bool use_bvh8 = false;
   double bvh_build_ms = 0.0;
+  float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};  // padded world bounds of the geometry
 
   // frame state
   uint32_t width = 0, height = 0;

@@ -73,6 +73,8 @@ struct FrameDev {
   HosekSky hosek;
   f3 dir_le, dir_dir;
   float dir_disk_radius;  // 1e9 * tan(rad(angle/2)), pt.cu:333-335
+  // padded scene bounds: camera rays that miss them skip the traversal queue
+  f3 scene_lo, scene_hi;
   // tables
   const uint32_t* sobol;  // 1024 x 52
   BsdfTables lut;
@@ -124,7 +126,7 @@ struct LayersDev {
 };
 
 // traversal statistics (only written by the instrumented kernel variants)
-struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; unsigned long long* rays; };
+struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; unsigned long long* rays; unsigned long long* wave_nodes; unsigned long long* wave_tris; };
 
 // ---- wave-aggregated queue append: one atomic per wave (ballot + popcount prefix)
 FH_D void queue_push(uint32_t* counter, uint32_t* queue, bool active, uint32_t value)

@@ -210,8 +210,13 @@ FH_D Ray8 ray8_prepare(const RayPre& rp, f3 d)
   return r;
 }
 
+// wave-level step counters of the instrumented build: how many times a wave executed the node test /
+// the triangle test, whatever the number of lanes taking part (SIMD efficiency = lane steps / (64 * wave steps))
+struct WaveSteps { uint32_t node = 0, tri = 0; };
+FH_D bool first_active_lane() { return __lane_id() == (uint32_t)__ffsll((long long)__ballot(true)) - 1u; }
+
 template <bool ANY_HIT, bool COUNT>
-FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris)
+FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr)
 {
   best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu;
   if (bvh.n_nodes == 0) return false;
@@ -233,7 +238,7 @@ FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
       const uint32_t ni = group.x + rel;
       const uint4 n0 = bvh.nodes[5 * (size_t)ni], n1 = bvh.nodes[5 * (size_t)ni + 1], n2 = bvh.nodes[5 * (size_t)ni + 2], n3 = bvh.nodes[5 * (size_t)ni + 3],
                   n4 = bvh.nodes[5 * (size_t)ni + 4];
-      if (COUNT) n_nodes++;
+      if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
       const uint32_t hm = node8_test(r, n0, n1, n2, n3, n4, best.t);
       group = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
       tg = make_uint2(n1.y, hm & 0x00ffffffu);
@@ -246,7 +251,7 @@ FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
       tg.y &= tg.y - 1u;
       const size_t ti = 3 * (size_t)(tg.x + b);
       const float4 a = bvh.tris[ti], bb = bvh.tris[ti + 1], c = bvh.tris[ti + 2];
-      if (COUNT) n_tris++;
+      if (COUNT) { n_tris++; if (ws && first_active_lane()) ws->tri++; }
       float t, bu, bv;
       if (!tri_test(rp, mk3(a), mk3(bb), mk3(c), t, bu, bv)) continue;
       if (t > tmax) continue;
@@ -374,9 +379,9 @@ struct WaveFeeder {
 
 // dispatch on the layout the scene was built with
 template <bool ANY_HIT, bool COUNT>
-FH_D bool traverse(const SceneDev& sc, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris)
+FH_D bool traverse(const SceneDev& sc, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr)
 {
-  if (sc.use_bvh8) return traverse_bvh8<ANY_HIT, COUNT>(sc.bvh8, o, d, tmax, best, n_nodes, n_tris);
+  if (sc.use_bvh8) return traverse_bvh8<ANY_HIT, COUNT>(sc.bvh8, o, d, tmax, best, n_nodes, n_tris, ws);
   return traverse_bvh2<ANY_HIT, COUNT>(sc.bvh2, o, d, tmax, best, n_nodes, n_tris);
 }
 

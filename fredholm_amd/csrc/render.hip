@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
   for (uint32_t base = blockIdx.x * blockDim.x; base < n_paths; base += stride) {
     const uint32_t p = base + threadIdx.x;
     const bool valid = p < n_paths;
+    bool enter = false;
     if (valid) {
       bool alive = false;
       const uint32_t i = p % n_owned, k = p / n_owned;
@@ -100,11 +101,15 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
       const float rr = sobol_draw(rows.m[0], sidx, 1u, fr.seed_hash);
       alive = fr.max_depth > 0 && !(rr >= 1.0f);
       pool.flags[p] = alive ? 0u : 2u;
-      if (!alive) pool.ray_o[p] = mk4(org, -1.0f);  // negative tmax: the traversal reports a miss without work
-      pool.q_rad[0][p] = p;                         // bounce 0 consumes every slot: no compaction, no atomics
+      // camera rays that miss the (padded) scene bounds cannot hit anything: record the miss here and keep
+      // them out of the traversal queue, so the waves of bounce 0 only hold rays that enter the scene
+      const RayPre rp = ray_prepare(org, dir);
+      float tn;
+      enter = alive && slab_test(rp, fr.scene_lo.x, fr.scene_lo.y, fr.scene_lo.z, fr.scene_hi.x, fr.scene_hi.y, fr.scene_hi.z, 1e9f, tn);
+      if (!enter) pool.hit[p] = make_float4(1e9f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
     }
+    queue_push(&pool.counters[CNT_RAD], pool.q_rad[0], enter, p);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) pool.counters[CNT_RAD] = n_paths;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -116,18 +121,28 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, Po
   const uint32_t count = cnt[CNT_RAD];
   const uint32_t* q = pool.q_rad[depth & 1u];
   uint32_t nn = 0, nt = 0, nr = 0;
+  WaveSteps ws;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const uint32_t p = q[i];
     if (COUNT) nr++;
     const float4 o = pool.ray_o[p], d = pool.ray_d[p];
     HitRec h;
-    traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
+    if (sc.use_bvh8 == 2u) {
+      Trav8 tr;
+      tr.init(mk3(o), mk3(d), o.w);
+      while (!tr.template step<false, COUNT>(sc.bvh8, nn, nt)) {}
+      h = tr.best;
+    } else {
+      traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
+    }
     pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
   }
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
     atomicAdd(tc.rays, (unsigned long long)nr);
+    if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
+    if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
   }
 }
 
@@ -485,6 +500,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
   const bool has_lights = sc.n_lights > 0;
   uint32_t nn = 0, nt = 0, nr = 0;
+  WaveSteps ws;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const uint32_t p = pool.q_sec[i];
     f3 L = mk3(pool.rad[p]);
@@ -499,10 +515,18 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
       HitRec h;
       if (COUNT) nr++;
       if (slot == SEC_LIGHT && has_lights) {
-        const bool hit = traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
+        const bool hit = traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
         L += resolve_light_ray(sc, fr, pool, p, mk3(o), mk3(d), hit, h);
       } else {
-        const bool occluded = traverse<true, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt);
+        bool occluded;
+        if (sc.use_bvh8 == 2u) {
+          Trav8 tr;
+          tr.init(mk3(o), mk3(d), o.w);
+          while (!tr.template step<true, COUNT>(sc.bvh8, nn, nt)) {}
+          occluded = tr.found;
+        } else {
+          occluded = traverse<true, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
+        }
         if (!occluded) L += mk3(pool.sec_c[k]);
       }
     }
@@ -512,6 +536,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
     atomicAdd(tc.rays, (unsigned long long)nr);
+    if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
+    if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
   }
 }
 
@@ -686,7 +712,7 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.bvh8.tris = ctx->d_bvh8_tris;
   s.bvh8.n_nodes = ctx->bvh8_n_nodes;
   s.bvh8.n_tris = ctx->bvh8_n_tris;
-  s.use_bvh8 = ctx->use_bvh8 ? 1u : 0u;
+  s.use_bvh8 = ctx->use_bvh8 ? (getenv("FH_STEP") ? 2u : 1u) : 0u;
   return s;
 }
 
@@ -752,6 +778,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   fr.dir_le = mk3(ctx->dir_le[0], ctx->dir_le[1], ctx->dir_le[2]);
   fr.dir_dir = mk3(ctx->dir_dir[0], ctx->dir_dir[1], ctx->dir_dir[2]);
   fr.dir_disk_radius = 1e9f * tanf(0.5f * ctx->dir_angle * kPi / 180.0f);
+  fr.scene_lo = mk3(ctx->scene_lo[0], ctx->scene_lo[1], ctx->scene_lo[2]);
+  fr.scene_hi = mk3(ctx->scene_hi[0], ctx->scene_hi[1], ctx->scene_hi[2]);
   fr.sobol = ctx->d_sobol;
   fr.lut.reflection = ctx->d_lut_refl;
   fr.lut.sheen = ctx->d_lut_sheen;
@@ -764,8 +792,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const SceneDev sc = scene_dev(ctx);
   const PoolDev& pool = ctx->pool;
   const bool count = (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) != 0;
-  TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2};
-  TraceCounters tc_shadow{ctx->d_trace_counters + 3, ctx->d_trace_counters + 4, ctx->d_trace_counters + 5};
+  TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2, ctx->d_trace_counters + 6, ctx->d_trace_counters + 7};
+  TraceCounters tc_shadow{ctx->d_trace_counters + 3, ctx->d_trace_counters + 4, ctx->d_trace_counters + 5, ctx->d_trace_counters + 8, ctx->d_trace_counters + 9};
 
   if (!ctx->render_pending) { (void)hipEventRecord(ctx->ev_render_begin, st); ctx->render_pending = true; }
 

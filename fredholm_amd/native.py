@@ -74,7 +74,9 @@ class StatsC(C.Structure):
                 ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
                 ("paths", C.c_uint64), ("bvh_build_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_node_bytes", C.c_uint64),
-                ("bvh_tri_bytes", C.c_uint64)]
+                ("bvh_tri_bytes", C.c_uint64),
+                ("wave_node_steps_closest", C.c_uint64), ("wave_tri_steps_closest", C.c_uint64), ("wave_node_steps_shadow", C.c_uint64),
+                ("wave_tri_steps_shadow", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

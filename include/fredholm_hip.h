@@ -97,6 +97,9 @@ typedef struct fh_stats {
   uint64_t paths;                              /* camera paths started */
   double bvh_build_ms;
   uint64_t bvh_nodes, bvh_node_bytes, bvh_tri_bytes;
+  /* instrumented build only: wave-level executions of the node test / triangle test (SIMD efficiency =
+   * nodes_* / (64 * wave_node_steps_*), likewise for triangles) */
+  uint64_t wave_node_steps_closest, wave_tri_steps_closest, wave_node_steps_shadow, wave_tri_steps_shadow;
 } fh_stats;
 
 #define FH_FLAG_TIME_KERNELS 1u    /* bracket traversal/shade launches with HIP events (fh_stats *_ms) */
