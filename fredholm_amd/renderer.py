@@ -189,7 +189,11 @@ class Renderer:
 
     # -- scene (renderer.h:354-432)
     def load_scene(self, scene, clear=True):
-        """scene: dict of flat arrays as produced by fredholm_amd.scenes (the layout Scene exposes, scene.h:103-135)."""
+        """scene: a .obj path (renderer.h:354: load_scene(filepath, clear)) or a dict of flat arrays as produced by
+        fredholm_amd.scenes (the layout Scene exposes, scene.h:103-135)."""
+        if isinstance(scene, (str, bytes)) or hasattr(scene, "__fspath__"):
+            from . import scenes as _scenes
+            scene = _scenes.load_obj(str(scene))
         v = np.ascontiguousarray(scene["vertices"], dtype=np.float32).reshape(-1, 3)
         n = np.ascontiguousarray(scene["normals"], dtype=np.float32).reshape(-1, 3)
         t = np.ascontiguousarray(scene["texcoords"], dtype=np.float32).reshape(-1, 2)

@@ -137,3 +137,132 @@ def triangle_soup(n_tris=1_000_000, edge_scale=0.02):
 
 SOUP_CAMERA = dict(origin=(0.0, 0.0, 3.0), fov=np.radians(60.0), F=100.0, focus=10000.0)
 SOUP_SUN = (-0.1, 1.0, 0.1)  # rtcamp8.cpp:142-146
+
+
+# ---------------------------------------------------------------------------------------------
+# Wavefront .obj/.mtl in and out (the wire format in front of the hot path).
+# The reader applies the reference's tinyobjloader mapping (fredholm/src/scene.cpp:119-443): Kd -> base_color,
+# Ks -> specular_color, Pr / Pm / Pc, coat_roughness <- clearcoat_thickness (:240-242), transmission = 1 - d (:245),
+# Tf, Ke, custom keys diffuse, diffuse_roughness, sheen*, subsurface*, thin_walled; face normals and barycentric
+# texcoords when absent (:361-377).  include/fredholm/scene.h is the C++ twin of this reader.
+# ---------------------------------------------------------------------------------------------
+def write_obj(scene, path):
+    """Write a flat scene as .obj + .mtl next to it (positions only: normals/texcoords are regenerated on load)."""
+    import os
+    base = os.path.splitext(path)[0]
+    mats = scene["materials"]
+    with open(base + ".mtl", "w") as f:
+        for i, m in enumerate(mats):
+            f.write(f"newmtl m{i}\n")
+            f.write("Kd %.9g %.9g %.9g\n" % tuple(m["base_color"]))
+            f.write("Ks %.9g %.9g %.9g\n" % tuple(m["specular_color"]))
+            f.write("Pr %.9g\nPm %.9g\n" % (m["specular_roughness"], m["metalness"]))
+            if m["coat"] > 0:
+                f.write("Pc %.9g\n" % m["coat"])
+            f.write("d %.9g\n" % (1.0 - m["transmission"]))
+            if (m["emission_color"] > 0).any():
+                f.write("Ke %.9g %.9g %.9g\n" % tuple(m["emission_color"]))
+            f.write("diffuse %.9g\ndiffuse_roughness %.9g\n" % (m["diffuse"], m["diffuse_roughness"]))
+            f.write("sheen %.9g\nsheen_color %.9g %.9g %.9g\nsheen_roughness %.9g\n" % (m["sheen"], *m["sheen_color"], m["sheen_roughness"]))
+            f.write("subsurface %.9g\nsubsurface_color %.9g %.9g %.9g\nthin_walled %.9g\n" % (m["subsurface"], *m["subsurface_color"], m["thin_walled"]))
+            f.write("specular_weight %.9g\n\n" % m["specular"])
+    v = scene["vertices"]
+    with open(path, "w") as f:
+        f.write(f"mtllib {os.path.basename(base)}.mtl\n")
+        for p in v:
+            f.write("v %.9g %.9g %.9g\n" % tuple(p))
+        cur = None
+        for face, mid in zip(scene["indices"], scene["material_ids"]):
+            if mid != cur:
+                f.write(f"usemtl m{mid}\n")
+                cur = mid
+            f.write("f %d %d %d\n" % tuple(int(i) + 1 for i in face))
+
+
+def load_obj(path):
+    """Minimal .obj/.mtl reader producing the flat arrays Renderer.load_scene takes."""
+    import os
+    pos, nrm, tex = [], [], []
+    mats, mat_index = [], {}
+    verts, norms, uvs, faces, mids = [], [], [], [], []
+    cur = -1
+
+    def load_mtl(p):
+        m = None
+        pc = 0.0
+        for line in open(p):
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "newmtl":
+                m = default_materials(1)[0]
+                m["base_color"] = 0.0
+                m["specular_color"] = 0.0
+                mat_index[t[1]] = len(mats)
+                mats.append(m)
+                pc = 0.0
+                continue
+            if m is None:
+                continue
+            f = [float(x) for x in t[1:]] if all(_isnum(x) for x in t[1:]) else None
+            if t[0] == "Kd": m["base_color"] = f
+            elif t[0] == "Ks": m["specular_color"] = f
+            elif t[0] == "Pr" and f[0] > 0: m["specular_roughness"] = f[0]
+            elif t[0] == "Pm": m["metalness"] = f[0]
+            elif t[0] == "Pc":
+                pc = f[0]
+                if pc > 0: m["coat"] = pc
+            elif t[0] == "Pcr" and f[0] > 0: m["coat_roughness"] = pc
+            elif t[0] == "d": m["transmission"] = max(np.float32(1.0) - np.float32(f[0]), 0.0)
+            elif t[0] == "Tf" and max(f) > 0: m["transmission_color"] = f
+            elif t[0] == "Ke" and max(f) > 0:
+                m["emission"] = 1.0
+                m["emission_color"] = f
+            elif t[0] in ("diffuse", "diffuse_roughness", "sheen", "sheen_roughness", "subsurface", "thin_walled"): m[t[0]] = f[0]
+            elif t[0] in ("sheen_color", "subsurface_color"): m[t[0]] = f
+            elif t[0].startswith("map_") or t[0] in ("bump", "norm"):
+                raise ValueError(f"texture maps are not supported in this build ({t[0]} in {p})")
+
+    for line in open(path):
+        t = line.split()
+        if not t or t[0].startswith("#"):
+            continue
+        if t[0] == "v": pos.append([float(x) for x in t[1:4]])
+        elif t[0] == "vn": nrm.append([float(x) for x in t[1:4]])
+        elif t[0] == "vt": tex.append([float(x) for x in t[1:3]])
+        elif t[0] == "mtllib": load_mtl(os.path.join(os.path.dirname(path), t[1]))
+        elif t[0] == "usemtl": cur = mat_index.get(t[1], -1)
+        elif t[0] == "f":
+            cs = []
+            for tok in t[1:]:
+                parts = (tok.split("/") + ["", ""])[:3]
+                cs.append(tuple(int(x) if x else 0 for x in parts))
+            for k in range(1, len(cs) - 1):
+                tri = (cs[0], cs[k], cs[k + 1])
+                p = [np.asarray(pos[c[0] - 1 if c[0] > 0 else len(pos) + c[0]], dtype=np.float32) for c in tri]
+                has_n, has_t = all(c[2] for c in tri), all(c[1] for c in tri)
+                if not has_n:
+                    e1, e2 = p[1] - p[0], p[2] - p[0]
+                    e1, e2 = e1 / np.linalg.norm(e1), e2 / np.linalg.norm(e2)
+                    fn = np.cross(e1, e2)
+                    fn = (fn / np.linalg.norm(fn)).astype(np.float32)
+                base = len(verts)
+                for j, c in enumerate(tri):
+                    verts.append(p[j])
+                    norms.append(nrm[c[2] - 1 if c[2] > 0 else len(nrm) + c[2]] if has_n else fn)
+                    uvs.append(tex[c[1] - 1 if c[1] > 0 else len(tex) + c[1]] if has_t else [(0, 0), (1, 0), (0, 1)][j])
+                faces.append((base, base + 1, base + 2))
+                mids.append(cur)
+    if any(m < 0 for m in mids):
+        mats.append(default_materials(1)[0])
+        mids = [len(mats) - 1 if m < 0 else m for m in mids]
+    return {"vertices": np.asarray(verts, dtype=np.float32), "normals": np.asarray(norms, dtype=np.float32), "texcoords": np.asarray(uvs, dtype=np.float32),
+            "indices": np.asarray(faces, dtype=np.uint32), "material_ids": np.asarray(mids, dtype=np.uint32), "materials": np.asarray(mats, dtype=default_materials(1).dtype)}
+
+
+def _isnum(s):
+    try:
+        float(s)
+        return True
+    except ValueError:
+        return False

@@ -1,0 +1,140 @@
+// fredholm/renderer.h -- drop-in facade with the method surface of the reference's header-only
+// fredholm::Renderer (fredholm/include/fredholm/renderer.h:29-846).  Every method forwards to the C ABI of
+// libfredholm_hip.so; a non-zero status becomes std::runtime_error like the reference's CUDA_CHECK /
+// OPTIX_CHECK.  The OptiX pipeline-construction calls are kept as no-ops so application code
+// (app/controller.cpp:60-68, app/rtcamp8.cpp:75-146) compiles unchanged.
+#pragma once
+#include <cstdint>
+#include <filesystem>
+#include <stdexcept>
+
+#include "../cwl/util.h"
+#include "../optwl/optwl.h"
+#include "camera.h"
+#include "scene.h"
+#include "shared.h"
+
+namespace fredholm
+{
+
+class Renderer
+{
+ public:
+  explicit Renderer(const OptixDeviceContext& context) : m_ctx(context) {}
+  ~Renderer() noexcept(false) {}
+
+  // OptiX plumbing of the reference (renderer.h:124-352): nothing to build, the kernels live in the library
+  void create_module(const std::filesystem::path&) {}
+  void create_program_group() {}
+  void create_pipeline() {}
+  void create_sbt() {}
+
+  // renderer.h:354-432
+  void load_scene(const std::filesystem::path& filepath, bool clear = true)
+  {
+    m_scene.load_model(filepath, clear);
+    upload_scene();
+  }
+  // same upload for a scene assembled in memory
+  void load_scene(const Scene& scene)
+  {
+    m_scene = scene;
+    upload_scene();
+  }
+
+  void build_gas() {}                                                            // renderer.h:434-496: folded into build_ias
+  void build_ias() { cwl::check(m_ctx, fh_bvh_build(m_ctx), "fh_bvh_build"); }  // renderer.h:498-552
+
+  void set_directional_light(const float3& le, const float3& dir, float angle)  // renderer.h:554-567
+  {
+    const float l[3] = {le.x, le.y, le.z}, d[3] = {dir.x, dir.y, dir.z};
+    cwl::check(m_ctx, fh_set_directional_light(m_ctx, l, d, angle), "fh_set_directional_light");
+  }
+  void set_sky_intensity(float v) { cwl::check(m_ctx, fh_set_sky_intensity(m_ctx, v), "fh_set_sky_intensity"); }
+  void load_ibl(const std::filesystem::path&) { cwl::check(m_ctx, fh_load_ibl(m_ctx, nullptr, 0, 0), "fh_load_ibl"); }
+  void clear_ibl() {}
+  void load_arhosek_sky(float turbidity, float albedo) { cwl::check(m_ctx, fh_load_arhosek_sky(m_ctx, turbidity, albedo), "fh_load_arhosek_sky"); }
+  void clear_arhosek_sky() { cwl::check(m_ctx, fh_clear_arhosek_sky(m_ctx), "fh_clear_arhosek_sky"); }
+
+  void set_time(float time)  // renderer.h:614-640: animation update + acceleration-structure rebuild
+  {
+    m_scene.update_animation(time);
+    build_ias();
+  }
+  void set_resolution(uint32_t width, uint32_t height)  // renderer.h:642-648
+  {
+    m_width = width;
+    m_height = height;
+    cwl::check(m_ctx, fh_set_resolution(m_ctx, width, height), "fh_set_resolution");
+  }
+  void init_render_states() { cwl::check(m_ctx, fh_init_render_states(m_ctx), "fh_init_render_states"); }  // renderer.h:650-655
+
+  // renderer.h:657-734
+  void render(const Camera& camera, const float3& bg_color, const RenderLayer& render_layer, uint32_t n_samples, uint32_t max_depth)
+  {
+    const fh_camera cam = m_scene.m_has_camera_transform ? camera_from(m_scene.m_camera_transform, camera) : camera.to_c();
+    const float bg[3] = {bg_color.x, bg_color.y, bg_color.z};
+    fh_render_layers layers{reinterpret_cast<float*>(render_layer.beauty), reinterpret_cast<float*>(render_layer.position), render_layer.depth,
+                            reinterpret_cast<float*>(render_layer.normal), reinterpret_cast<float*>(render_layer.texcoord), reinterpret_cast<float*>(render_layer.albedo)};
+    cwl::check(m_ctx, fh_render(m_ctx, &cam, bg, &layers, n_samples, max_depth, 1u /* params.seed = 1, renderer.h:664 */), "fh_render");
+  }
+  void wait_for_completion() { cwl::check(m_ctx, fh_sync(m_ctx), "fh_sync"); }  // renderer.h:736
+
+ private:
+  static fh_camera camera_from(const Mat4& m, const Camera& camera)
+  {
+    fh_camera c = camera.to_c();
+    for (int r = 0; r < 3; ++r)
+      for (int col = 0; col < 4; ++col) c.transform[4 * r + col] = m[col][r];
+    return c;
+  }
+  void upload_scene()
+  {
+    if (!m_scene.is_valid()) throw std::runtime_error("invalid scene");
+    std::vector<float> o2w, w2o;
+    for (const Mat4& m : m_scene.m_transforms) {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) o2w.push_back(m[c][r]);
+      const Mat4 inv = affine_inverse(m);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) w2o.push_back(inv[c][r]);
+    }
+    fh_scene_desc d{};
+    d.n_vertices = uint32_t(m_scene.m_vertices.size());
+    d.vertices = reinterpret_cast<const float*>(m_scene.m_vertices.data());
+    d.normals = reinterpret_cast<const float*>(m_scene.m_normals.data());
+    d.texcoords = reinterpret_cast<const float*>(m_scene.m_texcoords.data());
+    d.n_faces = uint32_t(m_scene.m_indices.size());
+    d.indices = reinterpret_cast<const uint32_t*>(m_scene.m_indices.data());
+    d.material_ids = m_scene.m_material_ids.data();
+    d.instance_ids = m_scene.m_instance_ids.empty() ? nullptr : m_scene.m_instance_ids.data();
+    d.n_materials = uint32_t(m_scene.m_materials.size());
+    d.materials = reinterpret_cast<const fh_material*>(m_scene.m_materials.data());
+    d.n_instances = uint32_t(m_scene.m_transforms.size());
+    d.object_to_world = o2w.empty() ? nullptr : o2w.data();
+    d.world_to_object = w2o.empty() ? nullptr : w2o.data();
+    cwl::check(m_ctx, fh_scene_upload(m_ctx, &d), "fh_scene_upload");
+  }
+  static Mat4 affine_inverse(const Mat4& m)
+  {
+    // inverse of [A t; 0 1] with A the upper-left 3x3 (column-major storage)
+    const float a = m[0][0], b = m[1][0], c = m[2][0], d = m[0][1], e = m[1][1], f = m[2][1], g = m[0][2], h = m[1][2], i = m[2][2];
+    const float det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    const float id = 1.0f / det;
+    Mat4 r;
+    r[0][0] = (e * i - f * h) * id; r[1][0] = (c * h - b * i) * id; r[2][0] = (b * f - c * e) * id;
+    r[0][1] = (f * g - d * i) * id; r[1][1] = (a * i - c * g) * id; r[2][1] = (c * d - a * f) * id;
+    r[0][2] = (d * h - e * g) * id; r[1][2] = (b * g - a * h) * id; r[2][2] = (a * e - b * d) * id;
+    const float tx = m[3][0], ty = m[3][1], tz = m[3][2];
+    r[3][0] = -(r[0][0] * tx + r[1][0] * ty + r[2][0] * tz);
+    r[3][1] = -(r[0][1] * tx + r[1][1] * ty + r[2][1] * tz);
+    r[3][2] = -(r[0][2] * tx + r[1][2] * ty + r[2][2] * tz);
+    return r;
+  }
+
+  fh_ctx* m_ctx = nullptr;
+  uint32_t m_width = 0, m_height = 0;
+  Scene m_scene;
+};
+
+}  // namespace fredholm

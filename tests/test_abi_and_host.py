@@ -155,3 +155,47 @@ def test_world_size_2_gather_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GLOO_OK" in outs[0]
+
+
+# ---------------------------------------------------------------- wire formats and the C++ facade
+def test_obj_mtl_round_trip(tmp_path):
+    c = scenes.cornell_box()
+    c["materials"]["sheen"][1] = 0.25
+    c["materials"]["metalness"][2] = 0.5
+    path = str(tmp_path / "cornell.obj")
+    scenes.write_obj(c, path)
+    d = scenes.load_obj(path)
+    assert np.array_equal(c["vertices"], d["vertices"]) and np.array_equal(c["material_ids"], d["material_ids"])
+    assert np.abs(c["normals"] - d["normals"]).max() < 1e-6
+    assert np.array_equal(d["texcoords"][:3], [[0, 0], [1, 0], [0, 1]])
+    for k in ("base_color", "specular_color", "specular_roughness", "metalness", "sheen", "emission_color", "transmission", "coat"):
+        assert np.allclose(c["materials"][k], d["materials"][k]), k
+    assert d["materials"]["emission"][3] == 1.0  # scene.cpp:279-284
+
+
+def test_obj_reader_quirks(tmp_path):
+    (tmp_path / "q.mtl").write_text("newmtl a\nKd 0.5 0.5 0.5\nPc 0.7\nPcr 0.3\nd 0.25\n")
+    (tmp_path / "q.obj").write_text("mtllib q.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nusemtl a\nf 1 2 3 4\nf -4 -3 -2\n")
+    d = scenes.load_obj(str(tmp_path / "q.obj"))
+    assert d["indices"].shape[0] == 3  # quad fan-triangulated + one triangle with negative indices
+    m = d["materials"][0]
+    assert m["coat"] == np.float32(0.7) and m["coat_roughness"] == np.float32(0.7)  # scene.cpp:240-242 copies the thickness
+    assert m["transmission"] == np.float32(0.75) and (m["specular_color"] == 0).all()
+    assert np.allclose(d["normals"], [0, 0, 1])
+    (tmp_path / "t.mtl").write_text("newmtl a\nmap_Kd wood.png\n")
+    (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nf 1 2 3\n")
+    with pytest.raises(ValueError):
+        scenes.load_obj(str(tmp_path / "t.obj"))
+
+
+def test_cpp_facade_compiles_and_links(tmp_path):
+    """The drop-in headers in include/ + examples/headless.cpp (rtcamp8-shaped driver) build with plain g++."""
+    exe = tmp_path / "headless"
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "headless.cpp"), "-L" + os.path.join(ROOT, "fredholm_amd"),
+           "-lfredholm_hip", "-Wl,-rpath," + os.path.join(ROOT, "fredholm_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        run = subprocess.run([str(exe), "missing.obj"], capture_output=True, text=True)
+        assert run.returncode == 1 and "no HIP device" in run.stderr  # loud failure, no fallback
