@@ -204,13 +204,25 @@ def main():
         bytes_per_launch = (rays * (RAY_BYTES + HIT_BYTES) + nodes * node_bytes + tris * TRI_BYTES) / max(cnt_launches, 1)
         avg_ms = ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM-side bytes per launch come from a separate rocprofv3 --pmc run (counters cannot be read from inside this
+        # process); the committed summary of the latest such run is quoted when it is for the same dominant kernel
+        traffic = None
+        try:
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if tf:
+                tj = json.load(open(tf[-1]))
+                if tj.get("kernel", "").startswith(dom):
+                    traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "Msamples/s at 1920x1080, max_depth=8", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: 1M random-triangle soup (PCG32 seed 0x853c49e6748fea9b), Hosek sky turbidity 3 albedo 0.3, 1920x1080, max_depth 8, seed 1",
                        "spp_per_step": args.spp, "triangles": N_TRIS, "parallelism": f"pixel-tile x{world}" if world > 1 else "single GPU",
                        "gather": "RCCL all_gather of packed float4 beauty tiles, inside the timed region" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "per_ray": {"nodes": round(nodes / max(rays, 1), 2), "triangles": round(tris / max(rays, 1), 2), "bytes": round(bytes_per_launch * cnt_launches / max(rays, 1), 1)},
                          "note": "rank 0 shard" if world > 1 else "whole frame"},
