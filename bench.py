@@ -227,7 +227,7 @@ def main():
                          "per_ray": {"nodes": round(nodes / max(rays, 1), 2), "triangles": round(tris / max(rays, 1), 2), "bytes": round(bytes_per_launch * cnt_launches / max(rays, 1), 1)},
                          "note": "rank 0 shard" if world > 1 else "whole frame"},
             "kernel_ms_per_step": {"trace_closest": round(timed["trace_closest_ms"] / args.steps, 3), "trace_secondary": round(timed["trace_shadow_ms"] / args.steps, 3),
-                                   "shade": round(timed["shade_ms"] / args.steps, 3), "render_total": round(timed["render_ms"] / args.steps, 3)},
+                                   "shade": round(timed["shade_ms"] / args.steps, 3), "tail": round(timed["tail_ms"] / args.steps, 3), "render_total": round(timed["render_ms"] / args.steps, 3)},
             "bvh": {"build_ms": round(timed["bvh_build_ms"], 2), "nodes": timed["bvh_nodes"], "node_bytes": timed["bvh_node_bytes"], "tri_bytes": timed["bvh_tri_bytes"]},
         }
         if world == 1 and not args.no_cpu_baseline:

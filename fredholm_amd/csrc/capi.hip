@@ -193,11 +193,13 @@ int fh_ctx_create(int device, fh_ctx** out)
   if (hipMalloc((void**)&ctx->d_sobol, kSobolMatricesBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_refl, kLutReflectionBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_sheen, kLutSheenBytes) != hipSuccess) return bail("hipMalloc failed");
-  if (hipMalloc((void**)&ctx->d_trace_counters, 10 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
+  if (hipMalloc((void**)&ctx->d_trace_counters, 26 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
   if (hipMemcpy(ctx->d_sobol, kSobolMatrices, kSobolMatricesBytes, hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
   (void)hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
-  (void)hipMemset(ctx->d_trace_counters, 0, 10 * sizeof(unsigned long long));
+  (void)hipMemset(ctx->d_trace_counters, 0, 26 * sizeof(unsigned long long));
+  (void)hipHostMalloc((void**)&ctx->h_counters, sizeof(uint32_t) * fh::kCounterStride * 66);
+  (void)hipEventCreate(&ctx->ev_counters);
   (void)hipEventCreate(&ctx->ev_render_begin);
   (void)hipEventCreate(&ctx->ev_render_end);
   *out = ctx;
@@ -216,6 +218,8 @@ int fh_ctx_destroy(fh_ctx* ctx)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+  (void)hipEventDestroy(ctx->ev_counters);
   (void)hipEventDestroy(ctx->ev_render_begin);
   (void)hipEventDestroy(ctx->ev_render_end);
   (void)hipStreamDestroy(ctx->stream);
@@ -239,6 +243,13 @@ int fh_set_path_pool(fh_ctx* ctx, uint32_t target)
   (void)hipStreamSynchronize(ctx->stream);
   pool_release(ctx);
   ctx->pool_target = target;
+  return FH_OK;
+}
+
+int fh_set_tail_depth(fh_ctx* ctx, uint32_t depth)
+{
+  CTX_CHECK(ctx);
+  ctx->tail_depth = depth;  // 0 = adaptive; bounce 0 always runs as wavefront kernels (it writes the first-hit AOVs)
   return FH_OK;
 }
 
@@ -422,6 +433,7 @@ int fh_sync(fh_ctx* ctx)
     if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
       if (s.kind == 0) ctx->stats.trace_closest_ms += ms;
       else if (s.kind == 1) ctx->stats.trace_shadow_ms += ms;
+      else if (s.kind == 3) ctx->stats.tail_ms += ms;
       else ctx->stats.shade_ms += ms;
     }
     ctx->event_pool.push_back(s.a);
@@ -429,9 +441,10 @@ int fh_sync(fh_ctx* ctx)
   }
   ctx->spans.clear();
   if (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) {
-    unsigned long long c[10];
+    unsigned long long c[26];
     FH_HIP(hipMemcpy(c, ctx->d_trace_counters, sizeof c, hipMemcpyDeviceToHost));
     ctx->stats.wave_node_steps_closest = c[6]; ctx->stats.wave_tri_steps_closest = c[7]; ctx->stats.wave_node_steps_shadow = c[8]; ctx->stats.wave_tri_steps_shadow = c[9];
+    for (int k = 0; k < 8; ++k) { ctx->stats.hist_nodes_closest[k] = c[10 + k]; ctx->stats.hist_nodes_shadow[k] = c[18 + k]; }
     ctx->stats.nodes_closest = c[0]; ctx->stats.tris_closest = c[1]; ctx->stats.rays_closest = c[2];
     ctx->stats.nodes_shadow = c[3]; ctx->stats.tris_shadow = c[4]; ctx->stats.rays_shadow = c[5];
   }
@@ -452,7 +465,7 @@ int fh_reset_stats(fh_ctx* ctx)
   const uint64_t nodes = ctx->stats.bvh_nodes, nb = ctx->stats.bvh_node_bytes, tb = ctx->stats.bvh_tri_bytes;
   ctx->stats = fh_stats{};
   ctx->stats.bvh_build_ms = build_ms; ctx->stats.bvh_nodes = nodes; ctx->stats.bvh_node_bytes = nb; ctx->stats.bvh_tri_bytes = tb;
-  FH_HIP(hipMemsetAsync(ctx->d_trace_counters, 0, 10 * sizeof(unsigned long long), ctx->stream));
+  FH_HIP(hipMemsetAsync(ctx->d_trace_counters, 0, 26 * sizeof(unsigned long long), ctx->stream));
   return FH_OK;
 }
 

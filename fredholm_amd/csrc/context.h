@@ -66,7 +66,13 @@ struct fh_ctx {
   // path pool
   fh::PoolDev pool{};
   std::vector<void*> pool_allocs;
-  uint32_t pool_target = 1u << 22;
+  uint32_t pool_target = 1u << 25;  // 32 Mi path slots (12.5 GB): 16 samples per pixel per pass at 1080p
+  uint32_t tail_depth = 0;          // bounces run as wavefront kernels before k_tail finishes the survivors; 0 = adaptive
+  uint32_t auto_wave_depth = 2;     // adaptive choice, updated from the per-bounce survivor counts of earlier passes
+  uint32_t* h_counters = nullptr;   // pinned snapshot of the per-bounce counters of a finished pass
+  hipEvent_t ev_counters = nullptr;
+  bool counters_in_flight = false;
+  uint32_t counters_wave_depth = 0; // wave depth used by the pass the snapshot comes from
 
   // stats
   fh_stats stats{};

@@ -126,7 +126,7 @@ struct LayersDev {
 };
 
 // traversal statistics (only written by the instrumented kernel variants)
-struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; unsigned long long* rays; unsigned long long* wave_nodes; unsigned long long* wave_tris; };
+struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; unsigned long long* rays; unsigned long long* wave_nodes; unsigned long long* wave_tris; unsigned long long* hist; };  // hist: 8 buckets of node steps per ray (<=8, <=16, ... <=512, more)
 
 // ---- wave-aggregated queue append: one atomic per wave (ballot + popcount prefix)
 FH_D void queue_push(uint32_t* counter, uint32_t* queue, bool active, uint32_t value)

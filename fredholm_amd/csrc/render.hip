@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
     bool enter = false;
     if (valid) {
       bool alive = false;
-      const uint32_t i = p % n_owned, k = p / n_owned;
+      const uint32_t i = p % n_owned, k = p / n_owned;  // slot p = sample-major: lanes of a wave hold neighbouring pixels of one sample index
       const uint32_t image_idx = owned[i];
       const uint32_t n_spp = layers.sample_count[image_idx] + k;
       const uint32_t px = image_idx % fr.width, py = image_idx / fr.width;
@@ -90,30 +90,37 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
       f3 d = normalize(p_object - p_lens);
       d.z *= -1.0f;
       const f3 dir = xform_dir(fr.cam_xf, d);
-      pool.ray_o[p] = mk4(org, 1e9f);
-      pool.ray_d[p] = mk4(dir, 0.0f);
-      pool.thr[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-      pool.rad[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      pool.pixel[p] = image_idx;
-      pool.nspp[p] = n_spp;
       // Russian roulette of bounce 0 has probability 1 but still consumes (and can fail on) a draw, pt.cu:457-461
       const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
       const float rr = sobol_draw(rows.m[0], sidx, 1u, fr.seed_hash);
       alive = fr.max_depth > 0 && !(rr >= 1.0f);
-      pool.flags[p] = alive ? 0u : 2u;
-      // camera rays that miss the (padded) scene bounds cannot hit anything: record the miss here and keep
-      // them out of the traversal queue, so the waves of bounce 0 only hold rays that enter the scene
+      // camera rays that miss the (padded) scene bounds cannot hit anything: they are finished right here
+      // (radiance = 0 + 1 * environment, pt.cu:504-523) and never enter the traversal queue, so the waves of
+      // bounce 0 only hold rays that enter the scene and no path state is written for the others
       const RayPre rp = ray_prepare(org, dir);
       float tn;
       enter = alive && slab_test(rp, fr.scene_lo.x, fr.scene_lo.y, fr.scene_lo.z, fr.scene_hi.x, fr.scene_hi.y, fr.scene_hi.z, 1e9f, tn);
-      if (!enter) pool.hit[p] = make_float4(1e9f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
+      if (enter) {
+        pool.ray_o[p] = mk4(org, 1e9f);
+        pool.ray_d[p] = mk4(dir, 0.0f);
+        pool.thr[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        pool.rad[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        pool.pixel[p] = image_idx;
+        pool.nspp[p] = n_spp;
+        pool.flags[p] = 0u;
+      } else {
+        const f3 r = alive ? mk3(0.0f) + mk3(1.0f) * env_radiance(fr, dir) : mk3(0.0f);
+        pool.rad[p] = mk4(r, 0.0f);
+        pool.flags[p] = 2u;  // finished: k_miss_primary must not touch it
+        pool.hit[p] = make_float4(1e9f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
+      }
     }
     queue_push(&pool.counters[CNT_RAD], pool.q_rad[0], enter, p);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// closest hit, binary-BVH fallback (tiny scenes / FH_BVH2): static grid-stride
+// closest hit: one lane per ray, grid-stride over the queue (binary-BVH fallback shares this kernel)
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc)
 {
@@ -127,6 +134,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, Po
     if (COUNT) nr++;
     const float4 o = pool.ray_o[p], d = pool.ray_d[p];
     HitRec h;
+    const uint32_t nn0 = nn;
     if (sc.use_bvh8 == 2u) {
       Trav8 tr;
       tr.init(mk3(o), mk3(d), o.w);
@@ -135,6 +143,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, Po
     } else {
       traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
     }
+    if (COUNT) { const uint32_t k = nn - nn0; int b = 0; while (b < 7 && k > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
     pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
   }
   if (COUNT) {
@@ -226,11 +235,13 @@ __global__ void __launch_bounds__(kBlock) k_route(SceneDev sc, PoolDev pool, uin
 
 // ------------------------------------------------------------------------------------------------
 // paths that leave the scene at depth 0 see the environment directly (pt.cu:504-523)
-__global__ void __launch_bounds__(kBlock) k_miss_primary(FrameDev fr, PoolDev pool, uint32_t n_paths)
+__global__ void __launch_bounds__(kBlock) k_miss_primary(FrameDev fr, PoolDev pool)
 {
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_paths; p += gridDim.x * blockDim.x) {
+  const uint32_t count = pool.counters[CNT_RAD];
+  const uint32_t* q = pool.q_rad[0];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const uint32_t p = q[i];
     if (__float_as_uint(pool.hit[p].w) != 0xffffffffu) continue;
-    if (pool.flags[p] & 2u) continue;  // never traced
     const f3 T = mk3(pool.thr[p]);
     const f3 d = mk3(pool.ray_d[p]);
     const f3 r = mk3(pool.rad[p]) + T * env_radiance(fr, d);
@@ -271,24 +282,197 @@ FH_D void store_secondary(const PoolDev& pool, uint32_t slot, uint32_t p, f3 o, 
   pool.sec_c[k] = mk4(c, 0.0f);
 }
 
+// Sobol' dimensions and CMJ slots of one bounce
+struct BounceSlots {
+  uint32_t has_lights;
+  uint32_t dim_area, dim_light, dim_next, dim_rr;
+  uint32_t slot_dir, slot_sky, slot_area, slot_light, slot_next;
+  FH_D void set(const FrameDev& fr, uint32_t n_lights, uint32_t depth)
+  {
+    has_lights = n_lights > 0 ? 1u : 0u;
+    const uint32_t dim0 = 1u + depth * fr.n1;  // this bounce's RR dimension (already consumed)
+    dim_area = dim0 + 1u;                      // only drawn if has_lights
+    dim_light = dim0 + 1u + has_lights;
+    dim_next = dim_light + 1u;
+    dim_rr = 1u + (depth + 1u) * fr.n1;
+    const uint32_t slot0 = 2u + depth * fr.n2;
+    slot_dir = slot0;
+    slot_sky = slot0 + fr.has_dir;
+    slot_area = slot_sky + 1u;
+    slot_light = slot_sky + 1u + has_lights;
+    slot_next = slot_light + 1u;
+  }
+  FH_D void load_rows(SobolRows& rows, const uint32_t* table) const
+  {
+    const uint32_t dims[4] = {dim_area, dim_light, dim_next, dim_rr};
+    load_sobol_rows(rows, table, dims);
+  }
+};
+
+struct SecRay { f3 o; float tmax; f3 d; bool active; f3 c; };
+
+// everything one shaded hit produces (pt.cu:680-944), independent of where it is stored
+struct ShadeOut {
+  bool emissive_done;  // first hit on an emitter: radiance updated, path ends, nothing else valid
+  bool shaded;         // secondary rays valid
+  bool cont;           // next ray valid
+  f3 L;                // radiance after a directly visible emitter
+  f3 T;                // throughput for the next bounce (after Russian roulette)
+  SecRay sec[SEC_COUNT];
+  f3 lp_T, lp_f;       // light ray with emitters: throughput before the update, BSDF value
+  float lp_cos, lp_pdf;
+  f3 next_o, next_d;
+  f3 aov_position, aov_normal, aov_albedo;
+  float aov_u, aov_v;
+};
+
+template <uint32_t LOBES>
+FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& rows, const BounceSlots& bs, uint32_t depth, float4 hit, f3 rd, f3 T, f3 L, uint32_t image_idx, uint32_t n_spp,
+                    ShadeOut& out)
+{
+  const uint32_t has_lights = bs.has_lights;
+  const uint32_t prim = __float_as_uint(hit.w);
+  const float bu = hit.y, bv = hit.z;
+  const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
+  out.emissive_done = false; out.shaded = false; out.cont = false;
+  out.L = L; out.T = T;
+#pragma unroll
+  for (uint32_t k = 0; k < SEC_COUNT; ++k) out.sec[k].active = false;
+
+  // surface (pt.cu:141-179) from the pre-transformed face record
+  const float4 r0 = sc.face_rec[7 * (size_t)prim], r1 = sc.face_rec[7 * (size_t)prim + 1], r2 = sc.face_rec[7 * (size_t)prim + 2];
+  const float4 r3 = sc.face_rec[7 * (size_t)prim + 3], r4 = sc.face_rec[7 * (size_t)prim + 4], r5 = sc.face_rec[7 * (size_t)prim + 5];
+  const float4 r6 = sc.face_rec[7 * (size_t)prim + 6];
+  const f3 p0 = mk3(r0), p1 = mk3(r1), p2 = mk3(r2);
+  const float bw = 1.0f - bu - bv;
+  const f3 x = bw * p0 + bu * p1 + bv * p2;
+  f3 ng = normalize(cross(p1 - p0, p2 - p0));
+  f3 ns = normalize(bw * mk3(r3) + bu * mk3(r4) + bv * mk3(r5));
+  const float tu = bw * r0.w + bu * r2.w + bv * r4.w;
+  const float tv = bw * r1.w + bu * r3.w + bv * r5.w;
+  const bool entering = dot(-rd, ng) > 0;
+  ns = entering ? ns : -ns;
+  ng = entering ? ng : -ng;
+  f3 tangent, bitangent;
+  onb(ns, tangent, bitangent);
+  const MaterialDev& mat = sc.materials[__float_as_uint(r6.x)];
+  const MatParams sp = load_params(mat);
+
+  if (depth == 0) {  // first hit: AOVs and directly visible emitters (pt.cu:745-760)
+    out.aov_position = x; out.aov_normal = ns; out.aov_albedo = sp.base_color; out.aov_u = tu; out.aov_v = tv;
+    if (mat.emissive) {
+      out.L = L + T * mk3(mat.w[38], mat.w[39], mat.w[40]);
+      out.emissive_done = true;
+      return;
+    }
+  }
+  out.shaded = true;
+  const f3 wo = to_local(-rd, tangent, ns, bitangent);
+  Bsdf<LOBES> bsdf;
+  bsdf.init(wo, sp, entering, fr.lut);
+  const f3 so = offset_origin(x, ng);
+
+  // directional light (pt.cu:772-793)
+  if (fr.has_dir) {
+    const f2 pdisk = concentric_disk(cmj_draw(n_spp, image_idx, bs.slot_dir, fr.seed_hash));
+    f3 t, b;
+    onb(fr.dir_dir, t, b);
+    const f3 pl = 1e9f * fr.dir_dir + fr.dir_disk_radius * (t * pdisk.x + b * pdisk.y);
+    const f3 sd = normalize(pl - so);
+    const f3 wi = to_local(sd, tangent, ns, bitangent);
+    const f3 f = bsdf.eval(wo, wi);
+    const float pdf = 1.0f;
+    const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
+    out.sec[SEC_DIR] = SecRay{so, 1e9f - 0.001f, sd, true, clamp01(T * w * f * abs_cos(wi) / pdf) * fr.dir_le};
+  }
+  // sky / constant background (pt.cu:817-857)
+  {
+    const f3 wi = cosine_hemisphere(cmj_draw(n_spp, image_idx, bs.slot_sky, fr.seed_hash));
+    const f3 sd = to_world(wi, tangent, ns, bitangent);
+    const f3 f = bsdf.eval(wo, wi);
+    const float pdf = abs_cos(wi) / kPi;
+    const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
+    out.sec[SEC_SKY] = SecRay{so, 1e9f - 0.001f, sd, true, clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, sd)};
+  }
+  // area lights (pt.cu:860-889, :282-322)
+  if (has_lights) {
+    const float u1 = sobol_draw(rows.m[0], sidx, bs.dim_area, fr.seed_hash);
+    const f2 u2 = cmj_draw(n_spp, image_idx, bs.slot_area, fr.seed_hash);
+    uint32_t li = (uint32_t)(u1 * sc.n_lights);
+    li = li < sc.n_lights - 1u ? li : sc.n_lights - 1u;
+    const AreaLightDev lt = sc.lights[li];
+    const f2 bc = triangle_barycentric(u2);
+    const float4 l0 = sc.face_rec[7 * (size_t)lt.face], l1 = sc.face_rec[7 * (size_t)lt.face + 1], l2 = sc.face_rec[7 * (size_t)lt.face + 2];
+    const float4 l3 = sc.face_rec[7 * (size_t)lt.face + 3], l4 = sc.face_rec[7 * (size_t)lt.face + 4], l5 = sc.face_rec[7 * (size_t)lt.face + 5];
+    const float lw = 1.0f - bc.x - bc.y;
+    const f3 lp = lw * mk3(l0) + bc.x * mk3(l1) + bc.y * mk3(l2);
+    const f3 ln = lw * mk3(l3) + bc.x * mk3(l4) + bc.y * mk3(l5);
+    const float area = 0.5f * length(cross(mk3(l1) - mk3(l0), mk3(l2) - mk3(l0)));
+    const MaterialDev& lm = sc.materials[lt.material];
+    const f3 le = mk3(lm.w[38], lm.w[39], lm.w[40]);
+    const float pdf_area = 1.0f / (sc.n_lights * area);
+    const f3 sd = normalize(lp - so);
+    const float r = length(lp - so);
+    const bool facing = dot(-sd, ln) > 0.0f;
+    const f3 wi = to_local(sd, tangent, ns, bitangent);
+    const f3 f = bsdf.eval(wo, wi);
+    const float pdf = r * r / fabsf(dot(-sd, ln)) * pdf_area;
+    const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
+    out.sec[SEC_AREA] = SecRay{so, r - 0.001f, sd, facing, clamp01(T * w * f * abs_cos(wi) / pdf) * le};
+  }
+  // BSDF-sampled light ray (pt.cu:893-925)
+  {
+    f3 f;
+    float pdf;
+    const float u1 = sobol_draw(rows.m[1], sidx, bs.dim_light, fr.seed_hash);
+    const f2 u2 = cmj_draw(n_spp, image_idx, bs.slot_light, fr.seed_hash);
+    const f3 wi = bsdf.sample(wo, u1, u2, f, pdf);
+    const f3 ld = to_world(wi, tangent, ns, bitangent);
+    const bool transmitted = dot(ld, ng) < 0;
+    const f3 lo = offset_origin(x, transmitted ? -ng : ng);
+    if (has_lights) {
+      // the MIS weight needs the hit (emitter or sky): finished once the closest hit is known
+      out.lp_T = T; out.lp_cos = abs_cos(wi); out.lp_f = f; out.lp_pdf = pdf;
+      out.sec[SEC_LIGHT] = SecRay{lo, 1e9f, ld, true, mk3(0.0f)};
+    } else {
+      // no emitters: the ray contributes only if it escapes, with the sky's cosine pdf (pt.cu:917-919)
+      const float pdf_light = abs_cos(wi) / kPi;
+      const float w = pdf / (pdf + pdf_light);
+      out.sec[SEC_LIGHT] = SecRay{lo, 1e9f, ld, true, clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, ld)};
+    }
+  }
+  // next direction (pt.cu:928-943) and the next bounce's Russian roulette (pt.cu:457-471)
+  {
+    f3 f;
+    float pdf;
+    const float u1 = sobol_draw(rows.m[2], sidx, bs.dim_next, fr.seed_hash);
+    const f2 u2 = cmj_draw(n_spp, image_idx, bs.slot_next, fr.seed_hash);
+    const f3 wi = bsdf.sample(wo, u1, u2, f, pdf);
+    const f3 wd = to_world(wi, tangent, ns, bitangent);
+    f3 Tn = T;
+    Tn *= f * abs_cos(wi) / pdf;
+    const bool transmitted = dot(wd, ng) < 0;
+    const f3 no = offset_origin(x, transmitted ? -ng : ng);
+    if (!bad3(Tn) && depth + 1u < fr.max_depth) {
+      const float prr = clampf(lum(Tn), 0.0f, 1.0f);
+      const float u = sobol_draw(rows.m[3], sidx, bs.dim_rr, fr.seed_hash);
+      if (!(u >= prr)) {
+        out.T = Tn / prr;
+        out.cont = true;
+        out.next_o = no;
+        out.next_d = wd;
+      }
+    }
+  }
+}
+
 template <uint32_t LOBES>
 __global__ void __launch_bounds__(kBlock) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
 {
   __shared__ SobolRows rows;
-  const uint32_t has_lights = sc.n_lights > 0 ? 1u : 0u;
-  const uint32_t dim0 = 1u + depth * fr.n1;              // this bounce's RR dimension (already consumed)
-  const uint32_t dim_area = dim0 + 1u;                   // only if has_lights
-  const uint32_t dim_light = dim0 + 1u + has_lights;
-  const uint32_t dim_next = dim_light + 1u;
-  const uint32_t dim_rr = 1u + (depth + 1u) * fr.n1;
-  const uint32_t dims[4] = {dim_area, dim_light, dim_next, dim_rr};
-  load_sobol_rows(rows, fr.sobol, dims);
-  const uint32_t slot0 = 2u + depth * fr.n2;
-  const uint32_t slot_dir = slot0;
-  const uint32_t slot_sky = slot0 + fr.has_dir;
-  const uint32_t slot_area = slot_sky + 1u;
-  const uint32_t slot_light = slot_sky + 1u + has_lights;
-  const uint32_t slot_next = slot_light + 1u;
+  BounceSlots bs;
+  bs.set(fr, sc.n_lights, depth);
+  bs.load_rows(rows, fr.sobol);
 
   uint32_t* cnt = pool.counters + depth * kCounterStride;
   uint32_t* cnt_next = cnt + kCounterStride;
@@ -303,151 +487,32 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev sc, FrameDev fr, Pool
     uint32_t p = 0;
     if (valid) {
       p = q[i];
-      const float4 hit = pool.hit[p];
-      const uint32_t prim = __float_as_uint(hit.w);
-      const float bu = hit.y, bv = hit.z;
-      const f3 rd = mk3(pool.ray_d[p]);
-      f3 T = mk3(pool.thr[p]);
-      f3 L = mk3(pool.rad[p]);
-      const uint32_t image_idx = pool.pixel[p], n_spp = pool.nspp[p];
-      const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
-
-      // surface (pt.cu:141-179) from the pre-transformed face record
-      const float4 r0 = sc.face_rec[7 * (size_t)prim], r1 = sc.face_rec[7 * (size_t)prim + 1], r2 = sc.face_rec[7 * (size_t)prim + 2];
-      const float4 r3 = sc.face_rec[7 * (size_t)prim + 3], r4 = sc.face_rec[7 * (size_t)prim + 4], r5 = sc.face_rec[7 * (size_t)prim + 5];
-      const float4 r6 = sc.face_rec[7 * (size_t)prim + 6];
-      const f3 p0 = mk3(r0), p1 = mk3(r1), p2 = mk3(r2);
-      const float bw = 1.0f - bu - bv;
-      const f3 x = bw * p0 + bu * p1 + bv * p2;
-      f3 ng = normalize(cross(p1 - p0, p2 - p0));
-      f3 ns = normalize(bw * mk3(r3) + bu * mk3(r4) + bv * mk3(r5));
-      const float tu = bw * r0.w + bu * r2.w + bv * r4.w;
-      const float tv = bw * r1.w + bu * r3.w + bv * r5.w;
-      const bool entering = dot(-rd, ng) > 0;
-      ns = entering ? ns : -ns;
-      ng = entering ? ng : -ng;
-      f3 tangent, bitangent;
-      onb(ns, tangent, bitangent);
-      const MaterialDev& mat = sc.materials[__float_as_uint(r6.x)];
-      const MatParams sp = load_params(mat);
-
-      bool done = false;
-      if (depth == 0) {  // first hit: AOVs and directly visible emitters (pt.cu:745-760)
-        pool.aov_position[p] = mk4(x, 0.0f);
-        pool.aov_normal[p] = mk4(ns, 0.0f);
-        pool.aov_albedo[p] = mk4(sp.base_color, 0.0f);
-        pool.aov_texdepth[p] = make_float4(tu, tv, hit.x, 0.0f);
+      ShadeOut o;
+      shade_hit<LOBES>(sc, fr, rows, bs, depth, pool.hit[p], mk3(pool.ray_d[p]), mk3(pool.thr[p]), mk3(pool.rad[p]), pool.pixel[p], pool.nspp[p], o);
+      if (depth == 0) {
+        pool.aov_position[p] = mk4(o.aov_position, 0.0f);
+        pool.aov_normal[p] = mk4(o.aov_normal, 0.0f);
+        pool.aov_albedo[p] = mk4(o.aov_albedo, 0.0f);
+        pool.aov_texdepth[p] = make_float4(o.aov_u, o.aov_v, pool.hit[p].x, 0.0f);
         pool.flags[p] |= 1u;
-        if (mat.emissive) {
-          L += T * mk3(mat.w[38], mat.w[39], mat.w[40]);
-          pool.rad[p] = mk4(L, 0.0f);
-          done = true;
-        }
       }
-      if (!done) {
-        shaded = true;
-        const f3 wo = to_local(-rd, tangent, ns, bitangent);
-        Bsdf<LOBES> bsdf;
-        bsdf.init(wo, sp, entering, fr.lut);
-        const f3 so = offset_origin(x, ng);
-
-        // directional light (pt.cu:772-793)
-        if (fr.has_dir) {
-          const f2 pdisk = concentric_disk(cmj_draw(n_spp, image_idx, slot_dir, fr.seed_hash));
-          f3 t, b;
-          onb(fr.dir_dir, t, b);
-          const f3 pl = 1e9f * fr.dir_dir + fr.dir_disk_radius * (t * pdisk.x + b * pdisk.y);
-          const f3 sd = normalize(pl - so);
-          const f3 wi = to_local(sd, tangent, ns, bitangent);
-          const f3 f = bsdf.eval(wo, wi);
-          const float pdf = 1.0f;
-          const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
-          const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * fr.dir_le;
-          store_secondary(pool, SEC_DIR, p, so, 1e9f - 0.001f, sd, true, c);
+      if (o.emissive_done) pool.rad[p] = mk4(o.L, 0.0f);
+      shaded = o.shaded;
+      cont = o.cont;
+      if (shaded) {
+        if (fr.has_dir) store_secondary(pool, SEC_DIR, p, o.sec[SEC_DIR].o, o.sec[SEC_DIR].tmax, o.sec[SEC_DIR].d, o.sec[SEC_DIR].active, o.sec[SEC_DIR].c);
+        store_secondary(pool, SEC_SKY, p, o.sec[SEC_SKY].o, o.sec[SEC_SKY].tmax, o.sec[SEC_SKY].d, o.sec[SEC_SKY].active, o.sec[SEC_SKY].c);
+        if (bs.has_lights) {
+          store_secondary(pool, SEC_AREA, p, o.sec[SEC_AREA].o, o.sec[SEC_AREA].tmax, o.sec[SEC_AREA].d, o.sec[SEC_AREA].active, o.sec[SEC_AREA].c);
+          pool.lp_a[p] = mk4(o.lp_T, o.lp_cos);
+          pool.lp_b[p] = mk4(o.lp_f, o.lp_pdf);
         }
-        // sky / constant background (pt.cu:817-857)
-        {
-          const f3 wi = cosine_hemisphere(cmj_draw(n_spp, image_idx, slot_sky, fr.seed_hash));
-          const f3 sd = to_world(wi, tangent, ns, bitangent);
-          const f3 f = bsdf.eval(wo, wi);
-          const float pdf = abs_cos(wi) / kPi;
-          const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
-          const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, sd);
-          store_secondary(pool, SEC_SKY, p, so, 1e9f - 0.001f, sd, true, c);
-        }
-        // area lights (pt.cu:860-889, :282-322)
-        if (has_lights) {
-          const float u1 = sobol_draw(rows.m[0], sidx, dim_area, fr.seed_hash);
-          const f2 u2 = cmj_draw(n_spp, image_idx, slot_area, fr.seed_hash);
-          uint32_t li = (uint32_t)(u1 * sc.n_lights);
-          li = li < sc.n_lights - 1u ? li : sc.n_lights - 1u;
-          const AreaLightDev lt = sc.lights[li];
-          const f2 bc = triangle_barycentric(u2);
-          const float4 l0 = sc.face_rec[7 * (size_t)lt.face], l1 = sc.face_rec[7 * (size_t)lt.face + 1], l2 = sc.face_rec[7 * (size_t)lt.face + 2];
-          const float4 l3 = sc.face_rec[7 * (size_t)lt.face + 3], l4 = sc.face_rec[7 * (size_t)lt.face + 4], l5 = sc.face_rec[7 * (size_t)lt.face + 5];
-          const float lw = 1.0f - bc.x - bc.y;
-          const f3 lp = lw * mk3(l0) + bc.x * mk3(l1) + bc.y * mk3(l2);
-          const f3 ln = lw * mk3(l3) + bc.x * mk3(l4) + bc.y * mk3(l5);
-          const float area = 0.5f * length(cross(mk3(l1) - mk3(l0), mk3(l2) - mk3(l0)));
-          const MaterialDev& lm = sc.materials[lt.material];
-          const f3 le = mk3(lm.w[38], lm.w[39], lm.w[40]);
-          const float pdf_area = 1.0f / (sc.n_lights * area);
-          const f3 sd = normalize(lp - so);
-          const float r = length(lp - so);
-          const bool facing = dot(-sd, ln) > 0.0f;
-          const f3 wi = to_local(sd, tangent, ns, bitangent);
-          const f3 f = bsdf.eval(wo, wi);
-          const float pdf = r * r / fabsf(dot(-sd, ln)) * pdf_area;
-          const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
-          const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * le;
-          store_secondary(pool, SEC_AREA, p, so, r - 0.001f, sd, facing, c);
-        }
-        // BSDF-sampled light ray (pt.cu:893-925)
-        {
-          f3 f;
-          float pdf;
-          const float u1 = sobol_draw(rows.m[1], sidx, dim_light, fr.seed_hash);
-          const f2 u2 = cmj_draw(n_spp, image_idx, slot_light, fr.seed_hash);
-          const f3 wi = bsdf.sample(wo, u1, u2, f, pdf);
-          const f3 ld = to_world(wi, tangent, ns, bitangent);
-          const bool transmitted = dot(ld, ng) < 0;
-          const f3 lo = offset_origin(x, transmitted ? -ng : ng);
-          if (has_lights) {
-            // the MIS weight needs the hit (emitter or sky): finish it in k_trace_secondary
-            pool.lp_a[p] = mk4(T, abs_cos(wi));
-            pool.lp_b[p] = mk4(f, pdf);
-            store_secondary(pool, SEC_LIGHT, p, lo, 1e9f, ld, true, mk3(0.0f));
-          } else {
-            // no emitters: the ray contributes only if it escapes, with the sky's cosine pdf (pt.cu:917-919)
-            const float pdf_light = abs_cos(wi) / kPi;
-            const float w = pdf / (pdf + pdf_light);
-            const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, ld);
-            store_secondary(pool, SEC_LIGHT, p, lo, 1e9f, ld, true, c);
-          }
-        }
-        // next direction (pt.cu:928-943) and the next bounce's Russian roulette (pt.cu:457-471)
-        {
-          f3 f;
-          float pdf;
-          const float u1 = sobol_draw(rows.m[2], sidx, dim_next, fr.seed_hash);
-          const f2 u2 = cmj_draw(n_spp, image_idx, slot_next, fr.seed_hash);
-          const f3 wi = bsdf.sample(wo, u1, u2, f, pdf);
-          const f3 wd = to_world(wi, tangent, ns, bitangent);
-          T *= f * abs_cos(wi) / pdf;
-          const bool transmitted = dot(wd, ng) < 0;
-          const f3 no = offset_origin(x, transmitted ? -ng : ng);
-          if (!bad3(T) && depth + 1u < fr.max_depth) {
-            const float prr = clampf(lum(T), 0.0f, 1.0f);
-            const float u = sobol_draw(rows.m[3], sidx, dim_rr, fr.seed_hash);
-            if (!(u >= prr)) {
-              T = T / prr;
-              cont = true;
-              pool.ray_o[p] = mk4(no, 1e9f);
-              pool.ray_d[p] = mk4(wd, 0.0f);
-              pool.thr[p] = mk4(T, 0.0f);
-            }
-          }
-        }
+        store_secondary(pool, SEC_LIGHT, p, o.sec[SEC_LIGHT].o, o.sec[SEC_LIGHT].tmax, o.sec[SEC_LIGHT].d, o.sec[SEC_LIGHT].active, o.sec[SEC_LIGHT].c);
+      }
+      if (cont) {
+        pool.ray_o[p] = mk4(o.next_o, 1e9f);
+        pool.ray_d[p] = mk4(o.next_d, 0.0f);
+        pool.thr[p] = mk4(o.T, 0.0f);
       }
     }
     queue_push(&cnt[CNT_SEC], pool.q_sec, shaded, p);
@@ -458,11 +523,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev sc, FrameDev fr, Pool
 // ------------------------------------------------------------------------------------------------
 // Finish the BSDF-sampled light ray of a scene with emitters once its closest hit is known
 // (pt.cu:952-999 closest-hit light, :531-543 miss light, :910-924 MIS weight).
-FH_D f3 resolve_light_ray(const SceneDev& sc, const FrameDev& fr, const PoolDev& pool, uint32_t p, f3 ro, f3 ld, bool hit, const HitRec& h)
+FH_D f3 resolve_light_ray(const SceneDev& sc, const FrameDev& fr, f3 T, float cosw, f3 f, float pdf, f3 ro, f3 ld, bool hit, const HitRec& h)
 {
-  const float4 a = pool.lp_a[p], b = pool.lp_b[p];
-  const f3 T = mk3(a), f = mk3(b);
-  const float cosw = a.w, pdf = b.w;
   f3 le = mk3(0.0f);
   float pdf_light = cosw / kPi;
   bool add = false;
@@ -516,9 +578,11 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
       if (COUNT) nr++;
       if (slot == SEC_LIGHT && has_lights) {
         const bool hit = traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
-        L += resolve_light_ray(sc, fr, pool, p, mk3(o), mk3(d), hit, h);
+        const float4 la = pool.lp_a[p], lb = pool.lp_b[p];
+        L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, mk3(o), mk3(d), hit, h);
       } else {
         bool occluded;
+        const uint32_t nn0 = nn;
         if (sc.use_bvh8 == 2u) {
           Trav8 tr;
           tr.init(mk3(o), mk3(d), o.w);
@@ -527,6 +591,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
         } else {
           occluded = traverse<true, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
         }
+        if (COUNT) { const uint32_t kk = nn - nn0; int b = 0; while (b < 7 && kk > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
         if (!occluded) L += mk3(pool.sec_c[k]);
       }
     }
@@ -594,7 +659,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDe
           const bool done = closest ? tr.template step<false, COUNT>(sc.bvh8, nn, nt) : tr.template step<true, COUNT>(sc.bvh8, nn, nt);
           if (done) {
             const size_t k = (size_t)slot * pool.capacity + p;
-            if (closest) L += resolve_light_ray(sc, fr, pool, p, tr.rp.o, mk3(pool.sec_d[k]), tr.found, tr.best);
+            if (closest) { const float4 la = pool.lp_a[p], lb = pool.lp_b[p]; L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, tr.rp.o, mk3(pool.sec_d[k]), tr.found, tr.best); }
             else if (!tr.found) L += mk3(pool.sec_c[k]);
             tracing = false;
             ++slot;
@@ -608,6 +673,69 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDe
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
     atomicAdd(tc.rays, (unsigned long long)nr);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail: after the first bounces only a few thousand of the millions of paths of a pass are still alive,
+// and a bounce-synchronous wavefront then costs one worst-case ray latency per kernel and bounce.
+// k_tail finishes those paths in one launch: each lane carries its path through all remaining bounces
+// (trace -> shade -> secondary rays -> Russian roulette), so slow rays of different paths overlap
+// instead of adding up.  Same device functions, same per-path operation order as the wavefront
+// kernels, hence the same bits.
+__global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth)
+{
+  __shared__ SobolRows rows;
+  const uint32_t count = pool.counters[first_depth * kCounterStride + CNT_RAD];
+  const uint32_t* q = pool.q_rad[first_depth & 1u];
+  const bool has_lights = sc.n_lights > 0;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+    const uint32_t i = base + threadIdx.x;
+    bool alive = i < count;
+    uint32_t p = 0, image_idx = 0, n_spp = 0;
+    f3 ro = mk3(0.0f), rd = mk3(0.0f), T = mk3(0.0f), L = mk3(0.0f);
+    if (alive) {
+      p = q[i];
+      const float4 o = pool.ray_o[p];
+      ro = mk3(o); rd = mk3(pool.ray_d[p]); T = mk3(pool.thr[p]); L = mk3(pool.rad[p]);
+      image_idx = pool.pixel[p]; n_spp = pool.nspp[p];
+    }
+    for (uint32_t depth = first_depth; depth < fr.max_depth; ++depth) {
+      BounceSlots bs;
+      bs.set(fr, sc.n_lights, depth);
+      __syncthreads();  // rows of the previous bounce are no longer read
+      bs.load_rows(rows, fr.sobol);
+      if (alive) {
+        HitRec h;
+        uint32_t a = 0, b = 0;
+        const bool hit = traverse<false, false>(sc, ro, rd, 1e9f, h, a, b);
+        if (!hit) {
+          alive = false;  // pt.cu:504-523 with firsthit == false: nothing added
+        } else {
+          ShadeOut o;
+          shade_hit<L_ALL>(sc, fr, rows, bs, depth, make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)), rd, T, L, image_idx, n_spp, o);
+          // secondary rays in the reference's order
+#pragma unroll
+          for (uint32_t slot = SEC_DIR; slot <= SEC_LIGHT; ++slot) {
+            if (slot == SEC_DIR && !fr.has_dir) continue;
+            if (slot == SEC_AREA && !has_lights) continue;
+            if (!o.sec[slot].active) continue;
+            HitRec sh;
+            if (slot == SEC_LIGHT && has_lights) {
+              const bool lhit = traverse<false, false>(sc, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh, a, b);
+              L += resolve_light_ray(sc, fr, o.lp_T, o.lp_cos, o.lp_f, o.lp_pdf, o.sec[slot].o, o.sec[slot].d, lhit, sh);
+            } else {
+              const bool occluded = traverse<true, false>(sc, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh, a, b);
+              if (!occluded) L += o.sec[slot].c;
+            }
+          }
+          if (o.cont) { ro = o.next_o; rd = o.next_d; T = o.T; }
+          else alive = false;
+        }
+      }
+    }
+    if (i < count) pool.rad[p] = mk4(L, 0.0f);
   }
 }
 
@@ -655,7 +783,12 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(PoolDev pool, LayersDev l
   }
 }
 
-uint32_t grid_for(uint32_t n) { const uint32_t b = (n + kBlock - 1) / kBlock; return b < 1 ? 1 : (b > 8192 ? 8192 : b); }
+uint32_t grid_for(uint32_t n)  // multiple of 8 (one share per XCD), at most 8192 blocks, grid-stride beyond
+{
+  uint32_t b = (n + kBlock - 1) / kBlock;
+  b = (b + 7u) & ~7u;
+  return b < 8 ? 8 : (b > 8192 ? 8192 : b);
+}
 
 template <uint32_t LOBES>
 void launch_shade(hipStream_t st, uint32_t grid, const SceneDev& sc, const FrameDev& fr, const PoolDev& pool, uint32_t cls, uint32_t depth)
@@ -792,8 +925,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const SceneDev sc = scene_dev(ctx);
   const PoolDev& pool = ctx->pool;
   const bool count = (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) != 0;
-  TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2, ctx->d_trace_counters + 6, ctx->d_trace_counters + 7};
-  TraceCounters tc_shadow{ctx->d_trace_counters + 3, ctx->d_trace_counters + 4, ctx->d_trace_counters + 5, ctx->d_trace_counters + 8, ctx->d_trace_counters + 9};
+  TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2, ctx->d_trace_counters + 6, ctx->d_trace_counters + 7, ctx->d_trace_counters + 10};
+  TraceCounters tc_shadow{ctx->d_trace_counters + 3, ctx->d_trace_counters + 4, ctx->d_trace_counters + 5, ctx->d_trace_counters + 8, ctx->d_trace_counters + 9, ctx->d_trace_counters + 18};
 
   if (!ctx->render_pending) { (void)hipEventRecord(ctx->ev_render_begin, st); ctx->render_pending = true; }
 
@@ -810,7 +943,22 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
     hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, fr, pool, L, ctx->d_owned, ctx->n_owned, n_paths);
     ctx->stats.paths += n_paths;
-    for (uint32_t depth = 0; depth < max_depth; ++depth) {
+    // bounces run as bounce-synchronous wavefront kernels; the survivors are finished by k_tail.  Adaptive mode picks the
+    // first depth at which an earlier pass had at most kTailPaths survivors (counts come from an asynchronous snapshot of
+    // the device counters: no host/device synchronisation)
+    constexpr uint32_t kTailPaths = 65536;
+    if (ctx->counters_in_flight && hipEventQuery(ctx->ev_counters) == hipSuccess) {
+      ctx->counters_in_flight = false;
+      const uint32_t wd = ctx->counters_wave_depth;
+      uint32_t pick = wd + 1u;  // too many survivors at the old switch depth: go one bounce deeper
+      for (uint32_t d = 1; d <= wd; ++d)
+        if (ctx->h_counters[d * kCounterStride + CNT_RAD] <= kTailPaths) { pick = d; break; }
+      ctx->auto_wave_depth = pick;
+    }
+    uint32_t wave_depth = ctx->tail_depth ? ctx->tail_depth : ctx->auto_wave_depth;
+    if (wave_depth < 1u) wave_depth = 1u;
+    if (wave_depth > max_depth) wave_depth = max_depth;
+    for (uint32_t depth = 0; depth < wave_depth; ++depth) {
       {
         Span sp(ctx, 0);
         if (wide) {
@@ -826,7 +974,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         Span sp(ctx, 2);
         hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, ctx->n_classes);
         for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pool, c, depth);
-        if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pool, n_paths);
+        if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pool);
       }
       {
         Span sp(ctx, 1);
@@ -843,7 +991,17 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         ctx->stats.n_shadow_launches++;
       }
     }
+    if (wave_depth < max_depth) {
+      Span sp(ctx, 3);
+      hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), 0, st, sc, fr, pool, wave_depth);
+    }
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb);
+    if (!ctx->counters_in_flight && ctx->h_counters) {
+      FH_HIP(hipMemcpyAsync(ctx->h_counters, pool.counters, sizeof(uint32_t) * kCounterStride * (max_depth + 1), hipMemcpyDeviceToHost, st));
+      FH_HIP(hipEventRecord(ctx->ev_counters, st));
+      ctx->counters_in_flight = true;
+      ctx->counters_wave_depth = wave_depth;
+    }
   }
   FH_HIP(hipGetLastError());
   return FH_OK;

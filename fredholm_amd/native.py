@@ -76,10 +76,10 @@ class StatsC(C.Structure):
                 ("paths", C.c_uint64), ("bvh_build_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_node_bytes", C.c_uint64),
                 ("bvh_tri_bytes", C.c_uint64),
                 ("wave_node_steps_closest", C.c_uint64), ("wave_tri_steps_closest", C.c_uint64), ("wave_node_steps_shadow", C.c_uint64),
-                ("wave_tri_steps_shadow", C.c_uint64)]
+                ("wave_tri_steps_shadow", C.c_uint64), ("hist_nodes_closest", C.c_uint64 * 8), ("hist_nodes_shadow", C.c_uint64 * 8), ("tail_ms", C.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}
 
 
 class FredholmError(RuntimeError):
@@ -88,7 +88,7 @@ class FredholmError(RuntimeError):
 
 # every symbol include/fredholm_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "fh_ctx_create", "fh_ctx_destroy", "fh_last_error", "fh_set_flags", "fh_set_path_pool", "fh_scene_upload", "fh_bvh_build", "fh_set_transforms",
+    "fh_ctx_create", "fh_ctx_destroy", "fh_last_error", "fh_set_flags", "fh_set_path_pool", "fh_set_tail_depth", "fh_scene_upload", "fh_bvh_build", "fh_set_transforms",
     "fh_scene_n_lights", "fh_set_directional_light", "fh_clear_directional_light", "fh_set_sky_intensity", "fh_load_arhosek_sky",
     "fh_clear_arhosek_sky", "fh_load_ibl", "fh_set_resolution", "fh_init_render_states", "fh_set_tile_shard", "fh_owned_pixel_count",
     "fh_pack_owned", "fh_unpack_shard", "fh_render", "fh_sync", "fh_get_stats", "fh_reset_stats", "fh_post_process", "fh_malloc",

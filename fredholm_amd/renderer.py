@@ -187,6 +187,9 @@ class Renderer:
     def set_path_pool(self, target_paths):
         self._ck(N.lib().fh_set_path_pool(self._ctx, C.c_uint32(target_paths)), "fh_set_path_pool")
 
+    def set_tail_depth(self, depth):
+        self._ck(N.lib().fh_set_tail_depth(self._ctx, C.c_uint32(depth)), "fh_set_tail_depth")
+
     # -- scene (renderer.h:354-432)
     def load_scene(self, scene, clear=True):
         """scene: a .obj path (renderer.h:354: load_scene(filepath, clear)) or a dict of flat arrays as produced by

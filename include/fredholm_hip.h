@@ -100,6 +100,9 @@ typedef struct fh_stats {
   /* instrumented build only: wave-level executions of the node test / triangle test (SIMD efficiency =
    * nodes_* / (64 * wave_node_steps_*), likewise for triangles) */
   uint64_t wave_node_steps_closest, wave_tri_steps_closest, wave_node_steps_shadow, wave_tri_steps_shadow;
+  /* instrumented build only: rays by number of node visits: <= 8, 16, 32, 64, 128, 256, 512, more */
+  uint64_t hist_nodes_closest[8], hist_nodes_shadow[8];
+  double tail_ms; /* summed HIP-event time of the k_tail launches */
 } fh_stats;
 
 #define FH_FLAG_TIME_KERNELS 1u    /* bracket traversal/shade launches with HIP events (fh_stats *_ms) */
@@ -111,8 +114,12 @@ int fh_ctx_destroy(fh_ctx* ctx);
 const char* fh_last_error(fh_ctx* ctx); /* ctx may be NULL for creation errors */
 int fh_set_flags(fh_ctx* ctx, uint32_t flags);
 /* target number of camera paths in flight per pass (path-pool slots); a pass starts floor(target / owned pixels) >= 1
- * samples per pixel.  Results do not depend on it.  Default 4 Mi paths. */
+ * samples per pixel.  Results do not depend on it.  Default 32 Mi paths (12.5 GB of pool). */
 int fh_set_path_pool(fh_ctx* ctx, uint32_t target_paths);
+/* number of bounces run as bounce-synchronous wavefront kernels before the surviving paths are finished by one
+ * fused launch (k_tail).  Results do not depend on it.  0 (default) = adaptive: the depth at which fewer than 64 Ki
+ * paths survived in earlier passes; a value >= max_depth disables the fused tail. */
+int fh_set_tail_depth(fh_ctx* ctx, uint32_t depth);
 
 /* -- scene: Renderer::load_scene upload + AreaLight extraction (renderer.h:354-432) */
 int fh_scene_upload(fh_ctx* ctx, const fh_scene_desc* scene);

@@ -347,6 +347,30 @@ def test_small_path_pool_and_batching_do_not_change_results(oracle):
     _assert_image_parity(a["beauty"], ref["beauty"])
 
 
+def test_fused_tail_depth_does_not_change_results(oracle):
+    sc = scenes.cornell_box()
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    imgs = []
+    for tail in (0, 1, 2, 3, 100):  # 0 = adaptive
+        r = F.Renderer(0)
+        r.set_tail_depth(tail)
+        r.load_scene(sc)
+        r.build_ias()
+        r.set_resolution(64, 48)
+        L = F.RenderLayer(r, 64, 48)
+        r.render(cam, (0.1, 0.2, 0.3), L, 3, 6)
+        r.wait_for_completion()
+        imgs.append(L.download("beauty"))
+        r.close()
+    for im in imgs[1:]:
+        assert np.array_equal(_bits(imgs[0]), _bits(im))
+    S = oracle.Scene(sc)
+    Lo = S.new_layers(64, 48)
+    for _ in range(3):
+        S.render(cam.params(), 64, 48, Lo, 1, 6, bg=(0.1, 0.2, 0.3), n_threads=8)
+    _assert_image_parity(imgs[0], Lo["beauty"])
+
+
 def test_transforms_and_instances(oracle):
     sc = scenes.cornell_box()
     nf = sc["indices"].shape[0]
