@@ -3,8 +3,8 @@
 
 Workload (BASELINE.json configs[2], the configuration the metric and target are quoted on):
 1,000,000-triangle synthetic soup, Hosek sky, 1920x1080, max_depth 8, seed 1.
-One step = one fh_render of `--spp` samples per pixel of that frame (default 16, the reference's
-rtcamp8 launch size) with every input resident in HBM, plus -- for N > 1 -- the RCCL all_gather of the
+One step = one fh_render of `--spp` samples per pixel of that frame (default 64 = 1/16 of the configuration's
+1024 spp; the path pool is sized so that a step is one pass: 133 M path slots, 50 GB, at N = 1) with every input resident in HBM, plus -- for N > 1 -- the RCCL all_gather of the
 packed beauty tiles to every rank.  For N > 1 the frame is sharded by interleaved 32x32 pixel tiles
 (one process per GPU), so total work is fixed: strong scaling.
 
@@ -58,9 +58,10 @@ def cpu_baseline(scene_dict, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step")
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per step (one fh_render call)")
+    ap.add_argument("--pool-spp", type=int, default=64, help="size the path pool for this many samples per pixel per pass (0 = library default, 32 Mi paths)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-frame", action="store_true", help="N > 1: rank 0 re-renders the whole frame unsharded and compares it bit for bit with the gathered one")
     args = ap.parse_args()
@@ -105,6 +106,8 @@ def main():
     r.set_resolution(WIDTH, HEIGHT)
     if world > 1:
         r.set_tile_shard(rank, world, 32, 32)
+    if args.pool_spp > 0:  # path-pool slots = owned pixels x pool_spp (372 B per slot): one pass per step when pool_spp >= spp
+        r.set_path_pool(min(r.owned_pixel_count() * args.pool_spp, 160 * 1024 * 1024))
     cam = F.Camera(**scenes.SOUP_CAMERA)
     dev = torch.device("cuda", local_rank)
     bufs = {n: torch.zeros((HEIGHT, WIDTH) if n == "depth" else (HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev) for n in F.RenderLayer.NAMES}

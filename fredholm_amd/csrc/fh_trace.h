@@ -215,15 +215,49 @@ FH_D Ray8 ray8_prepare(const RayPre& rp, f3 d)
 struct WaveSteps { uint32_t node = 0, tri = 0; };
 FH_D bool first_active_lane() { return __lane_id() == (uint32_t)__ffsll((long long)__ballot(true)) - 1u; }
 
-template <bool ANY_HIT, bool COUNT>
-FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr)
+// Traversal stack of node groups: the first kLdsStack entries of every lane live in LDS (column layout
+// [entry][thread], conflict-free), deeper entries in the lane's private (scratch) array.  A wide tree of a
+// million triangles is ~8 levels deep and each level leaves at most one pending group, so the spill part is cold.
+constexpr int kLdsStack = 8;
+template <bool LDS>
+struct GroupStack;
+template <>
+struct GroupStack<false> {  // all entries in the lane's private (scratch) array
+  int sp = 0;
+  uint2 spill[kBvh8Stack];
+  FH_D GroupStack(uint2*, int) {}
+  FH_D void push(uint2 g) { if (sp < kBvh8Stack) spill[sp++] = g; }
+  FH_D uint2 pop() { return spill[--sp]; }
+};
+template <>
+struct GroupStack<true> {  // first kLdsStack entries in LDS (column [entry][thread]), the rest in scratch
+  uint2* lds;
+  int stride;
+  int sp = 0;
+  uint2 spill[kBvh8Stack];
+  FH_D GroupStack(uint2* lds_column, int lds_stride) : lds(lds_column), stride(lds_stride) {}
+  FH_D void push(uint2 g)
+  {
+    if (sp < kLdsStack) lds[sp * stride] = g;
+    else if (sp < kBvh8Stack + kLdsStack) spill[sp - kLdsStack] = g;
+    ++sp;
+  }
+  FH_D uint2 pop()
+  {
+    --sp;
+    return sp < kLdsStack ? lds[sp * stride] : spill[sp - kLdsStack];
+  }
+};
+
+template <bool ANY_HIT, bool COUNT, bool LDS = false>
+FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr, uint2* lds_column = nullptr,
+                        int lds_stride = 0)
 {
   best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu;
   if (bvh.n_nodes == 0) return false;
   const RayPre rp = ray_prepare(o, d);
   const Ray8 r = ray8_prepare(rp, d);
-  uint2 stack[kBvh8Stack];
-  int sp = 0;
+  GroupStack<LDS> stack(lds_column, lds_stride);
   uint2 group = make_uint2(0u, 0x80000000u);
   bool found = false;
   for (;;) {
@@ -232,7 +266,7 @@ FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
       const uint32_t hits_imask = group.y;
       const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
       group.y &= ~(1u << bit);
-      if ((group.y & 0xff000000u) && sp < kBvh8Stack) stack[sp++] = group;
+      if (group.y & 0xff000000u) stack.push(group);
       const uint32_t slot = (bit - 24u) ^ (r.oct4 & 7u);
       const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
       const uint32_t ni = group.x + rel;
@@ -262,8 +296,8 @@ FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
       if (ANY_HIT) return true;
     }
     if ((group.y & 0xff000000u) == 0u) {
-      if (sp == 0) break;
-      group = stack[--sp];
+      if (stack.sp == 0) break;
+      group = stack.pop();
     }
   }
   return found;
@@ -381,7 +415,7 @@ struct WaveFeeder {
 template <bool ANY_HIT, bool COUNT>
 FH_D bool traverse(const SceneDev& sc, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr)
 {
-  if (sc.use_bvh8) return traverse_bvh8<ANY_HIT, COUNT>(sc.bvh8, o, d, tmax, best, n_nodes, n_tris, ws);
+  if (sc.use_bvh8) return traverse_bvh8<ANY_HIT, COUNT, false>(sc.bvh8, o, d, tmax, best, n_nodes, n_tris, ws);
   return traverse_bvh2<ANY_HIT, COUNT>(sc.bvh2, o, d, tmax, best, n_nodes, n_tris);
 }
 

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
 
 // ------------------------------------------------------------------------------------------------
 // closest hit: one lane per ray, grid-stride over the queue (binary-BVH fallback shares this kernel)
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc)
 {
   const uint32_t* cnt = pool.counters + depth * kCounterStride;
@@ -135,14 +135,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, Po
     const float4 o = pool.ray_o[p], d = pool.ray_d[p];
     HitRec h;
     const uint32_t nn0 = nn;
-    if (sc.use_bvh8 == 2u) {
-      Trav8 tr;
-      tr.init(mk3(o), mk3(d), o.w);
-      while (!tr.template step<false, COUNT>(sc.bvh8, nn, nt)) {}
-      h = tr.best;
-    } else {
-      traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
-    }
+    if (WIDE) traverse_bvh8<false, COUNT, false>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
+    else traverse_bvh2<false, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
     if (COUNT) { const uint32_t k = nn - nn0; int b = 0; while (b < 7 && k > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
     pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
   }
@@ -556,11 +550,12 @@ FH_D f3 resolve_light_ray(const SceneDev& sc, const FrameDev& fr, f3 T, float co
 }
 
 // secondary rays, binary-BVH fallback: one thread per shaded path, its rays in the reference's order
-template <bool COUNT>
+template <bool COUNT, bool WIDE, bool LIGHTS>
 __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc)
 {
+  __shared__ uint2 lds_stack[kLdsStack * kBlock];
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
-  const bool has_lights = sc.n_lights > 0;
+  constexpr bool has_lights = LIGHTS;
   uint32_t nn = 0, nt = 0, nr = 0;
   WaveSteps ws;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -577,20 +572,14 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
       HitRec h;
       if (COUNT) nr++;
       if (slot == SEC_LIGHT && has_lights) {
-        const bool hit = traverse<false, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
+        const bool hit = WIDE ? traverse_bvh8<false, COUNT, true>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack + threadIdx.x, kBlock)
+                              : traverse_bvh2<false, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
         const float4 la = pool.lp_a[p], lb = pool.lp_b[p];
         L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, mk3(o), mk3(d), hit, h);
       } else {
-        bool occluded;
         const uint32_t nn0 = nn;
-        if (sc.use_bvh8 == 2u) {
-          Trav8 tr;
-          tr.init(mk3(o), mk3(d), o.w);
-          while (!tr.template step<true, COUNT>(sc.bvh8, nn, nt)) {}
-          occluded = tr.found;
-        } else {
-          occluded = traverse<true, COUNT>(sc, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
-        }
+        const bool occluded = WIDE ? traverse_bvh8<true, COUNT, true>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack + threadIdx.x, kBlock)
+                                   : traverse_bvh2<true, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
         if (COUNT) { const uint32_t kk = nn - nn0; int b = 0; while (b < 7 && kk > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
         if (!occluded) L += mk3(pool.sec_c[k]);
       }
@@ -845,7 +834,7 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.bvh8.tris = ctx->d_bvh8_tris;
   s.bvh8.n_nodes = ctx->bvh8_n_nodes;
   s.bvh8.n_tris = ctx->bvh8_n_tris;
-  s.use_bvh8 = ctx->use_bvh8 ? (getenv("FH_STEP") ? 2u : 1u) : 0u;
+  s.use_bvh8 = ctx->use_bvh8 ? 1u : 0u;
   return s;
 }
 
@@ -965,8 +954,11 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
           if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
           else hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
         } else {
-          if (count) hipLaunchKernelGGL(k_trace_closest_static<true>, dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
-          else hipLaunchKernelGGL(k_trace_closest_static<false>, dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+          const bool w8 = sc.use_bvh8 != 0;
+          if (count && w8) hipLaunchKernelGGL((k_trace_closest_static<true, true>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+          else if (count) hipLaunchKernelGGL((k_trace_closest_static<true, false>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+          else if (w8) hipLaunchKernelGGL((k_trace_closest_static<false, true>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+          else hipLaunchKernelGGL((k_trace_closest_static<false, false>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
         }
         ctx->stats.n_closest_launches++;
       }
@@ -985,8 +977,11 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
           else if (lights) hipLaunchKernelGGL((k_trace_secondary<false, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
           else hipLaunchKernelGGL((k_trace_secondary<false, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
         } else {
-          if (count) hipLaunchKernelGGL(k_trace_secondary_static<true>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
-          else hipLaunchKernelGGL(k_trace_secondary_static<false>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
+          const bool w8 = sc.use_bvh8 != 0, lights = sc.n_lights > 0;
+#define FH_LAUNCH_SEC(C, W, Li) hipLaunchKernelGGL((k_trace_secondary_static<C, W, Li>), dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow)
+          if (count) { if (w8) { if (lights) FH_LAUNCH_SEC(true, true, true); else FH_LAUNCH_SEC(true, true, false); } else { if (lights) FH_LAUNCH_SEC(true, false, true); else FH_LAUNCH_SEC(true, false, false); } }
+          else { if (w8) { if (lights) FH_LAUNCH_SEC(false, true, true); else FH_LAUNCH_SEC(false, true, false); } else { if (lights) FH_LAUNCH_SEC(false, false, true); else FH_LAUNCH_SEC(false, false, false); } }
+#undef FH_LAUNCH_SEC
         }
         ctx->stats.n_shadow_launches++;
       }

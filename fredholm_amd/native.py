@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfredholm_hip.so")
+LIB_PATH = os.environ.get("FH_LIB") or os.path.join(_HERE, "libfredholm_hip.so")  # FH_LIB: developer override for A/B runs
 
 FH_OK = 0
 FLAG_TIME_KERNELS = 1
