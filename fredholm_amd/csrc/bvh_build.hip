@@ -210,14 +210,14 @@ __global__ void k_emit2_tiny(int n, const float4* face_lo, const float4* face_hi
   out[3] = make_float4(__int_as_float(ra), __int_as_float(ra), 0.0f, 0.0f);
 }
 
-__global__ void k_emit_tris(const float4* face_rec, const uint32_t* sorted_face, uint32_t n, float4* tris)
+__global__ void k_emit_tris(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, uint32_t n, float4* tris)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t f = sorted_face[i];
   const float4 a = face_rec[7 * f], b = face_rec[7 * f + 1], c = face_rec[7 * f + 2];
   tris[3 * i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
-  tris[3 * i + 1] = make_float4(b.x, b.y, b.z, 0.0f);
+  tris[3 * i + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);  // .w != 0: candidate hits need the alpha test
   tris[3 * i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
 }
 
@@ -380,14 +380,14 @@ __global__ void k_collapse8_tiny(int n, const float4* face_lo, const float4* fac
   nodes[4] = make_uint4(0xffu, 0u, 0xffu, 0u);
 }
 
-__global__ void k_emit_tris8(const float4* face_rec, const uint32_t* sorted_face, const uint32_t* tri_map, uint32_t n, float4* tris)
+__global__ void k_emit_tris8(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, const uint32_t* tri_map, uint32_t n, float4* tris)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t f = sorted_face[tri_map[i]];
   const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
   tris[3 * (size_t)i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
-  tris[3 * (size_t)i + 1] = make_float4(b.x, b.y, b.z, 0.0f);
+  tris[3 * (size_t)i + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);
   tris[3 * (size_t)i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
 }
 
@@ -444,7 +444,7 @@ int bvh_build_device(fh_ctx* ctx)
     for (uint32_t i = 0; i < n; ++i) ident[i] = i;
     FH_HIP(hipMemcpyAsync(vals_a.p, ident.data(), 4ull * n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_emit2_tiny, dim3(1), dim3(1), 0, st, (int)n, face_lo.p, face_hi.p, pad, ctx->d_bvh2_nodes);
-    hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, vals_a.p, n, ctx->d_bvh2_tris);
+    hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, n, ctx->d_bvh2_tris);
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh2_n_nodes = 1;
     if (n <= kLeafMax8) {
@@ -453,7 +453,7 @@ int bvh_build_device(fh_ctx* ctx)
       FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * 5));
       FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n));
       hipLaunchKernelGGL(k_collapse8_tiny, dim3(1), dim3(1), 0, st, (int)n, face_lo.p, face_hi.p, pad, ctx->d_bvh8_nodes, tri_map.p);
-      hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, vals_a.p, tri_map.p, n, ctx->d_bvh8_tris);
+      hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, tri_map.p, n, ctx->d_bvh8_tris);
       FH_HIP(hipStreamSynchronize(st));
       ctx->bvh8_n_nodes = 1;
       ctx->bvh8_n_tris = n;
@@ -478,7 +478,7 @@ int bvh_build_device(fh_ctx* ctx)
                        leaf_hi.p, arrive.p);
     FH_HIP(hipMalloc((void**)&ctx->d_bvh2_nodes, sizeof(float4) * 4ull * n_inner));
     hipLaunchKernelGGL(k_emit2, dim3(iblocks), dim3(256), 0, st, (int)n_inner, children.p, ranges.p, node_lo.p, node_hi.p, leaf_lo.p, leaf_hi.p, pad, ctx->d_bvh2_nodes);
-    hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, vals_b.p, n, ctx->d_bvh2_tris);
+    hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, n, ctx->d_bvh2_tris);
     FH_HIP(hipGetLastError());
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh2_n_nodes = n_inner;
@@ -510,7 +510,7 @@ int bvh_build_device(fh_ctx* ctx)
     FH_HIP(hipMemcpyAsync(final_counters, counters.p, 8, hipMemcpyDeviceToHost, st));
     FH_HIP(hipStreamSynchronize(st));
     if (final_counters[1] != n) return fail(ctx, FH_E_INVALID, "BVH8 collapse lost triangles");
-    hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, vals_b.p, tri_map.p, n, ctx->d_bvh8_tris);
+    hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_map.p, n, ctx->d_bvh8_tris);
     FH_HIP(hipGetLastError());
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh8_n_nodes = final_counters[0];

@@ -45,6 +45,8 @@ bool material_textured(const fh_material& m)
 // layering multiplier of every lobe after the metal one, so those lobes are dropped exactly.
 uint32_t material_lobes(const fh_material& m)
 {
+  // a texture on a parameter that switches lobes on or off makes the mask unknowable on the host: take every lobe
+  if (m.metalness_texture_id >= 0 || m.metallic_roughness_texture_id >= 0 || m.coat_texture_id >= 0 || m.specular_color_texture_id >= 0) return L_ALL;
   uint32_t l = 0;
   const float coat = clampf(m.coat, 0.0f, 1.0f);
   if (coat > 0.0f) l |= L_COAT;
@@ -76,6 +78,7 @@ int rebuild_device_scene(fh_ctx* ctx)
     const uint32_t lobes = material_lobes(ctx->h_materials[i]);
     mats[i].lobes = lobes;
     mats[i].emissive = material_emissive(ctx->h_materials[i]) ? 1u : 0u;
+    mats[i].alpha = (ctx->h_materials[i].base_color_texture_id >= 0 || ctx->h_materials[i].alpha_texture_id >= 0) ? 1u : 0u;
     uint32_t c = 0;
     for (; c < ctx->n_classes; ++c)
       if (ctx->class_lobes[c] == lobes) break;
@@ -92,6 +95,7 @@ int rebuild_device_scene(fh_ctx* ctx)
   std::vector<float4> rec(7ull * nf);
   std::vector<uint8_t> cls(nf);
   std::vector<AreaLightDev> lights;
+  bool any_alpha = false;
   for (uint32_t f = 0; f < nf; ++f) {
     const uint32_t inst = ctx->h_instance_ids.empty() ? 0u : ctx->h_instance_ids[f];
     if (inst >= ni) return fail(ctx, FH_E_INVALID, "instance id out of range");
@@ -116,7 +120,8 @@ int rebuild_device_scene(fh_ctx* ctx)
     std::memcpy(&a, &midbits, 4);
     std::memcpy(&b, &instbits, 4);
     r[6] = make_float4(a, b, 0.0f, 0.0f);
-    cls[f] = (uint8_t)(mats[mid].cls | (mats[mid].emissive ? 0x80u : 0u));
+    cls[f] = (uint8_t)(mats[mid].cls | (mats[mid].emissive ? 0x80u : 0u) | (mats[mid].alpha ? 0x40u : 0u));
+    if (mats[mid].alpha) any_alpha = true;
     if (mats[mid].emissive) lights.push_back({f, mid});  // renderer.h:388-402, face order
   }
   auto re_alloc = [&](auto*& ptr, size_t bytes) -> hipError_t {
@@ -134,7 +139,40 @@ int rebuild_device_scene(fh_ctx* ctx)
   ctx->n_faces = nf;
   ctx->n_lights = (uint32_t)lights.size();
   ctx->n_materials = nm;
+  ctx->has_alpha = any_alpha;
   ctx->bvh_valid = false;
+  return FH_OK;
+}
+
+// texels of all textures in one device blob + descriptors + the 256-entry sRGB table (cwl/texture.h:13-75 per texture)
+int upload_textures(fh_ctx* ctx, uint32_t n, const fh_texture_desc* descs)
+{
+  if (ctx->d_texels) { (void)hipFree(ctx->d_texels); ctx->d_texels = nullptr; }
+  if (ctx->d_textures) { (void)hipFree(ctx->d_textures); ctx->d_textures = nullptr; }
+  ctx->n_textures = n;
+  if (!ctx->d_srgb_lut) {
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = fht_srgb_to_linear((float)i * (1.0f / 255.0f));
+    FH_HIP(hipMalloc((void**)&ctx->d_srgb_lut, sizeof lut));
+    FH_HIP(hipMemcpy(ctx->d_srgb_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+  }
+  if (n == 0) return FH_OK;
+  size_t total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!descs[i].rgba8 || descs[i].width == 0 || descs[i].height == 0) return fail(ctx, FH_E_INVALID, "fh_scene_upload: empty texture");
+    total += (size_t)descs[i].width * descs[i].height * 4;
+  }
+  FH_HIP(hipMalloc((void**)&ctx->d_texels, total));
+  std::vector<fht_texture> t(n);
+  size_t off = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const size_t bytes = (size_t)descs[i].width * descs[i].height * 4;
+    FH_HIP(hipMemcpy(ctx->d_texels + off, descs[i].rgba8, bytes, hipMemcpyHostToDevice));
+    t[i] = fht_texture{ctx->d_texels + off, nullptr, descs[i].width, descs[i].height, descs[i].srgb ? 1u : 0u};
+    off += bytes;
+  }
+  FH_HIP(hipMalloc((void**)&ctx->d_textures, n * sizeof(fht_texture)));
+  FH_HIP(hipMemcpy(ctx->d_textures, t.data(), n * sizeof(fht_texture), hipMemcpyHostToDevice));
   return FH_OK;
 }
 
@@ -213,7 +251,7 @@ int fh_ctx_destroy(fh_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   pool_release(ctx);
   void* ptrs[] = {ctx->d_sobol, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
-                  ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters};
+                  ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -258,8 +296,18 @@ int fh_scene_upload(fh_ctx* ctx, const fh_scene_desc* s)
   CTX_CHECK(ctx);
   if (!s || !s->vertices || !s->normals || !s->texcoords || !s->indices || !s->material_ids || !s->materials || s->n_materials == 0)
     return fail(ctx, FH_E_INVALID, "fh_scene_upload: missing arrays");
-  for (uint32_t i = 0; i < s->n_materials; ++i)
-    if (material_textured(s->materials[i])) return fail(ctx, FH_E_UNSUPPORTED, "fh_scene_upload: textured materials are not supported in this build (all *_texture_id must be -1)");
+  for (uint32_t i = 0; i < s->n_materials; ++i) {
+    const fh_material& m = s->materials[i];
+    const int32_t ids[11] = {m.base_color_texture_id, m.specular_color_texture_id, m.specular_roughness_texture_id, m.metalness_texture_id, m.metallic_roughness_texture_id, m.coat_texture_id,
+                             m.coat_roughness_texture_id, m.emission_texture_id, m.heightmap_texture_id, m.normalmap_texture_id, m.alpha_texture_id};
+    for (int32_t id : ids)
+      if (id < -1 || id >= (int32_t)s->n_textures) return fail(ctx, FH_E_INVALID, "fh_scene_upload: material references a texture id outside [0, n_textures)");
+  }
+  if (s->n_textures && !s->textures) return fail(ctx, FH_E_INVALID, "fh_scene_upload: n_textures > 0 but textures == NULL");
+  {
+    const int rc = upload_textures(ctx, s->n_textures, s->textures);
+    if (rc) return rc;
+  }
   ctx->h_vertices.assign(s->vertices, s->vertices + 3ull * s->n_vertices);
   ctx->h_normals.assign(s->normals, s->normals + 3ull * s->n_vertices);
   ctx->h_texcoords.assign(s->texcoords, s->texcoords + 2ull * s->n_vertices);
@@ -345,7 +393,25 @@ int fh_clear_arhosek_sky(fh_ctx* ctx)
   ctx->has_hosek = false;
   return FH_OK;
 }
-int fh_load_ibl(fh_ctx* ctx, const float*, uint32_t, uint32_t) { return fail(ctx, FH_E_UNSUPPORTED, "image-based lighting is not supported in this build"); }
+int fh_load_ibl(fh_ctx* ctx, const float* rgba, uint32_t w, uint32_t h)
+{
+  CTX_CHECK(ctx);
+  if (!rgba || w == 0 || h == 0) return fail(ctx, FH_E_INVALID, "fh_load_ibl: empty image");
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_ibl) { (void)hipFree(ctx->d_ibl); ctx->d_ibl = nullptr; }
+  FH_HIP(hipMalloc((void**)&ctx->d_ibl, sizeof(float) * 4ull * w * h));
+  FH_HIP(hipMemcpy(ctx->d_ibl, rgba, sizeof(float) * 4ull * w * h, hipMemcpyHostToDevice));
+  ctx->ibl_w = w;
+  ctx->ibl_h = h;
+  return FH_OK;
+}
+int fh_clear_ibl(fh_ctx* ctx)
+{
+  CTX_CHECK(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_ibl) { (void)hipFree(ctx->d_ibl); ctx->d_ibl = nullptr; }
+  return FH_OK;
+}
 
 int fh_init_render_states(fh_ctx* ctx)
 {

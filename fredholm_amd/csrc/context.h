@@ -33,6 +33,16 @@ struct fh_ctx {
   uint8_t* d_face_cls = nullptr;
   fh::MaterialDev* d_materials = nullptr;
   fh::AreaLightDev* d_lights = nullptr;
+  // textures (renderer.h:372-386): one device blob of texels + descriptors + the sRGB table
+  std::vector<std::vector<uint8_t>> h_textures;
+  std::vector<uint32_t> h_tex_w, h_tex_h, h_tex_srgb;
+  uint8_t* d_texels = nullptr;
+  fht_texture* d_textures = nullptr;
+  float* d_srgb_lut = nullptr;
+  uint32_t n_textures = 0;
+  bool has_alpha = false;
+  float* d_ibl = nullptr;
+  uint32_t ibl_w = 0, ibl_h = 0;
   uint32_t n_faces = 0, n_lights = 0, n_materials = 0;
   uint32_t n_classes = 0;
   uint32_t class_lobes[fh::kMaxClasses] = {};

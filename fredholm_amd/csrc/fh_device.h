@@ -9,6 +9,7 @@
 //   path pool      structure-of-arrays indexed by path slot p (one slot per camera path of the pass).
 //   queues         uint32 path-slot lists with device-resident counters; no host readback inside a frame.
 #pragma once
+#include "../../include/fh_texture_unit.h"
 #include "fh_sky.h"
 #include "fh_vec.h"
 
@@ -26,6 +27,7 @@ struct MaterialDev {  // 180-byte reference record + derived words
   float w[45];
   uint32_t lobes;     // lobe mask of this material (fh_bsdf.h)
   uint32_t emissive;  // has_emission (pt.cu:125-129)
+  uint32_t alpha;     // base-colour or alpha texture present: candidate hits go through the any-hit test
   uint32_t cls;       // shading class index
 };
 
@@ -52,6 +54,10 @@ struct SceneDev {
   const MaterialDev* materials;
   const AreaLightDev* lights;
   uint32_t n_faces, n_lights;
+  const fht_texture* textures;  // software texture unit (include/fh_texture_unit.h)
+  const float* srgb_lut;        // 256-entry sRGB -> linear table
+  uint32_t n_textures;
+  uint32_t has_alpha;           // some faces carry an alpha cut-out (pt.cu:545-678): traversal runs the any-hit test for them
   Bvh2Dev bvh2;
   Bvh8Dev bvh8;
   uint32_t use_bvh8;
@@ -61,7 +67,8 @@ struct FrameDev {
   uint32_t width, height;
   uint32_t seed_hash;  // xxhash32(seed), used as Sobol seed and CMJ scramble (pt.cu:388,393)
   uint32_t max_depth;
-  uint32_t has_dir, has_hosek;
+  uint32_t has_dir, has_hosek, has_ibl;
+  fht_texture ibl;  // float4 lat-long environment (renderer.h:574-581)
   uint32_t n1, n2;     // Sobol dimensions / CMJ slots consumed per shaded bounce
   // camera (camera.cu:24-53)
   m34 cam_xf;

@@ -87,6 +87,34 @@ FH_D bool slab_test(const RayPre& r, float lox, float loy, float loz, float hix,
   return tnr <= tf && tf >= 0.0f && tnr <= tmax;
 }
 
+// __anyhit__{radiance,shadow,light} (pt.cu:545-678): a candidate hit is ignored when the base-colour texture's alpha or
+// the alpha texture's red channel is below 0.5 at the hit's texture coordinate
+FH_D f3 tex_rgb(const SceneDev& sc, int id, float u, float v)
+{
+  float o[4];
+  fht_tex2d(&sc.textures[id], sc.srgb_lut, u, v, o);
+  return mk3(o[0], o[1], o[2]);
+}
+FH_D float4 tex_rgba(const SceneDev& sc, int id, float u, float v)
+{
+  float o[4];
+  fht_tex2d(&sc.textures[id], sc.srgb_lut, u, v, o);
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+FH_D bool alpha_pass(const SceneDev& sc, uint32_t prim, float bu, float bv)
+{
+  const size_t fb = 7 * (size_t)prim;
+  const float4 r0 = sc.face_rec[fb], r1 = sc.face_rec[fb + 1], r2 = sc.face_rec[fb + 2], r3 = sc.face_rec[fb + 3], r4 = sc.face_rec[fb + 4], r5 = sc.face_rec[fb + 5];
+  const float bw = 1.0f - bu - bv;
+  const float tu = bw * r0.w + bu * r2.w + bv * r4.w;
+  const float tv = bw * r1.w + bu * r3.w + bv * r5.w;
+  const MaterialDev& m = sc.materials[__float_as_uint(sc.face_rec[fb + 6].x)];
+  const int base_tex = __float_as_int(m.w[4]), alpha_tex = __float_as_int(m.w[44]);
+  if (base_tex >= 0 && tex_rgba(sc, base_tex, tu, tv).w < 0.5f) return false;
+  if (alpha_tex >= 0 && tex_rgba(sc, alpha_tex, tu, tv).x < 0.5f) return false;
+  return true;
+}
+
 // accept a candidate under the closest-hit order (t, then face id)
 FH_D bool closer(float t, uint32_t prim, const HitRec& best) { return t < best.t || (t == best.t && prim < best.prim); }
 
@@ -96,8 +124,8 @@ FH_D bool closer(float t, uint32_t prim, const HitRec& best) { return t < best.t
 // ---------------------------------------------------------------------------------------------
 constexpr int kBvh2Stack = 96;
 
-template <bool ANY_HIT, bool COUNT>
-FH_D bool traverse_bvh2(const Bvh2Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris)
+template <bool ANY_HIT, bool COUNT, bool ALPHA = false>
+FH_D bool traverse_bvh2(const Bvh2Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, const SceneDev* sc = nullptr)
 {
   best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu;
   if (bvh.n_nodes == 0) return false;
@@ -132,6 +160,7 @@ FH_D bool traverse_bvh2(const Bvh2Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
         if (t > tmax) continue;
         const uint32_t prim = __float_as_uint(a.w);
         if (found && !closer(t, prim, best)) continue;
+        if (ALPHA && b.w != 0.0f && !alpha_pass(*sc, prim, bu, bv)) continue;
         best.t = t; best.u = bu; best.v = bv; best.prim = prim;
         found = true;
         if (ANY_HIT) return true;
@@ -249,9 +278,9 @@ struct GroupStack<true> {  // first kLdsStack entries in LDS (column [entry][thr
   }
 };
 
-template <bool ANY_HIT, bool COUNT, bool LDS = false>
+template <bool ANY_HIT, bool COUNT, bool LDS = false, bool ALPHA = false>
 FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr, uint2* lds_column = nullptr,
-                        int lds_stride = 0)
+                        int lds_stride = 0, const SceneDev* sc = nullptr)
 {
   best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu;
   if (bvh.n_nodes == 0) return false;
@@ -291,6 +320,7 @@ FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
       if (t > tmax) continue;
       const uint32_t prim = __float_as_uint(a.w);
       if (found && !closer(t, prim, best)) continue;
+      if (ALPHA && bb.w != 0.0f && !alpha_pass(*sc, prim, bu, bv)) continue;
       best.t = t; best.u = bu; best.v = bv; best.prim = prim;
       found = true;
       if (ANY_HIT) return true;
@@ -415,6 +445,10 @@ struct WaveFeeder {
 template <bool ANY_HIT, bool COUNT>
 FH_D bool traverse(const SceneDev& sc, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr)
 {
+  if (sc.has_alpha) {  // rare: scenes with cut-out textures take the variant with the any-hit test compiled in
+    if (sc.use_bvh8) return traverse_bvh8<ANY_HIT, COUNT, false, true>(sc.bvh8, o, d, tmax, best, n_nodes, n_tris, ws, nullptr, 0, &sc);
+    return traverse_bvh2<ANY_HIT, COUNT, true>(sc.bvh2, o, d, tmax, best, n_nodes, n_tris, &sc);
+  }
   if (sc.use_bvh8) return traverse_bvh8<ANY_HIT, COUNT, false>(sc.bvh8, o, d, tmax, best, n_nodes, n_tris, ws);
   return traverse_bvh2<ANY_HIT, COUNT>(sc.bvh2, o, d, tmax, best, n_nodes, n_tris);
 }

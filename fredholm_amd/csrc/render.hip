@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "context.h"
 #include "fh_bsdf.h"
@@ -51,7 +52,19 @@ FH_D void load_sobol_rows(SobolRows& rows, const uint32_t* table, const uint32_t
   __syncthreads();
 }
 
-FH_D f3 env_radiance(const FrameDev& fr, f3 d) { return fr.has_hosek ? hosek_radiance(fr.hosek, fr.sun_dir, fr.sky_intensity, d) : fr.bg; }
+// environment seen along d: IBL, else Hosek sky, else the constant background (pt.cu:511-517, :536-542)
+FH_D f3 env_radiance(const FrameDev& fr, f3 d)
+{
+  if (fr.has_ibl) {  // fetch_ibl (pt.cu:344-350) with cartesian_to_spherical (math.cu:111-118)
+    const float theta = fhe_acos(clampf(d.y, -1.0f, 1.0f));
+    float phi = fhe_atan2(d.z, d.x);
+    if (phi < 0) phi += 2.0f * kPi;
+    float o[4];
+    fht_tex2d(&fr.ibl, nullptr, phi / (2.0f * kPi), theta / kPi, o);
+    return fr.sky_intensity * mk3(o[0], o[1], o[2]);
+  }
+  return fr.has_hosek ? hosek_radiance(fr.hosek, fr.sun_dir, fr.sky_intensity, d) : fr.bg;
+}
 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, LayersDev layers, const uint32_t* owned, uint32_t n_owned, uint32_t n_paths)
@@ -121,7 +134,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
 
 // ------------------------------------------------------------------------------------------------
 // closest hit: one lane per ray, grid-stride over the queue (binary-BVH fallback shares this kernel)
-template <bool COUNT, bool WIDE>
+template <bool COUNT, bool WIDE, bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc)
 {
   const uint32_t* cnt = pool.counters + depth * kCounterStride;
@@ -135,8 +148,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, Po
     const float4 o = pool.ray_o[p], d = pool.ray_d[p];
     HitRec h;
     const uint32_t nn0 = nn;
-    if (WIDE) traverse_bvh8<false, COUNT, false>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws);
-    else traverse_bvh2<false, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+    if (WIDE) traverse_bvh8<false, COUNT, false, ALPHA>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, nullptr, 0, &sc);
+    else traverse_bvh2<false, COUNT, ALPHA>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt, &sc);
     if (COUNT) { const uint32_t k = nn - nn0; int b = 0; while (b < 7 && k > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
     pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
   }
@@ -207,7 +220,7 @@ __global__ void __launch_bounds__(kBlock) k_route(SceneDev sc, PoolDev pool, uin
     if (i < count) {
       p = q[i];
       const uint32_t prim = __float_as_uint(pool.hit[p].w);
-      if (prim != 0xffffffffu) cls = sc.face_cls[prim] & 0x7fu;
+      if (prim != 0xffffffffu) cls = sc.face_cls[prim] & 0x3fu;
     }
     uint32_t my_rank = 0;
     for (uint32_t c = 0; c < n_classes; ++c) {
@@ -244,19 +257,27 @@ __global__ void __launch_bounds__(kBlock) k_miss_primary(FrameDev fr, PoolDev po
 }
 
 // ------------------------------------------------------------------------------------------------
-FH_D MatParams load_params(const MaterialDev& m)
+FH_D int tex_id(const MaterialDev& m, int word) { return __float_as_int(m.w[word]); }
+
+// fill_shading_params (pt.cu:181-280): material constants, overridden by texture lookups where a texture id is set
+FH_D MatParams load_params(const SceneDev& sc, const MaterialDev& m, float tu, float tv)
 {
   MatParams p;
   p.diffuse = m.w[0];
-  p.base_color = mk3(m.w[1], m.w[2], m.w[3]);
+  p.base_color = tex_id(m, 4) >= 0 ? tex_rgb(sc, tex_id(m, 4), tu, tv) : mk3(m.w[1], m.w[2], m.w[3]);
   p.diffuse_roughness = m.w[5];
   p.specular = m.w[6];
-  p.specular_color = mk3(m.w[7], m.w[8], m.w[9]);
-  p.specular_roughness = clampf(m.w[11], 0.01f, 1.0f);
-  p.metalness = m.w[13];
-  p.coat = clampf(m.w[16], 0.0f, 1.0f);
+  p.specular_color = tex_id(m, 10) >= 0 ? tex_rgb(sc, tex_id(m, 10), tu, tv) : mk3(m.w[7], m.w[8], m.w[9]);
+  p.specular_roughness = clampf(tex_id(m, 12) >= 0 ? tex_rgba(sc, tex_id(m, 12), tu, tv).x : m.w[11], 0.01f, 1.0f);
+  p.metalness = tex_id(m, 14) >= 0 ? tex_rgba(sc, tex_id(m, 14), tu, tv).x : m.w[13];
+  if (tex_id(m, 15) >= 0) {  // glTF metallic-roughness texture: G = roughness, B = metalness (pt.cu:230-236)
+    const float4 mr = tex_rgba(sc, tex_id(m, 15), tu, tv);
+    p.specular_roughness = clampf(mr.y, 0.01f, 1.0f);
+    p.metalness = clampf(mr.z, 0.0f, 1.0f);
+  }
+  p.coat = clampf(tex_id(m, 17) >= 0 ? tex_rgba(sc, tex_id(m, 17), tu, tv).x : m.w[16], 0.0f, 1.0f);
   p.coat_color = mk3(1.0f, 1.0f, 1.0f);  // fill_shading_params never copies material.coat_color (pt.cu:238-255)
-  p.coat_roughness = clampf(m.w[21], 0.0f, 1.0f);
+  p.coat_roughness = clampf(tex_id(m, 22) >= 0 ? tex_rgba(sc, tex_id(m, 22), tu, tv).y : m.w[21], 0.0f, 1.0f);
   p.transmission = m.w[23];
   p.transmission_color = mk3(m.w[24], m.w[25], m.w[26]);
   p.sheen = m.w[27];
@@ -266,6 +287,12 @@ FH_D MatParams load_params(const MaterialDev& m)
   p.subsurface_color = mk3(m.w[33], m.w[34], m.w[35]);
   p.thin_walled = m.w[36];
   return p;
+}
+
+// get_emission (pt.cu:131-139)
+FH_D f3 emission_of(const SceneDev& sc, const MaterialDev& m, float tu, float tv)
+{
+  return tex_id(m, 41) >= 0 ? tex_rgb(sc, tex_id(m, 41), tu, tv) : mk3(m.w[38], m.w[39], m.w[40]);
 }
 
 FH_D void store_secondary(const PoolDev& pool, uint32_t slot, uint32_t p, f3 o, float tmax, f3 d, bool active, f3 c)
@@ -350,12 +377,29 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
   f3 tangent, bitangent;
   onb(ns, tangent, bitangent);
   const MaterialDev& mat = sc.materials[__float_as_uint(r6.x)];
-  const MatParams sp = load_params(mat);
+  const MatParams sp = load_params(sc, mat, tu, tv);
+  const f3 ns_geo = ns, tangent_geo = tangent, bitangent_geo = bitangent;  // surf_info frame before the maps
+  if (tex_id(mat, 42) >= 0) {  // bump mapping with a height map (pt.cu:709-731)
+    const fht_texture& hm = sc.textures[tex_id(mat, 42)];
+    const float du = 1.0f / hm.width, dv = 1.0f / hm.height;
+    const float hv = tex_rgba(sc, tex_id(mat, 42), tu, tv).x;
+    const float dfdu = tex_rgba(sc, tex_id(mat, 42), tu + du, tv).x - hv;
+    const float dfdv = tex_rgba(sc, tex_id(mat, 42), tu, tv + dv).x - hv;
+    tangent = normalize(tangent_geo + dfdu * ns_geo);
+    bitangent = normalize(bitangent_geo + dfdv * ns_geo);
+    ns = normalize(cross(tangent, bitangent));
+  }
+  if (tex_id(mat, 43) >= 0) {  // normal mapping (pt.cu:733-742)
+    f3 value = tex_rgb(sc, tex_id(mat, 43), tu, tv);
+    value = 2.0f * value - 1.0f;
+    ns = normalize(to_world(value, tangent_geo, bitangent_geo, ns_geo));
+    onb(ns, tangent, bitangent);
+  }
 
   if (depth == 0) {  // first hit: AOVs and directly visible emitters (pt.cu:745-760)
     out.aov_position = x; out.aov_normal = ns; out.aov_albedo = sp.base_color; out.aov_u = tu; out.aov_v = tv;
     if (mat.emissive) {
-      out.L = L + T * mk3(mat.w[38], mat.w[39], mat.w[40]);
+      out.L = L + T * emission_of(sc, mat, tu, tv);
       out.emissive_done = true;
       return;
     }
@@ -403,7 +447,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
     const f3 ln = lw * mk3(l3) + bc.x * mk3(l4) + bc.y * mk3(l5);
     const float area = 0.5f * length(cross(mk3(l1) - mk3(l0), mk3(l2) - mk3(l0)));
     const MaterialDev& lm = sc.materials[lt.material];
-    const f3 le = mk3(lm.w[38], lm.w[39], lm.w[40]);
+    const f3 le = emission_of(sc, lm, lw * l0.w + bc.x * l2.w + bc.y * l4.w, lw * l1.w + bc.x * l3.w + bc.y * l5.w);
     const float pdf_area = 1.0f / (sc.n_lights * area);
     const f3 sd = normalize(lp - so);
     const float r = length(lp - so);
@@ -531,7 +575,7 @@ FH_D f3 resolve_light_ray(const SceneDev& sc, const FrameDev& fr, f3 T, float co
       const f3 ln = lw * mk3(l3) + h.u * mk3(l4) + h.v * mk3(l5);
       if (dot(-ld, ln) > 0.0f) {
         const MaterialDev& lm = sc.materials[__float_as_uint(sc.face_rec[fb + 6].x)];
-        le = mk3(lm.w[38], lm.w[39], lm.w[40]);
+        le = emission_of(sc, lm, lw * l0.w + h.u * l2.w + h.v * l4.w, lw * l1.w + h.u * l3.w + h.v * l5.w);
         const float area = 0.5f * length(cross(mk3(l1) - mk3(l0), mk3(l2) - mk3(l0)));
         const f3 dl = lp - ro;
         const float r2 = dot(dl, dl);
@@ -550,7 +594,7 @@ FH_D f3 resolve_light_ray(const SceneDev& sc, const FrameDev& fr, f3 T, float co
 }
 
 // secondary rays, binary-BVH fallback: one thread per shaded path, its rays in the reference's order
-template <bool COUNT, bool WIDE, bool LIGHTS>
+template <bool COUNT, bool WIDE, bool LIGHTS, bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc)
 {
   __shared__ uint2 lds_stack[kLdsStack * kBlock];
@@ -572,14 +616,14 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
       HitRec h;
       if (COUNT) nr++;
       if (slot == SEC_LIGHT && has_lights) {
-        const bool hit = WIDE ? traverse_bvh8<false, COUNT, true>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack + threadIdx.x, kBlock)
-                              : traverse_bvh2<false, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+        const bool hit = WIDE ? traverse_bvh8<false, COUNT, true, ALPHA>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack + threadIdx.x, kBlock, &sc)
+                              : traverse_bvh2<false, COUNT, ALPHA>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt, &sc);
         const float4 la = pool.lp_a[p], lb = pool.lp_b[p];
         L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, mk3(o), mk3(d), hit, h);
       } else {
         const uint32_t nn0 = nn;
-        const bool occluded = WIDE ? traverse_bvh8<true, COUNT, true>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack + threadIdx.x, kBlock)
-                                   : traverse_bvh2<true, COUNT>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt);
+        const bool occluded = WIDE ? traverse_bvh8<true, COUNT, true, ALPHA>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack + threadIdx.x, kBlock, &sc)
+                                   : traverse_bvh2<true, COUNT, ALPHA>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt, &sc);
         if (COUNT) { const uint32_t kk = nn - nn0; int b = 0; while (b < 7 && kk > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
         if (!occluded) L += mk3(pool.sec_c[k]);
       }
@@ -772,6 +816,13 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(PoolDev pool, LayersDev l
   }
 }
 
+template <typename F>
+void with_bool(bool b, F&& f)
+{
+  if (b) f(std::true_type{});
+  else f(std::false_type{});
+}
+
 uint32_t grid_for(uint32_t n)  // multiple of 8 (one share per XCD), at most 8192 blocks, grid-stride beyond
 {
   uint32_t b = (n + kBlock - 1) / kBlock;
@@ -826,6 +877,10 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.lights = ctx->d_lights;
   s.n_faces = ctx->n_faces;
   s.n_lights = ctx->n_lights;
+  s.textures = ctx->d_textures;
+  s.srgb_lut = ctx->d_srgb_lut;
+  s.n_textures = ctx->n_textures;
+  s.has_alpha = ctx->has_alpha ? 1u : 0u;
   s.bvh2.nodes = ctx->d_bvh2_nodes;
   s.bvh2.tris = ctx->d_bvh2_tris;
   s.bvh2.n_nodes = ctx->bvh2_n_nodes;
@@ -887,6 +942,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   fr.max_depth = max_depth;
   fr.has_dir = ctx->has_dir ? 1u : 0u;
   fr.has_hosek = ctx->has_hosek ? 1u : 0u;
+  fr.has_ibl = ctx->d_ibl ? 1u : 0u;
+  fr.ibl = fht_texture{nullptr, ctx->d_ibl, ctx->ibl_w, ctx->ibl_h, 0u};
   const uint32_t has_lights = ctx->n_lights > 0 ? 1u : 0u;
   fr.n1 = 3u + has_lights;
   fr.n2 = 3u + fr.has_dir + has_lights;
@@ -954,11 +1011,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
           if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
           else hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
         } else {
-          const bool w8 = sc.use_bvh8 != 0;
-          if (count && w8) hipLaunchKernelGGL((k_trace_closest_static<true, true>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
-          else if (count) hipLaunchKernelGGL((k_trace_closest_static<true, false>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
-          else if (w8) hipLaunchKernelGGL((k_trace_closest_static<false, true>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
-          else hipLaunchKernelGGL((k_trace_closest_static<false, false>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+          with_bool(count, [&](auto C) { with_bool(sc.use_bvh8 != 0, [&](auto W) { with_bool(sc.has_alpha != 0, [&](auto A) {
+            hipLaunchKernelGGL((k_trace_closest_static<decltype(C)::value, decltype(W)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+          }); }); });
         }
         ctx->stats.n_closest_launches++;
       }
@@ -977,11 +1032,10 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
           else if (lights) hipLaunchKernelGGL((k_trace_secondary<false, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
           else hipLaunchKernelGGL((k_trace_secondary<false, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
         } else {
-          const bool w8 = sc.use_bvh8 != 0, lights = sc.n_lights > 0;
-#define FH_LAUNCH_SEC(C, W, Li) hipLaunchKernelGGL((k_trace_secondary_static<C, W, Li>), dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow)
-          if (count) { if (w8) { if (lights) FH_LAUNCH_SEC(true, true, true); else FH_LAUNCH_SEC(true, true, false); } else { if (lights) FH_LAUNCH_SEC(true, false, true); else FH_LAUNCH_SEC(true, false, false); } }
-          else { if (w8) { if (lights) FH_LAUNCH_SEC(false, true, true); else FH_LAUNCH_SEC(false, true, false); } else { if (lights) FH_LAUNCH_SEC(false, false, true); else FH_LAUNCH_SEC(false, false, false); } }
-#undef FH_LAUNCH_SEC
+          with_bool(count, [&](auto C) { with_bool(sc.use_bvh8 != 0, [&](auto W) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
+            hipLaunchKernelGGL((k_trace_secondary_static<decltype(C)::value, decltype(W)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, fr, pool,
+                               depth, tc_shadow);
+          }); }); }); });
         }
         ctx->stats.n_shadow_launches++;
       }

@@ -47,11 +47,16 @@ def default_materials(n):
     return m
 
 
+class TextureDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgba8", C.c_void_p), ("srgb", C.c_int32)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("n_vertices", C.c_uint32), ("vertices", C.c_void_p), ("normals", C.c_void_p), ("texcoords", C.c_void_p),
                 ("n_faces", C.c_uint32), ("indices", C.c_void_p), ("material_ids", C.c_void_p), ("instance_ids", C.c_void_p),
                 ("n_materials", C.c_uint32), ("materials", C.c_void_p),
-                ("n_instances", C.c_uint32), ("object_to_world", C.c_void_p), ("world_to_object", C.c_void_p)]
+                ("n_instances", C.c_uint32), ("object_to_world", C.c_void_p), ("world_to_object", C.c_void_p),
+                ("n_textures", C.c_uint32), ("textures", C.c_void_p)]
 
 
 class CameraC(C.Structure):
@@ -90,7 +95,7 @@ class FredholmError(RuntimeError):
 EXPORTS = [
     "fh_ctx_create", "fh_ctx_destroy", "fh_last_error", "fh_set_flags", "fh_set_path_pool", "fh_set_tail_depth", "fh_scene_upload", "fh_bvh_build", "fh_set_transforms",
     "fh_scene_n_lights", "fh_set_directional_light", "fh_clear_directional_light", "fh_set_sky_intensity", "fh_load_arhosek_sky",
-    "fh_clear_arhosek_sky", "fh_load_ibl", "fh_set_resolution", "fh_init_render_states", "fh_set_tile_shard", "fh_owned_pixel_count",
+    "fh_clear_arhosek_sky", "fh_load_ibl", "fh_clear_ibl", "fh_set_resolution", "fh_init_render_states", "fh_set_tile_shard", "fh_owned_pixel_count",
     "fh_pack_owned", "fh_unpack_shard", "fh_render", "fh_sync", "fh_get_stats", "fh_reset_stats", "fh_post_process", "fh_malloc",
     "fh_free", "fh_memset", "fh_copy_to_device", "fh_copy_to_host", "fh_stream", "fh_trace_rays", "fh_kat_hash", "fh_kat_cmj",
     "fh_kat_sobol", "fh_kat_elementary", "fh_kat_warp", "fh_kat_bsdf", "fh_kat_sky", "fh_kat_hosek_state", "fh_kat_camera",

@@ -220,7 +220,17 @@ class Renderer:
             w2o = np.ascontiguousarray(w2o, dtype=np.float32).reshape(-1, 12)
             d.n_instances = o2w.shape[0]
             d.object_to_world, d.world_to_object = N.ptr(o2w), N.ptr(w2o)
-        self._keep = (v, n, t, idx, mid, mats, inst, o2w, w2o)
+        textures = scene.get("textures") or []
+        tex_arr = (N.TextureDesc * max(len(textures), 1))()
+        tex_keep = []
+        for k, tex in enumerate(textures):
+            img = np.ascontiguousarray(tex["rgba8"], dtype=np.uint8)
+            assert img.ndim == 3 and img.shape[2] == 4
+            tex_keep.append(img)
+            tex_arr[k] = N.TextureDesc(img.shape[1], img.shape[0], img.ctypes.data, int(bool(tex.get("srgb", False))))
+        d.n_textures = len(textures)
+        d.textures = C.cast(tex_arr, C.c_void_p) if textures else None
+        self._keep = (v, n, t, idx, mid, mats, inst, o2w, w2o, tex_arr, tex_keep)
         self._ck(N.lib().fh_scene_upload(self._ctx, C.byref(d)), "fh_scene_upload")
 
     def build_gas(self):
@@ -261,6 +271,15 @@ class Renderer:
 
     def clear_arhosek_sky(self):
         self._ck(N.lib().fh_clear_arhosek_sky(self._ctx), "fh_clear_arhosek_sky")
+
+    def load_ibl(self, rgba32f):
+        """renderer.h:574-581; takes the decoded lat-long image (H x W x 4 float32) instead of a .hdr path"""
+        img = np.ascontiguousarray(rgba32f, dtype=np.float32)
+        assert img.ndim == 3 and img.shape[2] == 4
+        self._ck(N.lib().fh_load_ibl(self._ctx, N.ptr(img), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0])), "fh_load_ibl")
+
+    def clear_ibl(self):
+        self._ck(N.lib().fh_clear_ibl(self._ctx), "fh_clear_ibl")
 
     # -- frame state (renderer.h:642-655)
     def set_resolution(self, width, height):

@@ -266,3 +266,91 @@ def _isnum(s):
         return True
     except ValueError:
         return False
+
+
+def checker_texture(w, h, cells, c0, c1, alpha0=255, alpha1=255, seed=0):
+    """RGBA8 checkerboard with a little per-texel noise (so that filtering matters); row 0 first."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    on = (((x * cells) // w + (y * cells) // h) % 2).astype(bool)
+    img = np.zeros((h, w, 4), dtype=np.uint8)
+    img[..., :3] = np.where(on[..., None], np.asarray(c1, dtype=np.uint8), np.asarray(c0, dtype=np.uint8))
+    img[..., :3] = np.clip(img[..., :3].astype(np.int32) + rng.integers(-6, 7, (h, w, 3)), 0, 255).astype(np.uint8)
+    img[..., 3] = np.where(on, alpha1, alpha0)
+    return img
+
+
+def textured_cornell_box():
+    """Cornell box exercising every texture slot of the reference (pt.cu:181-280, :545-678, :709-742, :131-139):
+    sRGB base-colour checker on the floor, alpha cut-out card, normal-mapped back wall, height-mapped left wall,
+    roughness/metalness maps on the short block, coat maps on the tall block, textured emitter."""
+    sc = cornell_box()
+    m = default_materials(9)
+    m[:4] = sc["materials"]
+    rng = np.random.default_rng(7)
+    tex = []
+
+    def add(img, srgb):
+        tex.append({"rgba8": img, "srgb": srgb})
+        return len(tex) - 1
+
+    # 4: floor with base-colour checker (opaque alpha)
+    m["base_color_texture_id"][4] = add(checker_texture(64, 64, 8, (200, 60, 40), (230, 230, 210)), True)
+    # 5: back wall with normal map
+    nm = np.zeros((32, 32, 4), np.uint8)
+    nm[..., 0] = (128 + 60 * np.sin(np.arange(32) / 32 * 6 * np.pi))[None, :].astype(np.uint8)
+    nm[..., 1] = 128
+    nm[..., 2] = 230
+    nm[..., 3] = 255
+    m["normalmap_texture_id"][5] = add(nm, False)
+    m["base_color"][5] = (0.7, 0.7, 0.75)
+    # 6: left wall with height map
+    hm = np.zeros((48, 24, 4), np.uint8)
+    hm[..., 0] = rng.integers(0, 256, (48, 24))
+    hm[..., 3] = 255
+    m["heightmap_texture_id"][6] = add(hm, False)
+    m["base_color"][6] = (0.65, 0.05, 0.05)
+    # 7: short block: roughness + metalness + specular colour maps, tall block (8): coat + coat roughness + glTF metallic-roughness
+    m["specular_roughness_texture_id"][7] = add(checker_texture(16, 16, 4, (40, 0, 0), (200, 0, 0), seed=1), False)
+    m["metalness_texture_id"][7] = add(checker_texture(16, 16, 2, (0, 0, 0), (255, 0, 0), seed=2), False)
+    m["specular_color_texture_id"][7] = add(checker_texture(8, 8, 2, (255, 255, 255), (255, 200, 120), seed=3), True)
+    m["base_color"][7] = (0.8, 0.7, 0.3)
+    m["coat_texture_id"][8] = add(checker_texture(16, 16, 4, (30, 0, 0), (255, 0, 0), seed=4), False)
+    m["coat_roughness_texture_id"][8] = add(checker_texture(16, 16, 4, (0, 20, 0), (0, 120, 0), seed=5), False)
+    m["metallic_roughness_texture_id"][8] = add(checker_texture(16, 16, 2, (0, 60, 0), (0, 160, 255), seed=6), False)
+    # light with emission texture
+    em = checker_texture(8, 8, 2, (255, 255, 255), (255, 120, 40), seed=8)
+    m["emission_texture_id"][3] = add(em, True)
+    ids = sc["material_ids"].copy()
+    ids[0:2] = 4     # floor
+    ids[4:6] = 5     # back wall
+    ids[6:8] = 6     # left wall
+    ids[12:24] = 7   # short block
+    ids[24:36] = 8   # tall block
+    # alpha cut-out card in front of the back wall: base-colour alpha on one triangle pair, alpha texture on another
+    card = _quad((-0.6, 0.9, -0.5), (0.2, 0.9, -0.5), (0.2, 1.7, -0.5), (-0.6, 1.7, -0.5)) + _quad((0.3, 0.9, -0.4), (0.9, 0.9, -0.4), (0.9, 1.5, -0.4), (0.3, 1.5, -0.4))
+    mc = default_materials(2)
+    mc["base_color_texture_id"][0] = add(checker_texture(32, 32, 4, (40, 200, 60), (0, 0, 0), alpha0=255, alpha1=0, seed=9), True)
+    mc["alpha_texture_id"][1] = add(checker_texture(32, 32, 6, (255, 0, 0), (0, 0, 0), seed=10), False)
+    mc["base_color"][1] = (0.2, 0.3, 0.8)
+    verts = np.concatenate([sc["vertices"], np.asarray(card, dtype=np.float32)])
+    nf = verts.shape[0] // 3
+    out = _finish(verts, np.concatenate([ids, [9, 9, 10, 10]]).astype(np.uint32), np.concatenate([m, mc]))
+    # per-face uv: stretch the unit triangle uvs a bit so that wrap addressing is exercised
+    out["texcoords"] = (out["texcoords"] * np.float32(1.7) - np.float32(0.2)).astype(np.float32)
+    out["textures"] = tex
+    assert out["indices"].shape[0] == nf
+    return out
+
+
+def gradient_ibl(w=64, h=32):
+    """small lat-long float environment: warm sun blob + blue-ish gradient"""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.zeros((h, w, 4), dtype=np.float32)
+    img[..., 0] = 0.3 + 0.4 * (1 - y / h)
+    img[..., 1] = 0.4 + 0.4 * (1 - y / h)
+    img[..., 2] = 0.6 + 0.6 * (1 - y / h)
+    blob = np.exp(-(((x - 0.7 * w) / 4) ** 2 + ((y - 0.25 * h) / 3) ** 2))
+    img[..., :3] += 30.0 * blob[..., None] * np.asarray([1.0, 0.85, 0.6], dtype=np.float32)
+    img[..., 3] = 1.0
+    return img

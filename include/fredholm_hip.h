@@ -26,7 +26,7 @@ extern "C" {
 #define FH_OK 0
 #define FH_E_INVALID -1      /* bad argument / state */
 #define FH_E_HIP -2          /* a HIP runtime call failed */
-#define FH_E_UNSUPPORTED -3  /* feature present in the reference but not in this build (textures, IBL) */
+#define FH_E_UNSUPPORTED -3  /* feature present in the reference but not in this build (glTF, image file decoding) */
 
 typedef struct fh_ctx fh_ctx;
 
@@ -44,6 +44,14 @@ typedef struct fh_material {
   int32_t heightmap_texture_id; int32_t normalmap_texture_id; int32_t alpha_texture_id;
 } fh_material;
 
+/* 8-bit RGBA texture as the reference's Texture holds it after stb_image load (fredholm/src/scene.cpp:7-37: 4 channels,
+ * v-flipped on load) plus its TextureType: srgb = 1 for COLOR textures (hardware sRGB decode, cwl/texture.h:35-47) */
+typedef struct fh_texture_desc {
+  uint32_t width, height;
+  const uint8_t* rgba8;
+  int32_t srgb;
+} fh_texture_desc;
+
 /* Host-side flat scene, exactly the arrays Renderer::load_scene uploads (renderer.h:361-421; Scene members scene.h:103-135).
  * transforms are 3x4 row-major object_to_world / world_to_object per instance (renderer.h:404-421); NULL / 0 = one identity. */
 typedef struct fh_scene_desc {
@@ -60,6 +68,8 @@ typedef struct fh_scene_desc {
   uint32_t n_instances;
   const float* object_to_world; /* float[12] per instance, may be NULL */
   const float* world_to_object; /* float[12] per instance, may be NULL */
+  uint32_t n_textures;           /* textures referenced by the materials' *_texture_id fields (renderer.h:372-386) */
+  const fh_texture_desc* textures;
 } fh_scene_desc;
 
 /* CameraParams (shared.h:59-64): camera-to-world 3x4 rows, vertical fov in radians, F-number, focus distance */
@@ -135,7 +145,8 @@ int fh_clear_directional_light(fh_ctx* ctx);
 int fh_set_sky_intensity(fh_ctx* ctx, float intensity);
 int fh_load_arhosek_sky(fh_ctx* ctx, float turbidity, float albedo); /* renderer.h:588-607 */
 int fh_clear_arhosek_sky(fh_ctx* ctx);                               /* renderer.h:609-612 */
-int fh_load_ibl(fh_ctx* ctx, const float* rgba, uint32_t w, uint32_t h); /* renderer.h:574-581: FH_E_UNSUPPORTED in this round */
+int fh_load_ibl(fh_ctx* ctx, const float* rgba, uint32_t w, uint32_t h); /* renderer.h:574-581: float4 lat-long image, already decoded */
+int fh_clear_ibl(fh_ctx* ctx);                                          /* renderer.h:583-586 */
 
 /* -- frame state: renderer.h:642-655 */
 int fh_set_resolution(fh_ctx* ctx, uint32_t width, uint32_t height); /* also resets the sample counters */

@@ -24,7 +24,10 @@
 // Third-party arithmetic not in the tree (OptiX BVH traversal + triangle test, CUDA tex2D) is
 // replaced by a binned-SAH BVH + the watertight test of Woop/Benthin/Wald 2013; closest hits are
 // made independent of BVH shape by breaking equal-t ties towards the lower face index.
-// Textures are not supported by the checker (all *_texture_id must be -1).
+// Textures go through the normative software texture unit of include/fh_texture_unit.h (CUDA tex2D semantics as
+// documented; the hardware's exact arithmetic is not in the tree): base colour / specular / roughness / metalness /
+// coat lookups (pt.cu:181-280), bump and normal maps (pt.cu:709-742), emission textures (pt.cu:131-139), the alpha
+// any-hit test (pt.cu:545-678) and the lat-long IBL (pt.cu:344-350).
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -32,6 +35,7 @@
 #include <thread>
 #include <vector>
 
+#include "../include/fh_texture_unit.h"
 #include "obsdf.h"
 
 namespace orc {
@@ -73,6 +77,10 @@ struct Scene {
   // world-space triangles for intersection
   std::vector<V3> wtri;  // 3 per face
   std::vector<BvhNode> nodes; std::vector<uint32_t> order;
+  // textures
+  std::vector<std::vector<uint8_t>> texels; std::vector<fht_texture> textures; float srgb_lut[256];
+  std::vector<uint8_t> face_alpha;  // face needs the any-hit alpha test
+  std::vector<float> ibl_data; fht_texture ibl{}; bool has_ibl = false;
   // environment
   bool has_dir = false; DirLight dir{};
   bool has_hosek = false; HosekState hosek{};
@@ -125,6 +133,23 @@ static inline bool tri_test(const RayPre& r, V3 org, V3 p0, V3 p1, V3 p2, float&
   if (!(t >= 0.0f)) return false;
   bu = V * rcp;
   bv = W * rcp;
+  return true;
+}
+
+static inline V4 tex4(const Scene& s, int id, V2 uv)
+{
+  float o[4];
+  fht_tex2d(&s.textures[id], s.srgb_lut, uv.x, uv.y, o);
+  return v4(o[0], o[1], o[2], o[3]);
+}
+// __anyhit__* (pt.cu:545-678)
+static inline bool alpha_pass(const Scene& s, uint32_t prim, float bu, float bv)
+{
+  const U3 idx = s.faces[prim];
+  const V2 uv = (1.0f - bu - bv) * s.uvs[idx.x] + bu * s.uvs[idx.y] + bv * s.uvs[idx.z];
+  const Material& m = s.mats[s.mat_ids[prim]];
+  if (m.base_color_tex >= 0 && tex4(s, m.base_color_tex, uv).w < 0.5f) return false;
+  if (m.alpha_tex >= 0 && tex4(s, m.alpha_tex, uv).x < 0.5f) return false;
   return true;
 }
 
@@ -261,6 +286,7 @@ static bool intersect(const Scene& s, V3 o, V3 d, float tmax, bool any_hit, Hit&
         if (!tri_test(rp, o, s.wtri[3 * p], s.wtri[3 * p + 1], s.wtri[3 * p + 2], t, u, v)) continue;
         if (t > tmax) continue;
         if (found && (t > best.t || (t == best.t && p > best.prim))) continue;
+        if (s.face_alpha[p] && !alpha_pass(s, p, u, v)) continue;
         best = {t, u, v, p};
         found = true;
         if (any_hit) return true;
@@ -283,6 +309,7 @@ static bool intersect_brute(const Scene& s, V3 o, V3 d, float tmax, bool any_hit
     if (!tri_test(rp, o, s.wtri[3 * p], s.wtri[3 * p + 1], s.wtri[3 * p + 2], t, u, v)) continue;
     if (t > tmax) continue;
     if (found && (t > best.t || (t == best.t && p > best.prim))) continue;
+    if (s.face_alpha[p] && !alpha_pass(s, p, u, v)) continue;
     best = {t, u, v, p};
     found = true;
     if (any_hit) return true;
@@ -413,19 +440,24 @@ static void surface_at(const Scene& s, V3 rd, const Hit& h, Surface& si)
   onb(si.ns, si.tangent, si.bitangent);
 }
 
-// pt.cu:181-280 with every texture id == -1
-static ShadingParams shading_params(const Material& m)
+// pt.cu:181-280
+static ShadingParams shading_params(const Scene& s, const Material& m, V2 uv)
 {
   ShadingParams p;
   p.diffuse = m.diffuse;
   p.diffuse_roughness = m.diffuse_roughness;
-  p.base_color = v3(m.base_color[0], m.base_color[1], m.base_color[2]);
+  p.base_color = m.base_color_tex >= 0 ? v3(tex4(s, m.base_color_tex, uv)) : v3(m.base_color[0], m.base_color[1], m.base_color[2]);
   p.specular = m.specular;
-  p.specular_color = v3(m.specular_color[0], m.specular_color[1], m.specular_color[2]);
-  p.specular_roughness = clampf(m.specular_roughness, 0.01f, 1.0f);
-  p.metalness = m.metalness;
-  p.coat = clampf(m.coat, 0.0f, 1.0f);
-  p.coat_roughness = clampf(m.coat_roughness, 0.0f, 1.0f);
+  p.specular_color = m.specular_color_tex >= 0 ? v3(tex4(s, m.specular_color_tex, uv)) : v3(m.specular_color[0], m.specular_color[1], m.specular_color[2]);
+  p.specular_roughness = clampf(m.specular_roughness_tex >= 0 ? tex4(s, m.specular_roughness_tex, uv).x : m.specular_roughness, 0.01f, 1.0f);
+  p.metalness = m.metalness_tex >= 0 ? tex4(s, m.metalness_tex, uv).x : m.metalness;
+  if (m.metallic_roughness_tex >= 0) {
+    const V4 mr = tex4(s, m.metallic_roughness_tex, uv);
+    p.specular_roughness = clampf(mr.y, 0.01f, 1.0f);
+    p.metalness = clampf(mr.z, 0.0f, 1.0f);
+  }
+  p.coat = clampf(m.coat_tex >= 0 ? tex4(s, m.coat_tex, uv).x : m.coat, 0.0f, 1.0f);
+  p.coat_roughness = clampf(m.coat_roughness_tex >= 0 ? tex4(s, m.coat_roughness_tex, uv).y : m.coat_roughness, 0.0f, 1.0f);
   p.transmission = m.transmission;
   p.transmission_color = v3(m.transmission_color[0], m.transmission_color[1], m.transmission_color[2]);
   p.sheen = m.sheen;
@@ -435,6 +467,11 @@ static ShadingParams shading_params(const Material& m)
   p.subsurface_color = v3(m.subsurface_color[0], m.subsurface_color[1], m.subsurface_color[2]);
   p.thin_walled = m.thin_walled;
   return p;  // coat_color keeps its default (1,1,1): the reference never copies it
+}
+// pt.cu:131-139
+static V3 emission_of(const Scene& s, const Material& m, V2 uv)
+{
+  return m.emission_tex >= 0 ? v3(tex4(s, m.emission_tex, uv)) : v3(m.emission_color[0], m.emission_color[1], m.emission_color[2]);
 }
 
 struct Payload {  // pt.cu:19-36
@@ -451,7 +488,18 @@ static inline bool shadow_visible(const Scene& s, V3 o, V3 d, float tmax)
   Hit h;
   return !intersect(s, o, d, tmax - 0.001f, true, h);  // pt.cu:103
 }
-static inline V3 env_radiance(const Scene& s, const Frame& fr, V3 d) { return s.has_hosek ? sky_radiance(s, d) : fr.bg; }
+static inline V3 env_radiance(const Scene& s, const Frame& fr, V3 d)
+{
+  if (s.has_ibl) {  // pt.cu:344-350, math.cu:111-118
+    const float theta = fhe_acos(clampf(d.y, -1.0f, 1.0f));
+    float phi = fhe_atan2(d.z, d.x);
+    if (phi < 0) phi += 2.0f * kPi;
+    float o[4];
+    fht_tex2d(&s.ibl, nullptr, phi / (2.0f * kPi), theta / kPi, o);
+    return s.sky_intensity * v3(o[0], o[1], o[2]);
+  }
+  return s.has_hosek ? sky_radiance(s, d) : fr.bg;
+}
 static inline float mis(float a, float b) { return a / (a + b); }
 static inline V3 regularize(V3 w) { return clamp3(w, v3(0.0f), v3(1.0f)); }
 
@@ -462,13 +510,29 @@ static void closest_hit_radiance(const Scene& s, const Frame& fr, const Hit& h, 
   const Material& mat = s.mats[s.mat_ids[h.prim]];
   Surface si;
   surface_at(s, rd, h, si);
-  const ShadingParams sp = shading_params(mat);
-  const V3 tangent = si.tangent, normal = si.ns, bitangent = si.bitangent;
+  const ShadingParams sp = shading_params(s, mat, si.uv);
+  V3 tangent = si.tangent, normal = si.ns, bitangent = si.bitangent;
+  if (mat.heightmap_tex >= 0) {  // pt.cu:709-731
+    const fht_texture& hm = s.textures[mat.heightmap_tex];
+    const float du = 1.0f / hm.width, dv = 1.0f / hm.height;
+    const float hv = tex4(s, mat.heightmap_tex, si.uv).x;
+    const float dfdu = tex4(s, mat.heightmap_tex, v2(si.uv.x + du, si.uv.y)).x - hv;
+    const float dfdv = tex4(s, mat.heightmap_tex, v2(si.uv.x, si.uv.y + dv)).x - hv;
+    tangent = normalize(si.tangent + dfdu * si.ns);
+    bitangent = normalize(si.bitangent + dfdv * si.ns);
+    normal = normalize(cross(tangent, bitangent));
+  }
+  if (mat.normalmap_tex >= 0) {  // pt.cu:733-742
+    V3 value = v3(tex4(s, mat.normalmap_tex, si.uv));
+    value = 2.0f * value - 1.0f;
+    normal = normalize(to_world(value, si.tangent, si.bitangent, si.ns));
+    onb(normal, tangent, bitangent);
+  }
   if (pl.firsthit) {
     pl.position = si.x; pl.normal = normal; pl.depth = si.t; pl.texcoord = si.uv; pl.albedo = sp.base_color;
     pl.firsthit = false;
     if (emissive(mat)) {
-      pl.radiance += pl.throughput * v3(mat.emission_color[0], mat.emission_color[1], mat.emission_color[2]);
+      pl.radiance += pl.throughput * emission_of(s, mat, si.uv);
       pl.done = true;
       return;
     }
@@ -518,7 +582,8 @@ static void closest_hit_radiance(const Scene& s, const Frame& fr, const Hit& h, 
       const V3 n = (1.0f - bc.x - bc.y) * n0 + bc.x * n1 + bc.y * n2;
       const float area = 0.5f * length(cross(p1 - p0, p2 - p0));
       const Material& lm = s.mats[L.material_id];
-      const V3 le = v3(lm.emission_color[0], lm.emission_color[1], lm.emission_color[2]);
+      const V2 luv = (1.0f - bc.x - bc.y) * s.uvs[L.idx.x] + bc.x * s.uvs[L.idx.y] + bc.y * s.uvs[L.idx.z];
+      const V3 le = emission_of(s, lm, luv);
       const float pdf_area = 1.0f / (nl * area);
       const V3 sd = normalize(p - so);
       const float r = length(p - so);
@@ -556,7 +621,7 @@ static void closest_hit_radiance(const Scene& s, const Frame& fr, const Hit& h, 
       ln = (1.0f - lh.u - lh.v) * n0 + lh.u * n1 + lh.v * n2;
       if (emissive(lm) && dot(-ld, ln) > 0.0f) {
         hit_light = true;
-        le = v3(lm.emission_color[0], lm.emission_color[1], lm.emission_color[2]);
+        le = emission_of(s, lm, (1.0f - lh.u - lh.v) * s.uvs[idx.x] + lh.u * s.uvs[idx.y] + lh.v * s.uvs[idx.z]);
         larea = 0.5f * length(cross(p1 - p0, p2 - p0));
       }
     } else {
@@ -810,7 +875,8 @@ void orc_warp(int kind, int n, const float* u, const float* wo, const float* alp
 //   out[i] = { eval.rgb, eval_pdf, sample.wi.xyz, sample.f.rgb, sample.pdf, lobe pmf[7] } (18 floats)
 void orc_bsdf(const void* material180, int entering, int n, const float* wo, const float* wi, const float* u1, const float* u2, float* out)
 {
-  const ShadingParams sp = shading_params(*(const Material*)material180);
+  Scene dummy;
+  const ShadingParams sp = shading_params(dummy, *(const Material*)material180, v2(0.0f, 0.0f));
   for (int i = 0; i < n; ++i) {
     const V3 o = v3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), in = v3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
     const Bsdf b(o, sp, entering != 0);
@@ -858,8 +924,10 @@ void orc_camera_rays(const float* cam15, uint32_t width, uint32_t height, uint32
 }
 
 // ---- scene + render
+struct TexDesc { uint32_t width, height; const uint8_t* rgba8; int32_t srgb; };  // = fh_texture_desc
+
 void* orc_scene_create(uint32_t n_verts, const float* verts, const float* normals, const float* uvs, uint32_t n_faces, const uint32_t* faces, const uint32_t* mat_ids,
-                       const uint32_t* inst_ids, uint32_t n_mats, const void* mats180, uint32_t n_xf, const float* o2w, const float* w2o)
+                       const uint32_t* inst_ids, uint32_t n_mats, const void* mats180, uint32_t n_xf, const float* o2w, const float* w2o, uint32_t n_tex, const void* tex_descs)
 {
   Scene* s = new Scene;
   s->verts.resize(n_verts); s->normals.resize(n_verts); s->uvs.resize(n_verts);
@@ -872,9 +940,20 @@ void* orc_scene_create(uint32_t n_verts, const float* verts, const float* normal
   if (inst_ids) std::memcpy(s->inst_ids.data(), inst_ids, 4ull * n_faces);
   s->mats.resize(n_mats);
   std::memcpy(s->mats.data(), mats180, 180ull * n_mats);
-  for (const Material& m : s->mats)
-    if (m.base_color_tex != -1 || m.specular_color_tex != -1 || m.specular_roughness_tex != -1 || m.metalness_tex != -1 || m.metallic_roughness_tex != -1 || m.coat_tex != -1 ||
-        m.coat_roughness_tex != -1 || m.emission_tex != -1 || m.heightmap_tex != -1 || m.normalmap_tex != -1 || m.alpha_tex != -1) { delete s; return nullptr; }
+  for (int i = 0; i < 256; ++i) s->srgb_lut[i] = fht_srgb_to_linear((float)i * (1.0f / 255.0f));
+  const TexDesc* td = (const TexDesc*)tex_descs;
+  s->texels.resize(n_tex);
+  s->textures.resize(n_tex);
+  for (uint32_t i = 0; i < n_tex; ++i) {
+    s->texels[i].assign(td[i].rgba8, td[i].rgba8 + (size_t)td[i].width * td[i].height * 4);
+    s->textures[i] = fht_texture{s->texels[i].data(), nullptr, td[i].width, td[i].height, td[i].srgb ? 1u : 0u};
+  }
+  for (const Material& m : s->mats) {
+    const int ids[11] = {m.base_color_tex, m.specular_color_tex, m.specular_roughness_tex, m.metalness_tex, m.metallic_roughness_tex, m.coat_tex, m.coat_roughness_tex, m.emission_tex,
+                         m.heightmap_tex, m.normalmap_tex, m.alpha_tex};
+    for (int id : ids)
+      if (id < -1 || id >= (int)n_tex) { delete s; return nullptr; }
+  }
   if (n_xf == 0) {
     M34 id = {{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}}};
     s->o2w.assign(1, id); s->w2o.assign(1, id);
@@ -884,7 +963,10 @@ void* orc_scene_create(uint32_t n_verts, const float* verts, const float* normal
     std::memcpy(s->w2o.data(), w2o, 48ull * n_xf);
   }
   s->wtri.resize(3ull * n_faces);
+  s->face_alpha.assign(n_faces, 0);
   for (uint32_t f = 0; f < n_faces; ++f) {
+    const Material& fm = s->mats[s->mat_ids[f]];
+    s->face_alpha[f] = (fm.base_color_tex >= 0 || fm.alpha_tex >= 0) ? 1 : 0;
     const M34& m = s->o2w[s->inst_ids[f]];
     s->wtri[3 * f] = xform_point(m, s->verts[s->faces[f].x]);
     s->wtri[3 * f + 1] = xform_point(m, s->verts[s->faces[f].y]);
@@ -907,6 +989,14 @@ void orc_set_directional_light(void* h, int enable, const float* le, const float
   s->sun_dir = s->dir.dir;
 }
 void orc_set_sky_intensity(void* h, float v) { ((Scene*)h)->sky_intensity = v; }
+void orc_set_ibl(void* h, const float* rgba, uint32_t w, uint32_t hh)
+{
+  Scene* s = (Scene*)h;
+  s->has_ibl = rgba != nullptr;
+  if (!rgba) return;
+  s->ibl_data.assign(rgba, rgba + 4ull * w * hh);
+  s->ibl = fht_texture{nullptr, s->ibl_data.data(), w, hh, 0u};
+}
 void orc_set_hosek(void* h, int enable, float turbidity, float albedo)
 {
   Scene* s = (Scene*)h;
@@ -960,6 +1050,13 @@ void orc_post_process(const float* in, float* hi, float* tmp, int w, int h, int 
 {
   const PostParams pp{use_bloom, threshold, sigma, iso, ca};
   post_process(in, hi, tmp, w, h, pp, out);
+}
+void orc_tex2d(const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb, int n, const float* uv, float* out)
+{
+  float lut[256];
+  for (int i = 0; i < 256; ++i) lut[i] = fht_srgb_to_linear((float)i * (1.0f / 255.0f));
+  const fht_texture t{rgba8, nullptr, w, h, srgb ? 1u : 0u};
+  for (int i = 0; i < n; ++i) fht_tex2d(&t, lut, uv[2 * i], uv[2 * i + 1], out + 4 * i);
 }
 int orc_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 

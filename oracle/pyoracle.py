@@ -16,7 +16,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("oracle.cpp", "obsdf.h", "osampler.h", "ovec.h")] + [os.path.join(_HERE, "..", "include", "fh_elementary.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.cpp", "obsdf.h", "osampler.h", "ovec.h")] + [os.path.join(_HERE, "..", "include", "fh_elementary.h"), os.path.join(_HERE, "..", "include", "fh_texture_unit.h")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -138,6 +138,15 @@ def post_process(img, use_bloom, threshold, sigma, iso, ca):
     return out
 
 
+def tex2d(rgba8, srgb, uv):
+    """sample an 8-bit RGBA texture (H x W x 4) with the normative texture unit"""
+    img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((uv.shape[0], 4), dtype=np.float32)
+    lib().orc_tex2d(_p(img), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0]), int(bool(srgb)), int(uv.shape[0]), _p(uv), _p(out))
+    return out
+
+
 def hardware_threads():
     return lib().orc_hardware_threads()
 
@@ -161,10 +170,20 @@ class Scene:
             o2w = np.ascontiguousarray(o2w, dtype=np.float32).reshape(-1, 12)
             w2o = np.ascontiguousarray(w2o, dtype=np.float32).reshape(-1, 12)
             nxf = o2w.shape[0]
+        class _TexDesc(C.Structure):
+            _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgba8", C.c_void_p), ("srgb", C.c_int32)]
+
+        textures = scene.get("textures") or []
+        arr = (_TexDesc * max(len(textures), 1))()
+        keep = []
+        for k, tex in enumerate(textures):
+            img = np.ascontiguousarray(tex["rgba8"], dtype=np.uint8)
+            keep.append(img)
+            arr[k] = _TexDesc(img.shape[1], img.shape[0], img.ctypes.data, int(bool(tex.get("srgb", False))))
         self.h = L.orc_scene_create(C.c_uint32(v.shape[0]), _p(v), _p(n), _p(t), C.c_uint32(idx.shape[0]), _p(idx), _p(mid), _p(inst), C.c_uint32(mats.shape[0]), _p(mats),
-                                    C.c_uint32(nxf), _p(o2w), _p(w2o))
+                                    C.c_uint32(nxf), _p(o2w), _p(w2o), C.c_uint32(len(textures)), C.cast(arr, C.c_void_p))
         if not self.h:
-            raise RuntimeError("oracle: scene rejected (textures are not supported)")
+            raise RuntimeError("oracle: scene rejected (material references a texture id outside the texture list)")
         self.h = C.c_void_p(self.h)
 
     def __del__(self):
@@ -180,6 +199,13 @@ class Scene:
 
     def set_sky_intensity(self, v):
         lib().orc_set_sky_intensity(self.h, C.c_float(v))
+
+    def load_ibl(self, rgba32f):
+        img = np.ascontiguousarray(rgba32f, dtype=np.float32)
+        lib().orc_set_ibl(self.h, _p(img), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0]))
+
+    def clear_ibl(self):
+        lib().orc_set_ibl(self.h, None, 0, 0)
 
     def load_arhosek_sky(self, turbidity, albedo):
         lib().orc_set_hosek(self.h, 1, C.c_float(turbidity), C.c_float(albedo))

@@ -38,7 +38,8 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(N.CameraC) == 60
     assert C.sizeof(N.LayersC) == 48
     assert C.sizeof(N.PostParamsC) == 20
-    assert C.sizeof(N.SceneDesc) == 13 * 8
+    assert C.sizeof(N.SceneDesc) == 13 * 8 + 16
+    assert C.sizeof(N.TextureDesc) == 24
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -302,3 +302,54 @@ def test_post_process_floor_division_quirk(oracle):
     assert (inner >= 0).all() and (inner <= 1.0001).all() and (out[:32, :48, 3] == 1).all()
     plain = oracle.post_process(img, False, 2.0, 5.0, 80.0, 1.0)
     assert (plain[:32, :48, :3] <= inner + 1e-6).all()  # bloom only adds light
+
+
+# ---------------------------------------------------------------- software texture unit (include/fh_texture_unit.h)
+def test_texture_unit_follows_documented_cuda_filtering(oracle):
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    h, w = img.shape[:2]
+    # texel centres return the texel (normalised float read mode, cwl/texture.h:35-47)
+    uv = np.array([[(x + 0.5) / w, (y + 0.5) / h] for y in range(h) for x in range(w)], np.float32)
+    got = oracle.tex2d(img, False, uv).reshape(h, w, 4)
+    assert np.allclose(got, img.astype(np.float32) / 255.0, atol=1e-6)
+    # wrap addressing: shifting by whole periods changes nothing
+    assert np.array_equal(oracle.tex2d(img, False, uv + np.float32(3.0)), oracle.tex2d(img, False, uv - np.float32(2.0)))
+    # halfway between two texel centres: the mean of the two (weights have 8 fractional bits, 0.5 is exact)
+    mid = np.array([[1.0 / w, 0.5 / h]], np.float32)
+    assert np.allclose(oracle.tex2d(img, False, mid)[0], (img[0, 0].astype(np.float32) + img[0, 1]) / 510.0, atol=1e-6)
+    # the left edge blends with the texel that wraps around
+    edge = np.array([[0.0, 0.5 / h]], np.float32)
+    assert np.allclose(oracle.tex2d(img, False, edge)[0], (img[0, 0].astype(np.float32) + img[0, w - 1]) / 510.0, atol=1e-6)
+    # sRGB textures: colour channels are decoded per texel before filtering, alpha stays linear
+    c = img[2, 3].astype(np.float64) / 255.0
+    want = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    got = oracle.tex2d(img, True, np.array([[3.5 / w, 2.5 / h]], np.float32))[0]
+    assert np.allclose(got[:3], want[:3], atol=1e-6) and abs(got[3] - c[3]) < 1e-6
+
+
+def test_alpha_cutout_lets_rays_through(oracle):
+    sc = scenes.textured_cornell_box()
+    S = oracle.Scene(sc)
+    # rays from the room centre towards the cut-out card at z = -0.5: some pass through to the back wall (z = -1)
+    n = 4000
+    rng = np.random.default_rng(3)
+    o = np.tile(np.array([-0.2, 1.3, 0.5], np.float32), (n, 1))
+    tgt = np.stack([rng.uniform(-0.6, 0.2, n), rng.uniform(0.9, 1.7, n), np.full(n, -0.5)], axis=1).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d, np.full((n, 1), 1e9, np.float32)], axis=1).astype(np.float32)
+    tuv, prim = S.trace(rays)
+    opaque = scenes.textured_cornell_box()
+    opaque["materials"]["alpha_texture_id"][:] = -1
+    opaque["materials"]["base_color_texture_id"][9] = -1
+    tuv0, prim0 = oracle.Scene(opaque).trace(rays)
+    on_card0 = (prim0 == 36) | (prim0 == 37)
+    on_card = (prim == 36) | (prim == 37)
+    assert on_card0.mean() > 0.3 and not (on_card & ~on_card0).any()
+    through = on_card0 & ~on_card
+    assert 0.2 < through.sum() / on_card0.sum() < 0.8      # transparent checker cells
+    assert (tuv[through, 0] > tuv0[through, 0]).all()      # those rays continue to something behind the card
+    assert np.array_equal(tuv[~on_card0].view(np.uint32), tuv0[~on_card0].view(np.uint32))
+    tuv_b, prim_b = S.trace(rays, brute=True)
+    assert np.array_equal(prim, prim_b)
