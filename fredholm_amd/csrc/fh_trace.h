@@ -66,6 +66,7 @@ FH_D bool tri_test(const RayPre& r, f3 p0, f3 p1, f3 p2, float& t, float& bu, fl
   const float rcp = 1.0f / det;
   t = T * rcp;
   if (!(t >= 0.0f)) return false;
+  t = fabsf(t);  // -0.0 -> +0.0: hit distances order like their bit patterns
   bu = V * rcp;
   bv = W * rcp;
   return true;
@@ -331,6 +332,278 @@ FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
     }
   }
   return found;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-cooperative BVH8 traversal.  In the per-lane loop above a triangle test runs with 3-6 of 64 lanes
+// active (a node produces ~0.3 candidate triangles per lane), so more than half of a wave's issue slots
+// go to nearly empty triangle tests.  Here candidate triangles are not tested by the lane that found
+// them: they go into a wave-private LDS queue as (owner lane, triangle), and once the queue holds
+// `flush` entries ALL lanes take one entry each, fetch the owner's ray from LDS and test it.  The closest
+// hit of every ray lives in LDS as one 64-bit key (t bits << 32 | face id): the closest-hit order
+// "t, then lowest face id" is the unsigned order of that key for t >= 0, so concurrent testers commit with
+// ds_min_u64 and the lane whose key survives also stores the barycentrics.  The result is the minimum over
+// the same candidate set as the per-lane loop, i.e. bit-identical.  Must be called by all 64 lanes of a
+// wave together (lanes without a ray pass valid = false).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kCoopQueue = 128;      // ring of (triangle << 6 | owner lane); >= 64 + flush threshold
+constexpr uint32_t kCoopMaxTris = 1u << 26;
+struct CoopLds {            // per-wave slices of the block's LDS
+  float4* ray;              // [2][64]: (o.xyz, Sx), (Sy, Sz, kx|ky<<2|kz<<4, -)
+  unsigned long long* key;  // [64]
+  float2* uv;               // [64]
+  uint32_t* queue;          // [kCoopQueue]
+};
+constexpr uint32_t kCoopLdsBytesPerWave = 64 * 32 + 64 * 8 + 64 * 8 + kCoopQueue * 4;
+FH_D CoopLds coop_lds(unsigned char* block_lds, uint32_t wave_in_block)
+{
+  unsigned char* b = block_lds + (size_t)wave_in_block * kCoopLdsBytesPerWave;
+  CoopLds c;
+  c.ray = (float4*)b;
+  c.key = (unsigned long long*)(b + 64 * 32);
+  c.uv = (float2*)(b + 64 * 32 + 64 * 8);
+  c.queue = (uint32_t*)(b + 64 * 32 + 64 * 8 + 64 * 8);
+  return c;
+}
+
+// one queued candidate: test triangle (e >> 6) against the ray of lane (e & 63), commit into that lane's LDS record
+template <bool ANY_HIT, bool COUNT, bool ALPHA>
+FH_D void coop_test(const Bvh8Dev& bvh, const CoopLds& cl, uint32_t e, uint32_t& n_tris, WaveSteps* ws, const SceneDev* sc)
+{
+  const uint32_t owner = e & 63u;
+  const size_t ti = 3 * (size_t)(e >> 6);
+  const float4 a = bvh.tris[ti], bb = bvh.tris[ti + 1], c = bvh.tris[ti + 2];
+  if (COUNT) { n_tris++; if (ws && first_active_lane()) ws->tri++; }
+  const float4 r0 = cl.ray[owner], r1 = cl.ray[64 + owner];
+  if (ANY_HIT && r1.w != 0.0f && (uint32_t)cl.key[owner] != 0xffffffffu) return;  // the owner's ray stops at its first hit and has one
+  RayPre rp;
+  rp.o = mk3(r0.x, r0.y, r0.z);
+  rp.Sx = r0.w; rp.Sy = r1.x; rp.Sz = r1.y;
+  const uint32_t kk = __float_as_uint(r1.z);
+  rp.kx = (int)(kk & 3u); rp.ky = (int)((kk >> 2) & 3u); rp.kz = (int)((kk >> 4) & 3u);
+  float t, bu, bv;
+  if (!tri_test(rp, mk3(a), mk3(bb), mk3(c), t, bu, bv)) return;
+  const uint32_t prim = __float_as_uint(a.w);
+  const unsigned long long mine = ((unsigned long long)__float_as_uint(t) << 32) | prim;
+  if (mine >= cl.key[owner]) return;  // also rejects t > tmax: the record starts at (tmax, 0xffffffff)
+  if (ALPHA && bb.w != 0.0f && !alpha_pass(*sc, prim, bu, bv)) return;
+  atomicMin(&cl.key[owner], mine);
+  if (cl.key[owner] == mine) cl.uv[owner] = make_float2(bu, bv);
+}
+
+template <bool ANY_HIT, bool COUNT, bool LDS, bool ALPHA>
+FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws, const CoopLds& cl,
+                             uint32_t flush, uint2* lds_column, int lds_stride, const SceneDev* sc)
+{
+  const uint32_t lane = __lane_id();
+  if (!valid) { o = mk3(0.0f); d = mk3(0.0f, 0.0f, 1.0f); tmax = 0.0f; }
+  const RayPre rp = ray_prepare(o, d);
+  const Ray8 r = ray8_prepare(rp, d);
+  cl.ray[lane] = make_float4(rp.o.x, rp.o.y, rp.o.z, rp.Sx);
+  cl.ray[64 + lane] = make_float4(rp.Sy, rp.Sz, __uint_as_float((uint32_t)rp.kx | ((uint32_t)rp.ky << 2) | ((uint32_t)rp.kz << 4)), ANY_HIT ? 1.0f : 0.0f);
+  const unsigned long long key0 = ((unsigned long long)__float_as_uint(tmax) << 32) | 0xffffffffull;
+  cl.key[lane] = key0;
+  cl.uv[lane] = make_float2(0.0f, 0.0f);
+  GroupStack<LDS> stack(lds_column, lds_stride);
+  uint2 group = make_uint2(0u, (valid && bvh.n_nodes) ? 0x80000000u : 0u);
+  bool done = !(valid && bvh.n_nodes);
+  uint32_t q_head = 0, q_count = 0;  // wave-uniform
+  float best_t = tmax;
+  for (;;) {
+    uint2 tg = make_uint2(0u, 0u);
+    if (!done && (group.y & 0xff000000u) == 0u) {
+      if (stack.sp == 0) done = true;
+      else group = stack.pop();
+    }
+    if (!done) {
+      const unsigned long long k = cl.key[lane];
+      best_t = __uint_as_float((uint32_t)(k >> 32));
+      if (ANY_HIT && (uint32_t)k != 0xffffffffu) done = true;
+    }
+    if (!done) {
+      const uint32_t hits_imask = group.y;
+      const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
+      group.y &= ~(1u << bit);
+      if (group.y & 0xff000000u) stack.push(group);
+      const uint32_t slot = (bit - 24u) ^ (r.oct4 & 7u);
+      const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+      const uint32_t ni = group.x + rel;
+      const uint4 n0 = bvh.nodes[5 * (size_t)ni], n1 = bvh.nodes[5 * (size_t)ni + 1], n2 = bvh.nodes[5 * (size_t)ni + 2], n3 = bvh.nodes[5 * (size_t)ni + 3],
+                  n4 = bvh.nodes[5 * (size_t)ni + 4];
+      if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
+      const uint32_t hm = node8_test(r, n0, n1, n2, n3, n4, best_t);
+      group = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
+      tg = make_uint2(n1.y, hm & 0x00ffffffu);
+    }
+    // hand the candidate triangles to the wave's queue, one per lane and round
+    for (;;) {
+      const bool has = tg.y != 0u;
+      const unsigned long long m = __ballot(has);
+      if (m == 0ull) break;
+      if (has) {
+        const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
+        tg.y &= tg.y - 1u;
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        cl.queue[(q_head + q_count + pos) & (kCoopQueue - 1u)] = ((tg.x + b) << 6) | lane;
+      }
+      q_count += (uint32_t)__popcll(m);
+      if (q_count >= 64u) {
+        const uint32_t e = cl.queue[(q_head + lane) & (kCoopQueue - 1u)];
+        q_head = (q_head + 64u) & (kCoopQueue - 1u);
+        q_count -= 64u;
+        coop_test<ANY_HIT, COUNT, ALPHA>(bvh, cl, e, n_tris, ws, sc);
+      }
+    }
+    const bool more = __ballot(!done) != 0ull;
+    if (q_count && (q_count >= flush || !more)) {
+      const uint32_t n = q_count;  // < 64 here
+      if (lane < n) {
+        const uint32_t e = cl.queue[(q_head + lane) & (kCoopQueue - 1u)];
+        coop_test<ANY_HIT, COUNT, ALPHA>(bvh, cl, e, n_tris, ws, sc);
+      }
+      q_head = (q_head + n) & (kCoopQueue - 1u);
+      q_count = 0u;
+    }
+    if (!more) break;
+  }
+  const unsigned long long k = cl.key[lane];
+  const float2 uv = cl.uv[lane];
+  best.t = __uint_as_float((uint32_t)(k >> 32));
+  best.u = uv.x; best.v = uv.y;
+  best.prim = (uint32_t)k;
+  return valid && best.prim != 0xffffffffu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming form of the wave-cooperative traversal.  Rays differ a lot in length (the longest of 64 is
+// ~3x the mean), so a wave that traces one fixed batch runs its node tests with a third of its lanes.
+// Here a wave owns a long private sequence of work items and hands a new ray to lanes whose ray has
+// finished as soon as `refill` of them are idle -- no global atomics, the cursor is wave-uniform.
+// The policy object supplies the work:
+//   bool advance(o, d, tmax, any)      lane-local: the next ray of the lane's current item (a path's next secondary ray), if any
+//   bool take(s, o, d, tmax, any)      the s-th item of the wave's sequence (s = pol.cursor + rank among the asking lanes)
+//   void commit(hit, h, nodes)         once per ray, after its last candidate was tested
+//   bool drained()                     wave-uniform: the sequence has no item at pol.cursor or beyond
+//   bool followup()                    the lane's current item may have another ray after the current one
+//   uint32_t cursor                    wave-uniform position in the sequence
+// ---------------------------------------------------------------------------------------------
+template <bool MIXED, bool COUNT, bool LDS, bool ALPHA, class Policy>
+FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws, const CoopLds& cl, uint32_t flush, uint32_t refill,
+                          uint2* lds_column, int lds_stride, const SceneDev* sc)
+{
+  const uint32_t lane = __lane_id();
+  GroupStack<LDS> stack(lds_column, lds_stride);
+  Ray8 r;
+  r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct4 = 0u; r.nx = r.ny = r.nz = false;
+  uint2 group = make_uint2(0u, 0u);
+  bool busy = false;  // the lane's ray still has nodes to visit
+  bool have = false;  // the lane holds a ray that is not committed yet
+  bool any = false;   // the lane's ray stops at the first accepted hit
+  uint32_t q_head = 0, q_count = 0;  // wave-uniform
+  bool dry = false;                  // wave-uniform: a refill found no work at all
+  uint32_t ray_n0 = 0;               // instrumented build: node counter when the lane's ray started
+  cl.key[lane] = 0ull;
+  for (;;) {
+    const unsigned long long idle = __ballot(!busy);
+    const uint32_t n_idle = (uint32_t)__popcll(idle);
+    if (n_idle == 64u || (!dry && n_idle >= refill)) {
+      // every candidate of a finished ray must be tested before the ray is committed: drain the queue
+      while (q_count) {
+        const uint32_t n = q_count < 64u ? q_count : 64u;
+        if (lane < n) coop_test<MIXED, COUNT, ALPHA>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
+        q_head = (q_head + n) & (kCoopQueue - 1u);
+        q_count -= n;
+      }
+      if (have && !busy) {
+        const unsigned long long k = cl.key[lane];
+        const float2 uv = cl.uv[lane];
+        HitRec h;
+        h.t = __uint_as_float((uint32_t)(k >> 32)); h.u = uv.x; h.v = uv.y; h.prim = (uint32_t)k;
+        pol.commit(h.prim != 0xffffffffu, h, n_nodes - ray_n0);
+        have = false;
+      }
+      if (!dry) {
+        const bool want = !have;
+        f3 o = mk3(0.0f), d = mk3(0.0f, 0.0f, 1.0f);
+        float tmax = 0.0f;
+        bool got = false;
+        if (want) got = pol.advance(o, d, tmax, any);  // next ray of the lane's own item, if it has one
+        const bool need = want && !got;
+        const unsigned long long nm = __ballot(need);
+        if (nm != 0ull && !pol.drained()) {  // (the cursor stops at the end of the sequence)
+          const uint32_t base = pol.cursor;
+          if (need) got = pol.take(base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u)), o, d, tmax, any);
+          pol.cursor = base + (uint32_t)__popcll(nm);
+        }
+        if (got) {
+          const RayPre rp = ray_prepare(o, d);
+          r = ray8_prepare(rp, d);
+          cl.ray[lane] = make_float4(rp.o.x, rp.o.y, rp.o.z, rp.Sx);
+          cl.ray[64 + lane] = make_float4(rp.Sy, rp.Sz, __uint_as_float((uint32_t)rp.kx | ((uint32_t)rp.ky << 2) | ((uint32_t)rp.kz << 4)), (MIXED && any) ? 1.0f : 0.0f);
+          cl.key[lane] = ((unsigned long long)__float_as_uint(tmax) << 32) | 0xffffffffull;
+          cl.uv[lane] = make_float2(0.0f, 0.0f);
+          stack.sp = 0;
+          have = true;
+          group = make_uint2(0u, 0x80000000u);
+          busy = bvh.n_nodes != 0u;
+          if (COUNT) ray_n0 = n_nodes;
+        }
+        if (__ballot(got) == 0ull && pol.drained() && __ballot(have && pol.followup()) == 0ull) dry = true;
+      }
+      if (__ballot(busy) == 0ull) {
+        if (__ballot(have) == 0ull && dry) break;
+        continue;  // only rays without node work (empty BVH) or nothing fetched yet: commit / fetch again
+      }
+    }
+    uint2 tg = make_uint2(0u, 0u);
+    if (busy && (group.y & 0xff000000u) == 0u) {
+      if (stack.sp == 0) busy = false;
+      else group = stack.pop();
+    }
+    float best_t = 0.0f;
+    if (busy) {
+      const unsigned long long k = cl.key[lane];
+      best_t = __uint_as_float((uint32_t)(k >> 32));
+      if (MIXED && any && (uint32_t)k != 0xffffffffu) busy = false;
+    }
+    if (busy) {
+      const uint32_t hits_imask = group.y;
+      const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
+      group.y &= ~(1u << bit);
+      if (group.y & 0xff000000u) stack.push(group);
+      const uint32_t slot = (bit - 24u) ^ (r.oct4 & 7u);
+      const uint32_t ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+      const uint4 n0 = bvh.nodes[5 * (size_t)ni], n1 = bvh.nodes[5 * (size_t)ni + 1], n2 = bvh.nodes[5 * (size_t)ni + 2], n3 = bvh.nodes[5 * (size_t)ni + 3],
+                  n4 = bvh.nodes[5 * (size_t)ni + 4];
+      if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
+      const uint32_t hm = node8_test(r, n0, n1, n2, n3, n4, best_t);
+      group = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
+      tg = make_uint2(n1.y, hm & 0x00ffffffu);
+    }
+    for (;;) {
+      const bool has = tg.y != 0u;
+      const unsigned long long m = __ballot(has);
+      if (m == 0ull) break;
+      if (has) {
+        const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
+        tg.y &= tg.y - 1u;
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        cl.queue[(q_head + q_count + pos) & (kCoopQueue - 1u)] = ((tg.x + b) << 6) | lane;
+      }
+      q_count += (uint32_t)__popcll(m);
+      if (q_count >= 64u) {
+        coop_test<MIXED, COUNT, ALPHA>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
+        q_head = (q_head + 64u) & (kCoopQueue - 1u);
+        q_count -= 64u;
+      }
+    }
+    if (q_count >= flush) {
+      const uint32_t n = q_count;  // < 64 here
+      if (lane < n) coop_test<MIXED, COUNT, ALPHA>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
+      q_head = (q_head + n) & (kCoopQueue - 1u);
+      q_count = 0u;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

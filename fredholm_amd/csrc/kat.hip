@@ -167,6 +167,23 @@ __global__ void k_trace_batch(SceneDev sc, uint32_t n, const float* rays7, int a
   prim[i] = ok ? h.prim : 0xffffffffu;
 }
 
+// same batch through the wave-cooperative traversal the render kernels use (all 64 lanes of a wave enter together)
+template <bool ANY, bool ALPHA>
+__global__ void __launch_bounds__(256) k_trace_batch_coop(SceneDev sc, uint32_t n, const float* rays7, float* tuv, uint32_t* prim, uint32_t flush)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kCoopLdsBytesPerWave];
+  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  const float* r = rays7 + 7 * (size_t)(valid ? i : 0u);
+  HitRec h;
+  uint32_t a = 0, b = 0;
+  const bool ok = traverse_bvh8_coop<ANY, false, false, ALPHA>(sc.bvh8, valid, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], h, a, b, nullptr, cl, flush, nullptr, 0, &sc);
+  if (!valid) return;
+  tuv[3 * i] = ok ? h.t : 0.0f; tuv[3 * i + 1] = ok ? h.u : 0.0f; tuv[3 * i + 2] = ok ? h.v : 0.0f;
+  prim[i] = ok ? h.prim : 0xffffffffu;
+}
+
 uint32_t blocks(uint32_t n) { return (n + 255) / 256; }
 
 }  // namespace
@@ -188,7 +205,19 @@ int fh_trace_rays(fh_ctx* ctx, uint32_t n, const float* rays7, int any_hit, floa
   Tmp<float> r, t;
   Tmp<uint32_t> p;
   FH_HIP(r.up(rays7, 7ull * n)); FH_HIP(t.up(nullptr, 3ull * n)); FH_HIP(p.up(nullptr, n));
-  hipLaunchKernelGGL(k_trace_batch, dim3(blocks(n)), dim3(256), 0, ctx->stream, scene_dev(ctx), n, r.p, any_hit, t.p, p.p);
+  const SceneDev sd = scene_dev(ctx);
+  uint32_t flush = 8u;
+  if (const char* e = getenv("FH_COOP_T")) { const int v = atoi(e); if (v >= 1 && v <= 64) flush = (uint32_t)v; }
+  const char* coop_env = getenv("FH_COOP");
+  if (sd.use_bvh8 && sd.bvh8.n_tris < kCoopMaxTris && !(coop_env && coop_env[0] == '0')) {
+    const dim3 g(blocks(n)), b(256);
+    if (any_hit && sd.has_alpha) hipLaunchKernelGGL((k_trace_batch_coop<true, true>), g, b, 0, ctx->stream, sd, n, r.p, t.p, p.p, flush);
+    else if (any_hit) hipLaunchKernelGGL((k_trace_batch_coop<true, false>), g, b, 0, ctx->stream, sd, n, r.p, t.p, p.p, flush);
+    else if (sd.has_alpha) hipLaunchKernelGGL((k_trace_batch_coop<false, true>), g, b, 0, ctx->stream, sd, n, r.p, t.p, p.p, flush);
+    else hipLaunchKernelGGL((k_trace_batch_coop<false, false>), g, b, 0, ctx->stream, sd, n, r.p, t.p, p.p, flush);
+  } else {
+    hipLaunchKernelGGL(k_trace_batch, dim3(blocks(n)), dim3(256), 0, ctx->stream, sd, n, r.p, any_hit, t.p, p.p);
+  }
   FH_HIP(hipStreamSynchronize(ctx->stream));
   FH_HIP(t.down(tuv)); FH_HIP(p.down(prim));
   return FH_OK;

@@ -162,6 +162,94 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, Po
   }
 }
 
+// closest hit over the 8-wide BVH, wave-cooperative triangle tests (fh_trace.h: traverse_bvh8_coop)
+template <bool COUNT, bool ALPHA>
+__global__ void __launch_bounds__(kBlock) k_trace_closest_coop(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
+  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  const uint32_t* cnt = pool.counters + depth * kCounterStride;
+  const uint32_t count = cnt[CNT_RAD];
+  const uint32_t* q = pool.q_rad[depth & 1u];
+  uint32_t nn = 0, nt = 0, nr = 0;
+  WaveSteps ws;
+  // the loop bound is per wave, so that all 64 lanes enter the traversal together
+  for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < count; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + (threadIdx.x & 63u);
+    const bool valid = i < count;
+    const uint32_t p = valid ? q[i] : 0u;
+    if (COUNT && valid) nr++;
+    const float4 o = valid ? pool.ray_o[p] : make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = valid ? pool.ray_d[p] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+    HitRec h;
+    const uint32_t nn0 = nn;
+    traverse_bvh8_coop<false, COUNT, false, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, nullptr, 0, &sc);
+    if (COUNT && valid) { const uint32_t k = nn - nn0; int b = 0; while (b < 7 && k > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
+    if (valid) pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+  }
+  if (COUNT) {
+    atomicAdd(tc.nodes, (unsigned long long)nn);
+    atomicAdd(tc.tris, (unsigned long long)nt);
+    atomicAdd(tc.rays, (unsigned long long)nr);
+    if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
+    if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming kernels (fh_trace.h: traverse_stream): the grid is sized to the resident wave slots of the chip and wave w
+// owns the strided sequence  s -> (s / 64) * (64 * n_waves) + 64 * w + s % 64  of queue positions, so a launch of any size
+// is covered, neighbouring lanes read neighbouring queue entries, and finished lanes get their next ray without atomics.
+FH_D uint32_t stream_index(uint32_t s, uint32_t wave, uint32_t n_waves) { return (s >> 6) * (n_waves << 6) + (wave << 6) + (s & 63u); }
+
+template <bool COUNT>
+struct ClosestStream {
+  const PoolDev& pool;
+  const uint32_t* q;
+  uint32_t count, wave, n_waves;
+  uint32_t cursor = 0;
+  uint32_t p = 0;
+  uint32_t n_rays = 0;
+  unsigned long long* hist;
+  FH_D ClosestStream(const PoolDev& pl, const uint32_t* qq, uint32_t c, uint32_t w, uint32_t nw, unsigned long long* hs) : pool(pl), q(qq), count(c), wave(w), n_waves(nw), hist(hs) {}
+  FH_D bool advance(f3&, f3&, float&, bool&) { return false; }
+  FH_D bool take(uint32_t s, f3& o, f3& d, float& tmax, bool& any)
+  {
+    const uint32_t i = stream_index(s, wave, n_waves);
+    if (i >= count) return false;
+    p = q[i];
+    const float4 o4 = pool.ray_o[p], d4 = pool.ray_d[p];
+    o = mk3(o4); d = mk3(d4); tmax = o4.w; any = false;
+    if (COUNT) n_rays++;
+    return true;
+  }
+  FH_D void commit(bool, const HitRec& h, uint32_t nodes)
+  {
+    pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+    if (COUNT) { int b = 0; while (b < 7 && nodes > (8u << b)) ++b; atomicAdd(hist + b, 1ull); }
+  }
+  FH_D bool drained() const { return stream_index(cursor, wave, n_waves) >= count; }
+  FH_D bool followup() const { return false; }
+};
+
+template <bool COUNT, bool ALPHA>
+__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
+  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  const uint32_t count = pool.counters[depth * kCounterStride + CNT_RAD];
+  uint32_t nn = 0, nt = 0;
+  WaveSteps ws;
+  ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], count, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6, tc.hist);
+  traverse_stream<false, COUNT, false, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, nullptr, 0, &sc);
+  if (COUNT) {
+    atomicAdd(tc.nodes, (unsigned long long)nn);
+    atomicAdd(tc.tris, (unsigned long long)nt);
+    atomicAdd(tc.rays, (unsigned long long)pol.n_rays);
+    if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
+    if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
+  }
+}
+
 // closest hit over the 8-wide BVH: persistent waves with dynamic fetch
 constexpr uint32_t kRefill = 20;  // refill a wave's idle lanes once this many are idle
 
@@ -639,6 +727,148 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
   }
 }
 
+// secondary rays over the 8-wide BVH with wave-cooperative triangle tests: a lane owns one shaded path and walks its
+// secondary-ray slots in the reference's order; a slot is traversed by the whole wave when any lane has a ray in it
+template <bool COUNT, bool LIGHTS, bool ALPHA>
+__global__ void __launch_bounds__(kBlock) k_trace_secondary_coop(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush)
+{
+  __shared__ uint2 lds_stack[kLdsStack * kBlock];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
+  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
+  constexpr bool has_lights = LIGHTS;
+  uint32_t nn = 0, nt = 0, nr = 0;
+  WaveSteps ws;
+  for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < count; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + (threadIdx.x & 63u);
+    const bool in_range = i < count;
+    const uint32_t p = in_range ? pool.q_sec[i] : 0u;
+    f3 L = in_range ? mk3(pool.rad[p]) : mk3(0.0f);
+#pragma unroll
+    for (uint32_t slot = SEC_DIR; slot <= SEC_LIGHT; ++slot) {
+      if (slot == SEC_DIR && !fr.has_dir) continue;
+      if (slot == SEC_AREA && !has_lights) continue;
+      const size_t k = (size_t)slot * pool.capacity + p;
+      const float4 d = in_range ? pool.sec_d[k] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+      const bool valid = in_range && d.w != 0.0f;
+      if (__ballot(valid) == 0ull) continue;
+      const float4 o = valid ? pool.sec_o[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      HitRec h;
+      if (COUNT && valid) nr++;
+      if (slot == SEC_LIGHT && has_lights) {
+        const bool hit = traverse_bvh8_coop<false, COUNT, true, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, lds_stack + threadIdx.x, kBlock, &sc);
+        if (valid) {
+          const float4 la = pool.lp_a[p], lb = pool.lp_b[p];
+          L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, mk3(o), mk3(d), hit, h);
+        }
+      } else {
+        const uint32_t nn0 = nn;
+        const bool occluded = traverse_bvh8_coop<true, COUNT, true, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, lds_stack + threadIdx.x, kBlock, &sc);
+        if (COUNT && valid) { const uint32_t kk = nn - nn0; int b = 0; while (b < 7 && kk > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
+        if (valid && !occluded) L += mk3(pool.sec_c[k]);
+      }
+    }
+    if (in_range) pool.rad[p] = mk4(L, 0.0f);
+  }
+  if (COUNT) {
+    atomicAdd(tc.nodes, (unsigned long long)nn);
+    atomicAdd(tc.tris, (unsigned long long)nt);
+    atomicAdd(tc.rays, (unsigned long long)nr);
+    if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
+    if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
+  }
+}
+
+// secondary rays, streaming: a lane's item is one shaded path; its secondary-ray slots are traced one after the other by the
+// same lane, so the additions into the path's radiance keep the reference's order (directional, sky, area, BSDF-sampled)
+template <bool COUNT, bool LIGHTS>
+struct SecondaryStream {
+  const SceneDev& sc;
+  const FrameDev& fr;
+  const PoolDev& pool;
+  uint32_t count, wave, n_waves;
+  uint32_t cursor = 0;
+  uint32_t p = 0, slot = 0;
+  bool active = false;
+  f3 L;
+  uint32_t n_rays = 0;
+  unsigned long long* hist;
+  FH_D SecondaryStream(const SceneDev& s, const FrameDev& f, const PoolDev& pl, uint32_t c, uint32_t w, uint32_t nw, unsigned long long* hs)
+      : sc(s), fr(f), pool(pl), count(c), wave(w), n_waves(nw), L(mk3(0.0f)), hist(hs) {}
+  // first slot >= from of path p that holds a ray
+  FH_D bool scan(uint32_t from, f3& o, f3& d, float& tmax, bool& any)
+  {
+    for (uint32_t s = from; s <= SEC_LIGHT; ++s) {
+      if (s == SEC_DIR && !fr.has_dir) continue;
+      if (s == SEC_AREA && !LIGHTS) continue;
+      const size_t k = (size_t)s * pool.capacity + p;
+      const float4 d4 = pool.sec_d[k];
+      if (d4.w == 0.0f) continue;
+      const float4 o4 = pool.sec_o[k];
+      o = mk3(o4); d = mk3(d4); tmax = o4.w;
+      any = !(s == SEC_LIGHT && LIGHTS);
+      slot = s;
+      if (COUNT) n_rays++;
+      return true;
+    }
+    return false;
+  }
+  FH_D void finish() { if (active) { pool.rad[p] = mk4(L, 0.0f); active = false; } }
+  FH_D bool advance(f3& o, f3& d, float& tmax, bool& any)
+  {
+    if (!active) return false;
+    if (scan(slot + 1u, o, d, tmax, any)) return true;
+    finish();
+    return false;
+  }
+  FH_D bool take(uint32_t s, f3& o, f3& d, float& tmax, bool& any)
+  {
+    const uint32_t i = stream_index(s, wave, n_waves);
+    if (i >= count) return false;
+    p = pool.q_sec[i];
+    L = mk3(pool.rad[p]);
+    active = true;
+    if (scan(0u, o, d, tmax, any)) return true;
+    active = false;  // a path without secondary rays: its radiance stays as it is
+    return false;
+  }
+  FH_D void commit(bool hit, const HitRec& h, uint32_t nodes)
+  {
+    const size_t k = (size_t)slot * pool.capacity + p;
+    if (slot == SEC_LIGHT && LIGHTS) {
+      const float4 o = pool.sec_o[k], d = pool.sec_d[k];
+      const float4 la = pool.lp_a[p], lb = pool.lp_b[p];
+      L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, mk3(o), mk3(d), hit, h);
+    } else {
+      if (COUNT) { int b = 0; while (b < 7 && nodes > (8u << b)) ++b; atomicAdd(hist + b, 1ull); }
+      if (!hit) L += mk3(pool.sec_c[k]);
+    }
+  }
+  FH_D bool drained() const { return stream_index(cursor, wave, n_waves) >= count; }
+  FH_D bool followup() const { return active && slot < SEC_LIGHT; }
+};
+
+template <bool COUNT, bool LIGHTS, bool ALPHA>
+__global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill)
+{
+  __shared__ uint2 lds_stack[kLdsStack * kBlock];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
+  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
+  uint32_t nn = 0, nt = 0;
+  WaveSteps ws;
+  SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, count, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6, tc.hist);
+  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
+  pol.finish();
+  if (COUNT) {
+    atomicAdd(tc.nodes, (unsigned long long)nn);
+    atomicAdd(tc.tris, (unsigned long long)nt);
+    atomicAdd(tc.rays, (unsigned long long)pol.n_rays);
+    if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
+    if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
+  }
+}
+
 // secondary rays over the 8-wide BVH: persistent waves, a lane owns one shaded path at a time and
 // walks its secondary-ray slots in order, so the additions into the path's radiance keep the
 // reference's order (directional, sky, area, BSDF-sampled) without atomics.
@@ -981,6 +1211,20 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   FH_HIP(hipGetDeviceProperties(&prop, ctx->device));
   const uint32_t persistent_grid = (uint32_t)prop.multiProcessorCount * 8u;  // 8 blocks of 4 waves per CU: every wave resident
   const bool wide = sc.use_bvh8 != 0 && getenv("FH_PERSISTENT") != nullptr;  // experimental persistent/dynamic-fetch kernels
+  // wave-cooperative triangle tests (default for the wide BVH); FH_COOP=0 selects the per-lane loop, FH_COOP_T the flush threshold
+  uint32_t coop_flush = 8u;
+  if (const char* e = getenv("FH_COOP_T")) { const int v = atoi(e); if (v >= 1 && v <= 64) coop_flush = (uint32_t)v; }
+  const char* coop_env = getenv("FH_COOP");
+  const bool coop = sc.use_bvh8 != 0 && !wide && sc.bvh8.n_tris < kCoopMaxTris && !(coop_env && coop_env[0] == '0');
+  // streaming form: FH_STREAM=0 falls back to one fixed batch per wave; FH_STREAM_GRID blocks, FH_STREAM_REFILL idle lanes
+  const char* stream_env = getenv("FH_STREAM");
+  const bool stream = coop && !(stream_env && stream_env[0] == '0');
+  // 5 blocks (20 waves) per CU: all resident at the kernels' LDS / register budgets, and measured faster than 8 (fewer cache conflicts)
+  uint32_t stream_grid = (uint32_t)prop.multiProcessorCount * 5u, stream_refill = 24u;
+  uint32_t exp_lds = 0;  // experiment: extra dynamic LDS per block to lower the occupancy
+  if (const char* e = getenv("FH_EXP_LDS")) exp_lds = (uint32_t)atoi(e);
+  if (const char* e = getenv("FH_STREAM_GRID")) { const int v = atoi(e); if (v >= 8 && v <= 8192) stream_grid = (uint32_t)v & ~7u; }
+  if (const char* e = getenv("FH_STREAM_REFILL")) { const int v = atoi(e); if (v >= 1 && v <= 64) stream_refill = (uint32_t)v; }
 
   for (uint32_t done = 0; done < n_samples; done += batch) {
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
@@ -1010,6 +1254,15 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         if (wide) {
           if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
           else hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+        } else if (stream) {
+          with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
+            hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc, pool, depth, tc_closest,
+                               coop_flush, stream_refill);
+          }); });
+        } else if (coop) {
+          with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
+            hipLaunchKernelGGL((k_trace_closest_coop<decltype(C)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest, coop_flush);
+          }); });
         } else {
           with_bool(count, [&](auto C) { with_bool(sc.use_bvh8 != 0, [&](auto W) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_closest_static<decltype(C)::value, decltype(W)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
@@ -1031,6 +1284,16 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
           else if (count) hipLaunchKernelGGL((k_trace_secondary<true, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
           else if (lights) hipLaunchKernelGGL((k_trace_secondary<false, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
           else hipLaunchKernelGGL((k_trace_secondary<false, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
+        } else if (stream) {
+          with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
+            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc,
+                               fr, pool, depth, tc_shadow, coop_flush, stream_refill);
+          }); }); });
+        } else if (coop) {
+          with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
+            hipLaunchKernelGGL((k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow,
+                               coop_flush);
+          }); }); });
         } else {
           with_bool(count, [&](auto C) { with_bool(sc.use_bvh8 != 0, [&](auto W) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_secondary_static<decltype(C)::value, decltype(W)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, fr, pool,

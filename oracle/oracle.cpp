@@ -131,6 +131,7 @@ static inline bool tri_test(const RayPre& r, V3 org, V3 p0, V3 p1, V3 p2, float&
   const float rcp = 1.0f / det;
   t = T * rcp;
   if (!(t >= 0.0f)) return false;
+  t = fabsf(t);  // -0.0 -> +0.0 (a hit exactly at the origin with a negative determinant): keeps distances ordered like their bit patterns
   bu = V * rcp;
   bv = W * rcp;
   return true;

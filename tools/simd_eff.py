@@ -12,7 +12,7 @@ cam = F.Camera(**scenes.SOUP_CAMERA)
 r.set_flags(N.FLAG_COUNT_TRAVERSAL)
 for depth in (1, 2, 8):
     r.reset_stats(); L.clear(); r.init_render_states()
-    r.render(cam,(0,0,0),L,2,depth); r.wait_for_completion()
+    r.render(cam,(0,0,0),L,int(os.environ.get("SPP","16")),depth); r.wait_for_completion()
     s = r.stats()
     for k in ("closest","shadow"):
         rays=s["rays_"+k]; n=s["nodes_"+k]; t=s["tris_"+k]; wn=s["wave_node_steps_"+k]; wt=s["wave_tri_steps_"+k]
