@@ -13,7 +13,7 @@
 
 int main(int argc, char** argv)
 {
-  if (argc < 2) { std::fprintf(stderr, "usage: %s scene.obj [out.ppm] [width height spp depth]\n", argv[0]); return 2; }
+  if (argc < 2) { std::fprintf(stderr, "usage: %s scene.obj [out.ppm] [width height spp depth] [ibl.hdr]\n", argv[0]); return 2; }
   const char* out_path = argc > 2 ? argv[2] : "out.ppm";
   const uint32_t width = argc > 3 ? std::atoi(argv[3]) : 512, height = argc > 4 ? std::atoi(argv[4]) : 512;
   const uint32_t n_spp = argc > 5 ? std::atoi(argv[5]) : 16, max_depth = argc > 6 ? std::atoi(argv[6]) : 5;
@@ -29,6 +29,7 @@ int main(int argc, char** argv)
     renderer.build_gas();
     renderer.build_ias();
     renderer.create_sbt();
+    if (argc > 7) renderer.load_ibl(argv[7]);  // rtcamp8.cpp loads its environment the same way
 
     cwl::CUDABuffer<float4> beauty(width * height), position(width * height), normal(width * height), texcoord(width * height), albedo(width * height);
     cwl::CUDABuffer<float> depth(width * height);

@@ -201,21 +201,56 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_coop(SceneDev sc, Pool
 // is covered, neighbouring lanes read neighbouring queue entries, and finished lanes get their next ray without atomics.
 FH_D uint32_t stream_index(uint32_t s, uint32_t wave, uint32_t n_waves) { return (s >> 6) * (n_waves << 6) + (wave << 6) + (s & 63u); }
 
+// XCD-sliced variant: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MB L2.  Giving XCD x the
+// x-th contiguous eighth of the queue keeps rays that are neighbours in the queue (neighbouring pixels / hit points) behind one
+// L2 instead of spreading every part of the BVH over all eight.  Speed only: any block-to-XCD placement gives the same result.
+// instrumented build: per-lane histogram of nodes visited per ray (8 bins x 16 bits; a lane traces far fewer than 65535 rays),
+// flushed once per lane instead of one contended atomic per ray
+struct HistPack {
+  unsigned long long w[2] = {0ull, 0ull};
+  FH_D void add(uint32_t nodes) { int b = 0; while (b < 7 && nodes > (8u << b)) ++b; if (b < 4) w[0] += 1ull << (16 * b); else w[1] += 1ull << (16 * (b - 4)); }
+  FH_D void flush(unsigned long long* hist) const
+  {
+    for (int b = 0; b < 8; ++b) { const unsigned long long v = (w[b >> 2] >> (16 * (b & 3))) & 0xffffull; if (v) atomicAdd(hist + b, v); }
+  }
+};
+
+struct StreamSlice {
+  uint32_t lo, hi, wave, n_waves;  // queue range of this wave's XCD share, wave index and wave count inside the share
+  FH_D StreamSlice(uint32_t count, bool sliced)
+  {
+    const uint32_t wave_in_block = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
+    if (sliced && (gridDim.x & 7u) == 0u) {
+      const uint32_t x = blockIdx.x & 7u;
+      lo = (uint32_t)(((unsigned long long)count * x) >> 3);
+      hi = (uint32_t)(((unsigned long long)count * (x + 1u)) >> 3);
+      wave = (blockIdx.x >> 3) * waves_per_block + wave_in_block;
+      n_waves = (gridDim.x >> 3) * waves_per_block;
+    } else {
+      lo = 0u; hi = count;
+      wave = blockIdx.x * waves_per_block + wave_in_block;
+      n_waves = gridDim.x * waves_per_block;
+    }
+  }
+  FH_D uint32_t index(uint32_t s) const { return lo + stream_index(s, wave, n_waves); }
+};
+
 template <bool COUNT>
 struct ClosestStream {
   const PoolDev& pool;
   const uint32_t* q;
-  uint32_t count, wave, n_waves;
+  StreamSlice sl;
   uint32_t cursor = 0;
   uint32_t p = 0;
   uint32_t n_rays = 0;
   unsigned long long* hist;
-  FH_D ClosestStream(const PoolDev& pl, const uint32_t* qq, uint32_t c, uint32_t w, uint32_t nw, unsigned long long* hs) : pool(pl), q(qq), count(c), wave(w), n_waves(nw), hist(hs) {}
+  HistPack hp;
+  FH_D ClosestStream(const PoolDev& pl, const uint32_t* qq, const StreamSlice& s, unsigned long long* hs) : pool(pl), q(qq), sl(s), hist(hs) {}
   FH_D bool advance(f3&, f3&, float&, bool&) { return false; }
   FH_D bool take(uint32_t s, f3& o, f3& d, float& tmax, bool& any)
   {
-    const uint32_t i = stream_index(s, wave, n_waves);
-    if (i >= count) return false;
+    const uint32_t i = sl.index(s);
+    if (i >= sl.hi) return false;
     p = q[i];
     const float4 o4 = pool.ray_o[p], d4 = pool.ray_d[p];
     o = mk3(o4); d = mk3(d4); tmax = o4.w; any = false;
@@ -225,26 +260,27 @@ struct ClosestStream {
   FH_D void commit(bool, const HitRec& h, uint32_t nodes)
   {
     pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
-    if (COUNT) { int b = 0; while (b < 7 && nodes > (8u << b)) ++b; atomicAdd(hist + b, 1ull); }
+    if (COUNT) hp.add(nodes);
   }
-  FH_D bool drained() const { return stream_index(cursor, wave, n_waves) >= count; }
+  FH_D bool drained() const { return sl.index(cursor) >= sl.hi; }
   FH_D bool followup() const { return false; }
 };
 
 template <bool COUNT, bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill)
+__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t sliced)
 {
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
   const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_RAD];
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
-  ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], count, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6, tc.hist);
+  ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], StreamSlice(count, sliced != 0u), tc.hist);
   traverse_stream<false, COUNT, false, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, nullptr, 0, &sc);
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
     atomicAdd(tc.rays, (unsigned long long)pol.n_rays);
+    pol.hp.flush(tc.hist);
     if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
     if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
   }
@@ -786,15 +822,15 @@ struct SecondaryStream {
   const SceneDev& sc;
   const FrameDev& fr;
   const PoolDev& pool;
-  uint32_t count, wave, n_waves;
+  StreamSlice sl;
   uint32_t cursor = 0;
   uint32_t p = 0, slot = 0;
   bool active = false;
   f3 L;
   uint32_t n_rays = 0;
   unsigned long long* hist;
-  FH_D SecondaryStream(const SceneDev& s, const FrameDev& f, const PoolDev& pl, uint32_t c, uint32_t w, uint32_t nw, unsigned long long* hs)
-      : sc(s), fr(f), pool(pl), count(c), wave(w), n_waves(nw), L(mk3(0.0f)), hist(hs) {}
+  HistPack hp;
+  FH_D SecondaryStream(const SceneDev& s, const FrameDev& f, const PoolDev& pl, const StreamSlice& ss, unsigned long long* hs) : sc(s), fr(f), pool(pl), sl(ss), L(mk3(0.0f)), hist(hs) {}
   // first slot >= from of path p that holds a ray
   FH_D bool scan(uint32_t from, f3& o, f3& d, float& tmax, bool& any)
   {
@@ -823,8 +859,8 @@ struct SecondaryStream {
   }
   FH_D bool take(uint32_t s, f3& o, f3& d, float& tmax, bool& any)
   {
-    const uint32_t i = stream_index(s, wave, n_waves);
-    if (i >= count) return false;
+    const uint32_t i = sl.index(s);
+    if (i >= sl.hi) return false;
     p = pool.q_sec[i];
     L = mk3(pool.rad[p]);
     active = true;
@@ -840,16 +876,16 @@ struct SecondaryStream {
       const float4 la = pool.lp_a[p], lb = pool.lp_b[p];
       L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, mk3(o), mk3(d), hit, h);
     } else {
-      if (COUNT) { int b = 0; while (b < 7 && nodes > (8u << b)) ++b; atomicAdd(hist + b, 1ull); }
+      if (COUNT) hp.add(nodes);
       if (!hit) L += mk3(pool.sec_c[k]);
     }
   }
-  FH_D bool drained() const { return stream_index(cursor, wave, n_waves) >= count; }
+  FH_D bool drained() const { return sl.index(cursor) >= sl.hi; }
   FH_D bool followup() const { return active && slot < SEC_LIGHT; }
 };
 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill)
+__global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t sliced)
 {
   __shared__ uint2 lds_stack[kLdsStack * kBlock];
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
@@ -857,13 +893,14 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, 
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
-  SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, count, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6, tc.hist);
+  SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, StreamSlice(count, sliced != 0u), tc.hist);
   traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
   pol.finish();
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
     atomicAdd(tc.rays, (unsigned long long)pol.n_rays);
+    pol.hp.flush(tc.hist);
     if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
     if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
   }
@@ -1221,6 +1258,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const bool stream = coop && !(stream_env && stream_env[0] == '0');
   // 5 blocks (20 waves) per CU: all resident at the kernels' LDS / register budgets, and measured faster than 8 (fewer cache conflicts)
   uint32_t stream_grid = (uint32_t)prop.multiProcessorCount * 5u, stream_refill = 24u;
+  uint32_t xcd_slice = 0u;  // measured: no difference on the 1M-triangle soup (2933 vs 2934 Msamples/s), so the balanced interleave stays the default
+  if (const char* e = getenv("FH_XCD_SLICE")) xcd_slice = (uint32_t)atoi(e);
   uint32_t exp_lds = 0;  // experiment: extra dynamic LDS per block to lower the occupancy
   if (const char* e = getenv("FH_EXP_LDS")) exp_lds = (uint32_t)atoi(e);
   if (const char* e = getenv("FH_STREAM_GRID")) { const int v = atoi(e); if (v >= 8 && v <= 8192) stream_grid = (uint32_t)v & ~7u; }
@@ -1257,7 +1296,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         } else if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc, pool, depth, tc_closest,
-                               coop_flush, stream_refill);
+                               coop_flush, stream_refill, xcd_slice);
           }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
@@ -1287,7 +1326,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         } else if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc,
-                               fr, pool, depth, tc_shadow, coop_flush, stream_refill);
+                               fr, pool, depth, tc_shadow, coop_flush, stream_refill, xcd_slice);
           }); }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {

@@ -272,9 +272,13 @@ class Renderer:
     def clear_arhosek_sky(self):
         self._ck(N.lib().fh_clear_arhosek_sky(self._ctx), "fh_clear_arhosek_sky")
 
-    def load_ibl(self, rgba32f):
-        """renderer.h:574-581; takes the decoded lat-long image (H x W x 4 float32) instead of a .hdr path"""
-        img = np.ascontiguousarray(rgba32f, dtype=np.float32)
+    def load_ibl(self, filepath_or_image):
+        """renderer.h:574-581: a Radiance .hdr path (read like the reference's FloatTexture, scene.cpp:39-66) or the decoded
+        lat-long image (H x W x 4 float32)"""
+        if isinstance(filepath_or_image, (str, bytes)) or hasattr(filepath_or_image, "__fspath__"):
+            from . import image_io
+            filepath_or_image = image_io.load_hdr(filepath_or_image)
+        img = np.ascontiguousarray(filepath_or_image, dtype=np.float32)
         assert img.ndim == 3 and img.shape[2] == 4
         self._ck(N.lib().fh_load_ibl(self._ctx, N.ptr(img), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0])), "fh_load_ibl")
 

@@ -8,6 +8,8 @@ surface is seen from behind (bsdf.cu:56-62).
 """
 import numpy as np
 
+from . import image_io
+
 from .native import default_materials
 
 
@@ -147,13 +149,21 @@ SOUP_SUN = (-0.1, 1.0, 0.1)  # rtcamp8.cpp:142-146
 # texcoords when absent (:361-377).  include/fredholm/scene.h is the C++ twin of this reader.
 # ---------------------------------------------------------------------------------------------
 def write_obj(scene, path):
-    """Write a flat scene as .obj + .mtl next to it (positions only: normals/texcoords are regenerated on load)."""
+    """Write a flat scene as .obj + .mtl next to it (normals are regenerated on load; texture coordinates are written when the
+    scene has textures, which go next to the .mtl as PNG files, stored bottom row last like any image file)."""
     import os
     base = os.path.splitext(path)[0]
     mats = scene["materials"]
+    textures = scene.get("textures") or []
+    for k, tex in enumerate(textures):
+        image_io.write_png(f"{base}_tex{k}.png", np.asarray(tex["rgba8"])[::-1], filter_type=k % 5)
+    inv = {v[0]: k for k, v in _MTL_TEXTURES.items() if k not in ("map_Bump", "bump")}
     with open(base + ".mtl", "w") as f:
         for i, m in enumerate(mats):
             f.write(f"newmtl m{i}\n")
+            for field, stmt in inv.items():
+                if m[field] >= 0:
+                    f.write(f"{stmt} {os.path.basename(base)}_tex{int(m[field])}.png\n")
             f.write("Kd %.9g %.9g %.9g\n" % tuple(m["base_color"]))
             f.write("Ks %.9g %.9g %.9g\n" % tuple(m["specular_color"]))
             f.write("Pr %.9g\nPm %.9g\n" % (m["specular_roughness"], m["metalness"]))
@@ -171,12 +181,18 @@ def write_obj(scene, path):
         f.write(f"mtllib {os.path.basename(base)}.mtl\n")
         for p in v:
             f.write("v %.9g %.9g %.9g\n" % tuple(p))
+        if textures:
+            for t in scene["texcoords"]:
+                f.write("vt %.9g %.9g\n" % tuple(t))
         cur = None
         for face, mid in zip(scene["indices"], scene["material_ids"]):
             if mid != cur:
                 f.write(f"usemtl m{mid}\n")
                 cur = mid
-            f.write("f %d %d %d\n" % tuple(int(i) + 1 for i in face))
+            if textures:
+                f.write("f %d/%d %d/%d %d/%d\n" % tuple(int(i) + 1 for i in face for _ in (0, 1)))
+            else:
+                f.write("f %d %d %d\n" % tuple(int(i) + 1 for i in face))
 
 
 def load_obj(path):
@@ -185,6 +201,7 @@ def load_obj(path):
     pos, nrm, tex = [], [], []
     mats, mat_index = [], {}
     verts, norms, uvs, faces, mids = [], [], [], [], []
+    textures, tex_index = [], {}
     cur = -1
 
     def load_mtl(p):
@@ -220,8 +237,17 @@ def load_obj(path):
                 m["emission_color"] = f
             elif t[0] in ("diffuse", "diffuse_roughness", "sheen", "sheen_roughness", "subsurface", "thin_walled"): m[t[0]] = f[0]
             elif t[0] in ("sheen_color", "subsurface_color"): m[t[0]] = f
-            elif t[0].startswith("map_") or t[0] in ("bump", "norm"):
-                raise ValueError(f"texture maps are not supported in this build ({t[0]} in {p})")
+            elif t[0] in _MTL_TEXTURES:
+                # scene.cpp:144-153,196-310: one texture per distinct file name (its first use fixes COLOR / NONCOLOR); the last
+                # token is the file name (options such as "-bm 1" precede it)
+                field, srgb = _MTL_TEXTURES[t[0]]
+                name = t[-1]
+                if name not in tex_index:
+                    tex_index[name] = len(textures)
+                    textures.append({"rgba8": image_io.load_rgba8(os.path.join(os.path.dirname(p), name), flip_vertically=True), "srgb": srgb})
+                m[field] = tex_index[name]
+            elif t[0].startswith("map_"):
+                raise ValueError(f"{t[0]} is not a texture slot of the reference's .mtl mapping ({p})")
 
     for line in open(path):
         t = line.split()
@@ -256,8 +282,17 @@ def load_obj(path):
     if any(m < 0 for m in mids):
         mats.append(default_materials(1)[0])
         mids = [len(mats) - 1 if m < 0 else m for m in mids]
-    return {"vertices": np.asarray(verts, dtype=np.float32), "normals": np.asarray(norms, dtype=np.float32), "texcoords": np.asarray(uvs, dtype=np.float32),
-            "indices": np.asarray(faces, dtype=np.uint32), "material_ids": np.asarray(mids, dtype=np.uint32), "materials": np.asarray(mats, dtype=default_materials(1).dtype)}
+    out = {"vertices": np.asarray(verts, dtype=np.float32), "normals": np.asarray(norms, dtype=np.float32), "texcoords": np.asarray(uvs, dtype=np.float32),
+           "indices": np.asarray(faces, dtype=np.uint32), "material_ids": np.asarray(mids, dtype=np.uint32), "materials": np.asarray(mats, dtype=default_materials(1).dtype)}
+    if textures:
+        out["textures"] = textures
+    return out
+
+
+# .mtl statement -> (Material field, sRGB) as tinyobjloader names them and scene.cpp:196-310 consumes them
+_MTL_TEXTURES = {"map_Kd": ("base_color_texture_id", True), "map_Ks": ("specular_color_texture_id", True), "map_Pr": ("specular_roughness_texture_id", False),
+                 "map_Pm": ("metalness_texture_id", False), "map_bump": ("heightmap_texture_id", False), "map_Bump": ("heightmap_texture_id", False),
+                 "bump": ("heightmap_texture_id", False), "norm": ("normalmap_texture_id", False), "map_d": ("alpha_texture_id", False)}
 
 
 def _isnum(s):

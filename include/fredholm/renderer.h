@@ -51,8 +51,12 @@ class Renderer
     cwl::check(m_ctx, fh_set_directional_light(m_ctx, l, d, angle), "fh_set_directional_light");
   }
   void set_sky_intensity(float v) { cwl::check(m_ctx, fh_set_sky_intensity(m_ctx, v), "fh_set_sky_intensity"); }
-  void load_ibl(const std::filesystem::path&) { cwl::check(m_ctx, fh_load_ibl(m_ctx, nullptr, 0, 0), "fh_load_ibl"); }
-  void clear_ibl() {}
+  void load_ibl(const std::filesystem::path& filepath)  // renderer.h:574-581
+  {
+    const FloatTexture ibl(filepath);
+    cwl::check(m_ctx, fh_load_ibl(m_ctx, reinterpret_cast<const float*>(ibl.m_data.data()), ibl.m_width, ibl.m_height), "fh_load_ibl");
+  }
+  void clear_ibl() { cwl::check(m_ctx, fh_clear_ibl(m_ctx), "fh_clear_ibl"); }  // renderer.h:583-586
   void load_arhosek_sky(float turbidity, float albedo) { cwl::check(m_ctx, fh_load_arhosek_sky(m_ctx, turbidity, albedo), "fh_load_arhosek_sky"); }
   void clear_arhosek_sky() { cwl::check(m_ctx, fh_clear_arhosek_sky(m_ctx), "fh_clear_arhosek_sky"); }
 
@@ -113,6 +117,11 @@ class Renderer
     d.n_instances = uint32_t(m_scene.m_transforms.size());
     d.object_to_world = o2w.empty() ? nullptr : o2w.data();
     d.world_to_object = w2o.empty() ? nullptr : w2o.data();
+    std::vector<fh_texture_desc> tex;  // renderer.h:414-424: COLOR textures are sRGB-decoded by the texture unit
+    for (const Texture& t : m_scene.m_textures)
+      tex.push_back(fh_texture_desc{t.m_width, t.m_height, reinterpret_cast<const uint8_t*>(t.m_data.data()), t.m_texture_type == TextureType::COLOR ? 1 : 0});
+    d.n_textures = uint32_t(tex.size());
+    d.textures = tex.empty() ? nullptr : tex.data();
     cwl::check(m_ctx, fh_scene_upload(m_ctx, &d), "fh_scene_upload");
   }
   static Mat4 affine_inverse(const Mat4& m)

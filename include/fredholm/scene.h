@@ -4,7 +4,9 @@
 // face normals / barycentric texcoords when absent (:361-377), Kd -> base_color, Ks -> specular_color,
 // Pr/Pm/Pc, d -> transmission = 1 - d (:245), Tf, Ke, and the custom keys diffuse, diffuse_roughness, sheen*,
 // subsurface*, thin_walled (:183-284); coat_roughness takes clearcoat_thickness as in the reference (:240-242).
-// Not supported in this build: texture maps (map_*: rejected, never silently dropped) and glTF.
+// Texture statements (map_Kd, map_Ks, map_Pr, map_Pm, map_bump/bump, norm, map_d) load PNG / binary PPM files through
+// image_io.h with the reference's conventions (scene.cpp:7-37,144-153: vertical flip, one Texture per distinct file name, its
+// first use fixes COLOR / NONCOLOR).  Not supported in this build: JPEG files and glTF.
 #pragma once
 #include <cmath>
 #include <filesystem>
@@ -16,10 +18,46 @@
 #include <vector>
 
 #include "camera.h"
+#include "image_io.h"
 #include "shared.h"
 
 namespace fredholm
 {
+
+// fredholm/include/fredholm/scene.h:60-79
+enum class TextureType { COLOR, NONCOLOR };
+
+struct Texture {
+  uint32_t m_width = 0;
+  uint32_t m_height = 0;
+  std::vector<uchar4> m_data;
+  TextureType m_texture_type = TextureType::NONCOLOR;
+
+  Texture() {}
+  Texture(const std::filesystem::path& filepath, const TextureType& texture_type) : m_texture_type(texture_type)
+  {
+    const image_io::Image8 img = image_io::load_rgba8(filepath, /*flip_vertically=*/true);  // scene.cpp:15-16
+    m_width = uint32_t(img.width);
+    m_height = uint32_t(img.height);
+    m_data.resize(size_t(m_width) * m_height);
+    for (size_t i = 0; i < m_data.size(); ++i) m_data[i] = uchar4{img.rgba[4 * i], img.rgba[4 * i + 1], img.rgba[4 * i + 2], img.rgba[4 * i + 3]};
+  }
+};
+
+struct FloatTexture {
+  uint32_t m_width = 0;
+  uint32_t m_height = 0;
+  std::vector<float4> m_data;
+
+  explicit FloatTexture(const std::filesystem::path& filepath)
+  {
+    const image_io::ImageF img = image_io::load_hdr(filepath);  // scene.cpp:44-45: no flip
+    m_width = uint32_t(img.width);
+    m_height = uint32_t(img.height);
+    m_data.resize(size_t(m_width) * m_height);
+    for (size_t i = 0; i < m_data.size(); ++i) m_data[i] = float4{img.rgba[4 * i], img.rgba[4 * i + 1], img.rgba[4 * i + 2], img.rgba[4 * i + 3]};
+  }
+};
 
 struct Scene {
   bool m_has_camera_transform = false;
@@ -30,6 +68,7 @@ struct Scene {
   std::vector<float3> m_normals = {};
   std::vector<uint> m_material_ids = {};
   std::vector<Material> m_materials;
+  std::vector<Texture> m_textures;
   std::vector<uint> m_submesh_offsets = {};
   std::vector<uint> m_submesh_n_faces = {};
   std::vector<uint> m_instance_ids = {};
@@ -39,7 +78,7 @@ struct Scene {
 
   void clear()
   {
-    m_vertices.clear(); m_indices.clear(); m_texcoords.clear(); m_normals.clear(); m_material_ids.clear(); m_materials.clear();
+    m_vertices.clear(); m_indices.clear(); m_texcoords.clear(); m_normals.clear(); m_material_ids.clear(); m_materials.clear(); m_textures.clear();
     m_submesh_offsets.clear(); m_submesh_n_faces.clear(); m_instance_ids.clear(); m_transforms.clear();
   }
 
@@ -59,7 +98,7 @@ struct Scene {
     if (!in) throw std::runtime_error("failed to load " + filepath.generic_string());
     std::vector<float3> pos, nrm;
     std::vector<float2> tex;
-    std::map<std::string, int> mat_index;
+    std::map<std::string, int> mat_index, unique_textures;
     const size_t material_base = m_materials.size();
     int current_material = -1;
     bool need_default = false;
@@ -73,7 +112,7 @@ struct Scene {
       if (tag == "v") { float3 p; ss >> p.x >> p.y >> p.z; pos.push_back(p); }
       else if (tag == "vn") { float3 n; ss >> n.x >> n.y >> n.z; nrm.push_back(n); }
       else if (tag == "vt") { float2 t{0, 0}; ss >> t.x >> t.y; tex.push_back(t); }
-      else if (tag == "mtllib") { std::string name; ss >> name; load_mtl(filepath.parent_path() / name, mat_index); }
+      else if (tag == "mtllib") { std::string name; ss >> name; load_mtl(filepath.parent_path() / name, mat_index, unique_textures); }
       else if (tag == "usemtl") { std::string name; ss >> name; current_material = mat_index.count(name) ? mat_index[name] : -1; }
       else if (tag == "f") {
         struct Corner { int v, t, n; };
@@ -133,7 +172,7 @@ struct Scene {
     return make_float3(a.x / l, a.y / l, a.z / l);
   }
 
-  void load_mtl(const std::filesystem::path& path, std::map<std::string, int>& mat_index)
+  void load_mtl(const std::filesystem::path& path, std::map<std::string, int>& mat_index, std::map<std::string, int>& unique_textures)
   {
     std::ifstream in(path);
     if (!in) throw std::runtime_error("failed to load " + path.generic_string());
@@ -177,8 +216,24 @@ struct Scene {
       else if (tag == "subsurface") cur->subsurface = f1();
       else if (tag == "subsurface_color") cur->subsurface_color = f3();
       else if (tag == "thin_walled") cur->thin_walled = f1();
-      else if (tag.rfind("map_", 0) == 0 || tag == "bump" || tag == "norm")
-        throw std::runtime_error("texture maps are not supported in this build (" + tag + " in " + path.generic_string() + ")");
+      else if (tag == "map_Kd" || tag == "map_Ks" || tag == "map_Pr" || tag == "map_Pm" || tag == "map_bump" || tag == "map_Bump" || tag == "bump" || tag == "norm" || tag == "map_d") {
+        std::string name, tok;
+        while (ss >> tok) name = tok;  // options ("-bm 1") precede the file name
+        const bool color = tag == "map_Kd" || tag == "map_Ks";
+        if (!unique_textures.count(name)) {  // scene.cpp:144-153
+          unique_textures[name] = int(m_textures.size());
+          m_textures.push_back(Texture(path.parent_path() / name, color ? TextureType::COLOR : TextureType::NONCOLOR));
+        }
+        const int id = unique_textures[name];
+        if (tag == "map_Kd") cur->base_color_texture_id = id;
+        else if (tag == "map_Ks") cur->specular_color_texture_id = id;
+        else if (tag == "map_Pr") cur->specular_roughness_texture_id = id;
+        else if (tag == "map_Pm") cur->metalness_texture_id = id;
+        else if (tag == "norm") cur->normalmap_texture_id = id;
+        else if (tag == "map_d") cur->alpha_texture_id = id;
+        else cur->heightmap_texture_id = id;
+      } else if (tag.rfind("map_", 0) == 0)
+        throw std::runtime_error(tag + " is not a texture slot of the reference's .mtl mapping (" + path.generic_string() + ")");
     }
   }
 };

@@ -8,6 +8,7 @@
 struct float2 { float x, y; };
 struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
+struct uchar4 { unsigned char x, y, z, w; };
 struct uint3 { unsigned int x, y, z; };
 struct uint2 { unsigned int x, y; };
 inline float2 make_float2(float x, float y) { return {x, y}; }

@@ -200,3 +200,131 @@ def test_cpp_facade_compiles_and_links(tmp_path):
     if not torch.cuda.is_available():
         run = subprocess.run([str(exe), "missing.obj"], capture_output=True, text=True)
         assert run.returncode == 1 and "no HIP device" in run.stderr  # loud failure, no fallback
+
+
+# ---------------------------------------------------------------- image files (include/fredholm/image_io.h, fredholm_amd/image_io.py)
+def _png_bytes(w, h, depth, ctype, rows, extra=b""):
+    import struct
+    import zlib
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+    raw = b"".join(bytes([ft]) + bytes(r) for ft, r in rows)
+    z = zlib.compress(raw, 9)
+    idat = chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:])  # split IDAT: decoders must concatenate
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + extra + idat + chunk(b"IEND", b"")
+
+
+@pytest.fixture(scope="module")
+def image_dump(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("imgdump") / "image_dump"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "image_dump.cpp"), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+    def run(mode, path):
+        p = subprocess.run([str(exe), mode, str(path)], capture_output=True)
+        if p.returncode != 0:
+            raise ValueError(p.stderr.decode())
+        w, h = np.frombuffer(p.stdout[:8], dtype=np.int32)
+        body = p.stdout[8:]
+        return np.frombuffer(body, dtype=np.float32 if mode == "hdr" else np.uint8).reshape(h, w, 4)
+    return run
+
+
+def test_png_decoders_agree_on_every_filter_and_colour_type(tmp_path, image_dump):
+    import struct
+    from fredholm_amd import image_io as I
+    rng = np.random.default_rng(11)
+    n = 0
+    for ch in (1, 2, 3, 4):
+        for ft in (None, 1, 2, 3, 4):
+            img = rng.integers(0, 256, (9, 14, ch), dtype=np.uint8)
+            img[2:5, 3:9] = img[2, 3]  # a flat patch: exercises deflate back-references
+            p = tmp_path / f"f{ch}_{ft}.png"
+            I.write_png(p, img, ft)
+            py = I.load_rgba8(p, flip_vertically=False)
+            want = np.full((9, 14, 4), 255, np.uint8)
+            want[..., :3] = img[..., :3] if ch >= 3 else img[..., :1]
+            if ch in (2, 4):
+                want[..., 3] = img[..., -1]
+            assert np.array_equal(py, want), (ch, ft)
+            assert np.array_equal(image_dump("rgba8", p), want), (ch, ft)
+            assert np.array_equal(image_dump("rgba8_flip", p), want[::-1]) and np.array_equal(I.load_rgba8(p), want[::-1])
+            n += 1
+    # hand-assembled files: palette + tRNS, 16-bit RGB with a colour key, 2-bit grey, split IDAT chunks
+    pal = bytes(range(30))
+    rows = [(0, [0, 1, 2, 9]), (1, [3, 1, 0, 0]), (2, [0, 0, 1, 1])]
+    f = tmp_path / "pal.png"
+    f.write_bytes(_png_bytes(4, 3, 8, 3, rows, struct.pack(">I", 30) + b"PLTE" + pal + b"\0\0\0\0" + struct.pack(">I", 2) + b"tRNS" + bytes([7, 200]) + b"\0\0\0\0"))
+    a, b = I.load_rgba8(f, False), image_dump("rgba8", f)
+    assert np.array_equal(a, b) and tuple(a[0, 3]) == (27, 28, 29, 255) and a[0, 0, 3] == 7 and a[0, 1, 3] == 200 and tuple(a[1, 1][:3]) == (12, 13, 14)
+    px = rng.integers(0, 65536, (2, 3, 3), dtype=np.uint16)
+    rows = [(0, px[y].astype(">u2").tobytes()) for y in range(2)]
+    key = struct.pack(">HHH", *[int(v) for v in px[1, 2]])
+    f = tmp_path / "rgb16.png"
+    f.write_bytes(_png_bytes(3, 2, 16, 2, rows, struct.pack(">I", 6) + b"tRNS" + key + b"\0\0\0\0"))
+    a, b = I.load_rgba8(f, False), image_dump("rgba8", f)
+    assert np.array_equal(a, b) and np.array_equal(a[..., :3], (px >> 8).astype(np.uint8)) and a[1, 2, 3] == 0 and a[0, 0, 3] == 255
+    f = tmp_path / "g2.png"
+    f.write_bytes(_png_bytes(5, 1, 2, 0, [(0, [0b00011011, 0b01000000])]))
+    a, b = I.load_rgba8(f, False), image_dump("rgba8", f)
+    assert np.array_equal(a, b) and a[0, :, 0].tolist() == [0, 85, 170, 255, 85]
+    # rejected, not mis-decoded
+    jpg = tmp_path / "x.jpg"
+    jpg.write_bytes(b"\xff\xd8\xff\xe0" + bytes(64))
+    for loader in (lambda: I.load_rgba8(jpg), lambda: image_dump("rgba8", jpg)):
+        with pytest.raises(ValueError):
+            loader()
+    bad = bytearray(_png_bytes(2, 1, 8, 0, [(0, [1, 2])]))
+    bad[8 + 8 + 12] = 1  # interlace flag
+    (tmp_path / "i.png").write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        I.load_rgba8(tmp_path / "i.png")
+    with pytest.raises(ValueError):
+        image_dump("rgba8", tmp_path / "i.png")
+    assert n == 20
+
+
+def test_hdr_and_ppm_decoders_agree(tmp_path, image_dump):
+    from fredholm_amd import image_io as I
+    rng = np.random.default_rng(12)
+    hdr = (rng.random((7, 40, 3)) * np.array([30.0, 2.0, 0.01])).astype(np.float32)
+    hdr[3, 5:30] = hdr[3, 5]  # a run for the RLE writer
+    hdr[0, 0] = 0.0
+    for rle in (False, True):
+        p = tmp_path / f"e{int(rle)}.hdr"
+        I.write_hdr(p, hdr, rle)
+        a, b = I.load_hdr(p), image_dump("hdr", p)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert (a[..., 3] == 1).all() and (a[0, 0, :3] == 0).all()
+        assert (np.abs(a[..., :3] - hdr) <= hdr.max(axis=-1, keepdims=True) / 128 + 1e-12).all()
+    # mantissa * 2^(e - 136) exactly (stb_image's documented conversion)
+    (tmp_path / "k.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 2\n" + bytes([128, 64, 1, 129, 255, 0, 3, 120]))
+    a = I.load_hdr(tmp_path / "k.hdr")
+    assert a[0, 0].tolist() == [1.0, 0.5, 1 / 128, 1.0] and a[0, 1].tolist() == [255 / 65536, 0.0, 3 / 65536, 1.0]
+    assert np.array_equal(a, image_dump("hdr", tmp_path / "k.hdr"))
+    ppm = tmp_path / "a.ppm"
+    px = rng.integers(0, 256, (3, 4, 3), dtype=np.uint8)
+    ppm.write_bytes(b"P6\n# comment\n4 3\n255\n" + px.tobytes())
+    a, b = I.load_rgba8(ppm, False), image_dump("rgba8", ppm)
+    assert np.array_equal(a, b) and np.array_equal(a[..., :3], px) and (a[..., 3] == 255).all()
+
+
+def test_textured_obj_round_trip(tmp_path):
+    sc = scenes.textured_cornell_box()
+    path = str(tmp_path / "t.obj")
+    scenes.write_obj(sc, path)
+    back = scenes.load_obj(path)
+    assert np.array_equal(sc["texcoords"], back["texcoords"]) and np.array_equal(sc["vertices"], back["vertices"])
+    seen = 0
+    for stmt, (field, srgb) in scenes._MTL_TEXTURES.items():
+        for i in range(len(sc["materials"])):
+            a, c = int(sc["materials"][field][i]), int(back["materials"][field][i])
+            assert (a < 0) == (c < 0), (field, i)
+            if a >= 0:
+                assert np.array_equal(sc["textures"][a]["rgba8"], back["textures"][c]["rgba8"]), (field, i)
+                seen += 1
+    assert seen >= 7
+    srgb_of = {int(back["materials"]["base_color_texture_id"][i]) for i in range(len(back["materials"])) if back["materials"]["base_color_texture_id"][i] >= 0}
+    assert all(back["textures"][k]["srgb"] for k in srgb_of)  # map_Kd textures are COLOR textures (scene.cpp:201-202)

@@ -599,19 +599,27 @@ def test_full_size_render_is_deterministic_shard_invariant_and_matches_checker_r
 
 
 # ------------------------------------------------------------------ the C++ drop-in facade end to end
-def test_cpp_headless_driver_matches_python_path(tmp_path, oracle):
+@pytest.mark.parametrize("textured", [False, True])
+def test_cpp_headless_driver_matches_python_path(tmp_path, oracle, textured):
+    """C++ facade (own .obj/.mtl/.png/.hdr readers) and Python mirror (its own readers) drive the same library to the same image"""
     import os
     import subprocess
+    from fredholm_amd import image_io
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "headless"
     cmd = ["g++", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "headless.cpp"), "-L" + os.path.join(root, "fredholm_amd"), "-lfredholm_hip",
            "-Wl,-rpath," + os.path.join(root, "fredholm_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
     assert subprocess.run(cmd).returncode == 0
     obj = str(tmp_path / "cornell.obj")
-    scenes.write_obj(scenes.cornell_box(), obj)
+    scenes.write_obj(scenes.textured_cornell_box() if textured else scenes.cornell_box(), obj)
     ppm = str(tmp_path / "out.ppm")
     w, h, spp, depth = 96, 64, 4, 4
-    run = subprocess.run([str(exe), obj, ppm, str(w), str(h), str(spp), str(depth)], capture_output=True, text=True)
+    args = [str(exe), obj, ppm, str(w), str(h), str(spp), str(depth)]
+    hdr = str(tmp_path / "env.hdr")
+    if textured:
+        image_io.write_hdr(hdr, scenes.gradient_ibl()[..., :3], rle=True)
+        args.append(hdr)
+    run = subprocess.run(args, capture_output=True, text=True)
     assert run.returncode == 0, run.stderr
     data = open(ppm, "rb").read()
     header = f"P6\n{w} {h}\n255\n".encode()
@@ -621,6 +629,8 @@ def test_cpp_headless_driver_matches_python_path(tmp_path, oracle):
     r = F.Renderer(0)
     r.load_scene(obj)
     r.build_ias()
+    if textured:
+        r.load_ibl(hdr)
     r.set_resolution(w, h)
     L = F.RenderLayer(r, w, h)
     r.render(F.Camera(**scenes.CORNELL_CAMERA), (0, 0, 0), L, spp, depth)
@@ -635,6 +645,8 @@ def test_cpp_headless_driver_matches_python_path(tmp_path, oracle):
     assert np.array_equal(img_cpp, img_py)
     # and the checker agrees with the beauty layer that went in
     S = oracle.Scene(scenes.load_obj(obj))
+    if textured:
+        S.load_ibl(image_io.load_hdr(hdr))
     Lo = S.new_layers(w, h)
     for _ in range(spp):
         S.render(F.Camera(**scenes.CORNELL_CAMERA).params(), w, h, Lo, 1, depth, n_threads=8)
