@@ -60,8 +60,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per step (one fh_render call)")
-    ap.add_argument("--pool-spp", type=int, default=64, help="size the path pool for this many samples per pixel per pass (0 = library default, 32 Mi paths)")
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step (one fh_render call = one presented frame; BASELINE configs[2] presents 1024-spp frames)")
+    ap.add_argument("--pool-spp", type=int, default=0, help="samples per pixel per pass of the path pool; 0 = half a step per pass (two passes in flight overlap), at most 64 spp of the full frame (132.7 M paths, 49 GB per pool)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-frame", action="store_true", help="N > 1: rank 0 re-renders the whole frame unsharded and compares it bit for bit with the gathered one")
     args = ap.parse_args()
@@ -106,8 +106,10 @@ def main():
     r.set_resolution(WIDTH, HEIGHT)
     if world > 1:
         r.set_tile_shard(rank, world, 32, 32)
-    if args.pool_spp > 0:  # path-pool slots = owned pixels x pool_spp (372 B per slot): one pass per step when pool_spp >= spp
-        r.set_path_pool(min(r.owned_pixel_count() * args.pool_spp, 160 * 1024 * 1024))
+    # path-pool slots = owned pixels x samples per pass (372 B per slot, two pools): by default a step is at least two passes, so
+    # that the library's two-passes-in-flight pipelining has something to overlap inside a step
+    pool_spp = args.pool_spp if args.pool_spp > 0 else max(args.spp // 2, 1)
+    r.set_path_pool(min(r.owned_pixel_count() * pool_spp, WIDTH * HEIGHT * 64))
     cam = F.Camera(**scenes.SOUP_CAMERA)
     dev = torch.device("cuda", local_rank)
     bufs = {n: torch.zeros((HEIGHT, WIDTH) if n == "depth" else (HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev) for n in F.RenderLayer.NAMES}
@@ -204,7 +206,10 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, launches, rays, nodes, tris, cnt_launches = kernels[dom]
         node_bytes = timed["bvh_node_bytes"] / max(timed["bvh_nodes"], 1)  # 80 B wide nodes (64 B for the binary fallback)
-        bytes_per_launch = (rays * (RAY_BYTES + HIT_BYTES) + nodes * node_bytes + tris * TRI_BYTES) / max(cnt_launches, 1)
+        # algorithmic bytes of one step (counted replay) x timed steps / timed launches = bytes per launch; launch time = HIP-event
+        # total / timed launches.  Both sides use the timed launch count, so achieved = bytes per step x steps / kernel seconds.
+        bytes_per_step = rays * (RAY_BYTES + HIT_BYTES) + nodes * node_bytes + tris * TRI_BYTES
+        bytes_per_launch = bytes_per_step * args.steps / max(launches, 1)
         avg_ms = ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc run (counters cannot be read from inside this
@@ -227,7 +232,7 @@ def main():
                        "gather": "RCCL all_gather of packed float4 beauty tiles, inside the timed region" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "per_ray": {"nodes": round(nodes / max(rays, 1), 2), "triangles": round(tris / max(rays, 1), 2), "bytes": round(bytes_per_launch * cnt_launches / max(rays, 1), 1)},
+                         "per_ray": {"nodes": round(nodes / max(rays, 1), 2), "triangles": round(tris / max(rays, 1), 2), "bytes": round(bytes_per_step / max(rays, 1), 1)},
                          "note": "rank 0 shard" if world > 1 else "whole frame"},
             "kernel_ms_per_step": {"trace_closest": round(timed["trace_closest_ms"] / args.steps, 3), "trace_secondary": round(timed["trace_shadow_ms"] / args.steps, 3),
                                    "shade": round(timed["shade_ms"] / args.steps, 3), "tail": round(timed["tail_ms"] / args.steps, 3), "render_total": round(timed["render_ms"] / args.steps, 3)},

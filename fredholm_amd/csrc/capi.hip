@@ -236,8 +236,15 @@ int fh_ctx_create(int device, fh_ctx** out)
   (void)hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
   (void)hipMemset(ctx->d_trace_counters, 0, 26 * sizeof(unsigned long long));
-  (void)hipHostMalloc((void**)&ctx->h_counters, sizeof(uint32_t) * fh::kCounterStride * 66);
-  (void)hipEventCreate(&ctx->ev_counters);
+  if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+  for (int k = 0; k < 2; ++k) {
+    (void)hipHostMalloc((void**)&ctx->h_counters[k], sizeof(uint32_t) * fh::kCounterStride * 66);
+    (void)hipEventCreate(&ctx->ev_counters[k]);
+    (void)hipEventCreateWithFlags(&ctx->ev_gen[k], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&ctx->ev_acc[k], hipEventDisableTiming);
+  }
+  (void)hipEventCreateWithFlags(&ctx->ev_enter, hipEventDisableTiming);
+  if (const char* e = getenv("FH_PIPELINE")) ctx->pipeline = e[0] != '0';
   (void)hipEventCreate(&ctx->ev_render_begin);
   (void)hipEventCreate(&ctx->ev_render_end);
   *out = ctx;
@@ -249,15 +256,22 @@ int fh_ctx_destroy(fh_ctx* ctx)
   if (!ctx) return FH_E_INVALID;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream2);
   pool_release(ctx);
-  void* ptrs[] = {ctx->d_sobol, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
+  void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
                   ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-  if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-  (void)hipEventDestroy(ctx->ev_counters);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->h_counters[k]) (void)hipHostFree(ctx->h_counters[k]);
+    (void)hipEventDestroy(ctx->ev_counters[k]);
+    (void)hipEventDestroy(ctx->ev_gen[k]);
+    (void)hipEventDestroy(ctx->ev_acc[k]);
+  }
+  (void)hipEventDestroy(ctx->ev_enter);
+  (void)hipStreamDestroy(ctx->stream2);
   (void)hipEventDestroy(ctx->ev_render_begin);
   (void)hipEventDestroy(ctx->ev_render_end);
   (void)hipStreamDestroy(ctx->stream);
@@ -418,6 +432,7 @@ int fh_init_render_states(fh_ctx* ctx)
   CTX_CHECK(ctx);
   if (!ctx->d_sample_count) return fail(ctx, FH_E_INVALID, "resolution not set");
   FH_HIP(hipMemsetAsync(ctx->d_sample_count, 0, 4ull * ctx->width * ctx->height, ctx->stream));
+  FH_HIP(hipMemsetAsync(ctx->d_sample_issued, 0, 4ull * ctx->width * ctx->height, ctx->stream));
   return FH_OK;
 }
 
@@ -427,8 +442,10 @@ int fh_set_resolution(fh_ctx* ctx, uint32_t w, uint32_t h)
   if (w == 0 || h == 0) return fail(ctx, FH_E_INVALID, "zero resolution");
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_sample_count) { (void)hipFree(ctx->d_sample_count); ctx->d_sample_count = nullptr; }
+  if (ctx->d_sample_issued) { (void)hipFree(ctx->d_sample_issued); ctx->d_sample_issued = nullptr; }
   ctx->width = w; ctx->height = h;
   FH_HIP(hipMalloc((void**)&ctx->d_sample_count, 4ull * w * h));
+  FH_HIP(hipMalloc((void**)&ctx->d_sample_issued, 4ull * w * h));
   const int rc = rebuild_ownership(ctx);
   if (rc) return rc;
   return fh_init_render_states(ctx);

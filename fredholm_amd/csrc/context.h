@@ -12,7 +12,8 @@
 
 struct fh_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // main stream: everything the caller can observe is ordered on it
+  hipStream_t stream2 = nullptr;  // odd passes of fh_render run here, overlapping the latency-bound end of the pass before
   std::string err;
   uint32_t flags = 0;
 
@@ -60,7 +61,8 @@ struct fh_ctx {
 
   // frame state
   uint32_t width = 0, height = 0;
-  uint32_t* d_sample_count = nullptr;
+  uint32_t* d_sample_count = nullptr;   // samples accumulated per pixel (written by k_accumulate)
+  uint32_t* d_sample_issued = nullptr;  // samples started per pixel (written after k_generate): the next pass does not wait for the accumulate
   uint32_t shard_rank = 0, shard_world = 1, tile_w = 32, tile_h = 32;
   uint32_t* d_owned = nullptr;  // image indices of owned pixels, in tile order
   uint32_t n_owned = 0;
@@ -73,16 +75,20 @@ struct fh_ctx {
   bool has_hosek = false;
   fh::HosekSky hosek{};
 
-  // path pool
-  fh::PoolDev pool{};
-  std::vector<void*> pool_allocs;
+  // path pools: two, so that two passes can be in flight (pass j uses slot j % 2 and the stream of that slot)
+  fh::PoolDev pool[2] = {};
+  std::vector<void*> pool_allocs[2];
   uint32_t pool_target = 1u << 25;  // 32 Mi path slots (12.5 GB): 16 samples per pixel per pass at 1080p
   uint32_t tail_depth = 0;          // bounces run as wavefront kernels before k_tail finishes the survivors; 0 = adaptive
   uint32_t auto_wave_depth = 2;     // adaptive choice, updated from the per-bounce survivor counts of earlier passes
-  uint32_t* h_counters = nullptr;   // pinned snapshot of the per-bounce counters of a finished pass
-  hipEvent_t ev_counters = nullptr;
-  bool counters_in_flight = false;
-  uint32_t counters_wave_depth = 0; // wave depth used by the pass the snapshot comes from
+  uint32_t* h_counters[2] = {nullptr, nullptr};  // pinned snapshots of the per-bounce counters of a finished pass
+  hipEvent_t ev_counters[2] = {nullptr, nullptr};
+  bool counters_in_flight[2] = {false, false};
+  uint32_t counters_wave_depth[2] = {0, 0};  // wave depth used by the pass the snapshot comes from
+  unsigned long long pass_seq = 0;           // passes submitted so far
+  hipEvent_t ev_gen[2] = {nullptr, nullptr}, ev_acc[2] = {nullptr, nullptr}, ev_enter = nullptr;
+  bool gen_valid[2] = {false, false}, acc_valid[2] = {false, false};
+  bool pipeline = true;  // FH_PIPELINE=0: every pass on the main stream
 
   // stats
   fh_stats stats{};
@@ -105,7 +111,7 @@ int fail(fh_ctx* ctx, int code, const std::string& msg);
 SceneDev scene_dev(const fh_ctx* ctx);
 int bvh_build_device(fh_ctx* ctx);                 // bvh_build.hip
 int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_render_layers* layers, uint32_t n_samples, uint32_t max_depth, uint32_t seed);  // render.hip
-int pool_ensure(fh_ctx* ctx, uint32_t capacity);   // render.hip
+int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity);   // render.hip
 void pool_release(fh_ctx* ctx);
 int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int w, int h, const fh_post_params* pp, float* out);  // post.hip
 }  // namespace fh

@@ -474,18 +474,44 @@ FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float t
   return valid && best.prim != 0xffffffffu;
 }
 
+// A wave's share of a work queue: chunks of `chunk` consecutive entries taken from a global cursor.  All members are wave-uniform.
+struct ChunkFeed {
+  uint32_t* cursor;   // global, zeroed per pass (one word per bounce and kernel)
+  uint32_t count, chunk;
+  uint32_t cur = 0, end = 0;
+  bool exhausted = false;
+  FH_D ChunkFeed(uint32_t* c, uint32_t n, uint32_t ch) : cursor(c), count(n), chunk(ch) { exhausted = n == 0u; }
+  // position of the first of up to n entries for the asking lanes; entries at or beyond `end` do not exist (yet): those lanes ask again
+  FH_D uint32_t reserve(uint32_t n)
+  {
+    if (cur >= end && !exhausted) {
+      uint32_t b = 0;
+      if (__lane_id() == 0u) b = atomicAdd(cursor, chunk);
+      b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+      cur = b;
+      end = b + chunk < count ? b + chunk : count;
+      if (b >= count) { exhausted = true; cur = end = 0u; }
+    }
+    const uint32_t base = cur;
+    cur = cur + n < end ? cur + n : end;
+    return base;
+  }
+  FH_D bool drained() const { return exhausted && cur >= end; }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Streaming form of the wave-cooperative traversal.  Rays differ a lot in length (the longest of 64 is
 // ~3x the mean), so a wave that traces one fixed batch runs its node tests with a third of its lanes.
 // Here a wave owns a long private sequence of work items and hands a new ray to lanes whose ray has
-// finished as soon as `refill` of them are idle -- no global atomics, the cursor is wave-uniform.
+// finished as soon as `refill` of them are idle.  Work is taken from the launch's queue in chunks (ChunkFeed): one global atomic
+// per chunk and wave, nothing per ray, and waves that drew short rays simply draw more chunks, so the launch ends balanced.
 // The policy object supplies the work:
 //   bool advance(o, d, tmax, any)      lane-local: the next ray of the lane's current item (a path's next secondary ray), if any
-//   bool take(s, o, d, tmax, any)      the s-th item of the wave's sequence (s = pol.cursor + rank among the asking lanes)
+//   bool take(i, o, d, tmax, any)      queue entry i (i = pol.feed.reserve(n) + rank among the n asking lanes); false past the chunk's end
 //   void commit(hit, h, nodes)         once per ray, after its last candidate was tested
-//   bool drained()                     wave-uniform: the sequence has no item at pol.cursor or beyond
+//   bool drained()                     wave-uniform: the queue is used up
 //   bool followup()                    the lane's current item may have another ray after the current one
-//   uint32_t cursor                    wave-uniform position in the sequence
+//   ChunkFeed feed                     the wave's share of the queue
 // ---------------------------------------------------------------------------------------------
 template <bool MIXED, bool COUNT, bool LDS, bool ALPHA, class Policy>
 FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws, const CoopLds& cl, uint32_t flush, uint32_t refill,
@@ -530,10 +556,9 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
         if (want) got = pol.advance(o, d, tmax, any);  // next ray of the lane's own item, if it has one
         const bool need = want && !got;
         const unsigned long long nm = __ballot(need);
-        if (nm != 0ull && !pol.drained()) {  // (the cursor stops at the end of the sequence)
-          const uint32_t base = pol.cursor;
+        if (nm != 0ull && !pol.drained()) {
+          const uint32_t base = pol.feed.reserve((uint32_t)__popcll(nm));  // wave-uniform
           if (need) got = pol.take(base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u)), o, d, tmax, any);
-          pol.cursor = base + (uint32_t)__popcll(nm);
         }
         if (got) {
           const RayPre rp = ray_prepare(o, d);

@@ -67,7 +67,7 @@ FH_D f3 env_radiance(const FrameDev& fr, f3 d)
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, LayersDev layers, const uint32_t* owned, uint32_t n_owned, uint32_t n_paths)
+__global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, const uint32_t* issued, const uint32_t* owned, uint32_t n_owned, uint32_t n_paths)
 {
   __shared__ SobolRows rows;
   const uint32_t dims[4] = {1u, 1u, 1u, 1u};
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
       bool alive = false;
       const uint32_t i = p % n_owned, k = p / n_owned;  // slot p = sample-major: lanes of a wave hold neighbouring pixels of one sample index
       const uint32_t image_idx = owned[i];
-      const uint32_t n_spp = layers.sample_count[image_idx] + k;
+      const uint32_t n_spp = issued[image_idx] + k;  // sample index = samples started on this pixel so far (pt.cu:423: params.sample_count)
       const uint32_t px = image_idx % fr.width, py = image_idx / fr.width;
       f2 u = cmj_draw(n_spp, image_idx, 0u, fr.seed_hash);
       float uvx = (2.0f * (px + u.x) - fr.width) / fr.height;
@@ -130,6 +130,13 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
     }
     queue_push(&pool.counters[CNT_RAD], pool.q_rad[0], enter, p);
   }
+}
+
+// samples started per owned pixel, bumped after k_generate has read it for every path of the pass
+__global__ void __launch_bounds__(kBlock) k_bump_issued(uint32_t* issued, const uint32_t* owned, uint32_t n_owned, uint32_t n_batch)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_owned) issued[owned[i]] += n_batch;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -196,14 +203,9 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_coop(SceneDev sc, Pool
 }
 
 // ------------------------------------------------------------------------------------------------
-// Streaming kernels (fh_trace.h: traverse_stream): the grid is sized to the resident wave slots of the chip and wave w
-// owns the strided sequence  s -> (s / 64) * (64 * n_waves) + 64 * w + s % 64  of queue positions, so a launch of any size
-// is covered, neighbouring lanes read neighbouring queue entries, and finished lanes get their next ray without atomics.
-FH_D uint32_t stream_index(uint32_t s, uint32_t wave, uint32_t n_waves) { return (s >> 6) * (n_waves << 6) + (wave << 6) + (s & 63u); }
+// Streaming kernels (fh_trace.h: traverse_stream): the grid is sized to the resident wave slots of the chip; every wave draws
+// chunks of the bounce's queue from a global cursor (ChunkFeed) and hands the rays to its lanes as they become idle.
 
-// XCD-sliced variant: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MB L2.  Giving XCD x the
-// x-th contiguous eighth of the queue keeps rays that are neighbours in the queue (neighbouring pixels / hit points) behind one
-// L2 instead of spreading every part of the BVH over all eight.  Speed only: any block-to-XCD placement gives the same result.
 // instrumented build: per-lane histogram of nodes visited per ray (8 bins x 16 bits; a lane traces far fewer than 65535 rays),
 // flushed once per lane instead of one contended atomic per ray
 struct HistPack {
@@ -215,42 +217,20 @@ struct HistPack {
   }
 };
 
-struct StreamSlice {
-  uint32_t lo, hi, wave, n_waves;  // queue range of this wave's XCD share, wave index and wave count inside the share
-  FH_D StreamSlice(uint32_t count, bool sliced)
-  {
-    const uint32_t wave_in_block = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
-    if (sliced && (gridDim.x & 7u) == 0u) {
-      const uint32_t x = blockIdx.x & 7u;
-      lo = (uint32_t)(((unsigned long long)count * x) >> 3);
-      hi = (uint32_t)(((unsigned long long)count * (x + 1u)) >> 3);
-      wave = (blockIdx.x >> 3) * waves_per_block + wave_in_block;
-      n_waves = (gridDim.x >> 3) * waves_per_block;
-    } else {
-      lo = 0u; hi = count;
-      wave = blockIdx.x * waves_per_block + wave_in_block;
-      n_waves = gridDim.x * waves_per_block;
-    }
-  }
-  FH_D uint32_t index(uint32_t s) const { return lo + stream_index(s, wave, n_waves); }
-};
-
 template <bool COUNT>
 struct ClosestStream {
   const PoolDev& pool;
   const uint32_t* q;
-  StreamSlice sl;
-  uint32_t cursor = 0;
+  ChunkFeed feed;
   uint32_t p = 0;
   uint32_t n_rays = 0;
   unsigned long long* hist;
   HistPack hp;
-  FH_D ClosestStream(const PoolDev& pl, const uint32_t* qq, const StreamSlice& s, unsigned long long* hs) : pool(pl), q(qq), sl(s), hist(hs) {}
+  FH_D ClosestStream(const PoolDev& pl, const uint32_t* qq, const ChunkFeed& f, unsigned long long* hs) : pool(pl), q(qq), feed(f), hist(hs) {}
   FH_D bool advance(f3&, f3&, float&, bool&) { return false; }
-  FH_D bool take(uint32_t s, f3& o, f3& d, float& tmax, bool& any)
+  FH_D bool take(uint32_t i, f3& o, f3& d, float& tmax, bool& any)
   {
-    const uint32_t i = sl.index(s);
-    if (i >= sl.hi) return false;
+    if (i >= feed.end) return false;
     p = q[i];
     const float4 o4 = pool.ray_o[p], d4 = pool.ray_d[p];
     o = mk3(o4); d = mk3(d4); tmax = o4.w; any = false;
@@ -262,19 +242,19 @@ struct ClosestStream {
     pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
     if (COUNT) hp.add(nodes);
   }
-  FH_D bool drained() const { return sl.index(cursor) >= sl.hi; }
+  FH_D bool drained() const { return feed.drained(); }
   FH_D bool followup() const { return false; }
 };
 
 template <bool COUNT, bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t sliced)
+__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk)
 {
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
   const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_RAD];
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
-  ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], StreamSlice(count, sliced != 0u), tc.hist);
+  ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, chunk), tc.hist);
   traverse_stream<false, COUNT, false, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, nullptr, 0, &sc);
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
@@ -822,15 +802,14 @@ struct SecondaryStream {
   const SceneDev& sc;
   const FrameDev& fr;
   const PoolDev& pool;
-  StreamSlice sl;
-  uint32_t cursor = 0;
+  ChunkFeed feed;
   uint32_t p = 0, slot = 0;
   bool active = false;
   f3 L;
   uint32_t n_rays = 0;
   unsigned long long* hist;
   HistPack hp;
-  FH_D SecondaryStream(const SceneDev& s, const FrameDev& f, const PoolDev& pl, const StreamSlice& ss, unsigned long long* hs) : sc(s), fr(f), pool(pl), sl(ss), L(mk3(0.0f)), hist(hs) {}
+  FH_D SecondaryStream(const SceneDev& s, const FrameDev& f, const PoolDev& pl, const ChunkFeed& cf, unsigned long long* hs) : sc(s), fr(f), pool(pl), feed(cf), L(mk3(0.0f)), hist(hs) {}
   // first slot >= from of path p that holds a ray
   FH_D bool scan(uint32_t from, f3& o, f3& d, float& tmax, bool& any)
   {
@@ -857,10 +836,9 @@ struct SecondaryStream {
     finish();
     return false;
   }
-  FH_D bool take(uint32_t s, f3& o, f3& d, float& tmax, bool& any)
+  FH_D bool take(uint32_t i, f3& o, f3& d, float& tmax, bool& any)
   {
-    const uint32_t i = sl.index(s);
-    if (i >= sl.hi) return false;
+    if (i >= feed.end) return false;
     p = pool.q_sec[i];
     L = mk3(pool.rad[p]);
     active = true;
@@ -880,12 +858,12 @@ struct SecondaryStream {
       if (!hit) L += mk3(pool.sec_c[k]);
     }
   }
-  FH_D bool drained() const { return sl.index(cursor) >= sl.hi; }
+  FH_D bool drained() const { return feed.drained(); }
   FH_D bool followup() const { return active && slot < SEC_LIGHT; }
 };
 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t sliced)
+__global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk)
 {
   __shared__ uint2 lds_stack[kLdsStack * kBlock];
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
@@ -893,7 +871,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, 
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
-  SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, StreamSlice(count, sliced != 0u), tc.hist);
+  SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, chunk), tc.hist);
   traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
   pol.finish();
   if (COUNT) {
@@ -1122,14 +1100,14 @@ hipEvent_t take_event(fh_ctx* ctx)
 }
 
 struct Span {
-  fh_ctx* ctx; int kind; hipEvent_t a = nullptr, b = nullptr; bool on;
-  Span(fh_ctx* c, int k) : ctx(c), kind(k), on((c->flags & FH_FLAG_TIME_KERNELS) != 0)
+  fh_ctx* ctx; hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr; bool on;
+  Span(fh_ctx* c, hipStream_t s, int k) : ctx(c), st(s), kind(k), on((c->flags & FH_FLAG_TIME_KERNELS) != 0)
   {
-    if (on) { a = take_event(ctx); b = take_event(ctx); (void)hipEventRecord(a, ctx->stream); }
+    if (on) { a = take_event(ctx); b = take_event(ctx); (void)hipEventRecord(a, st); }
   }
   ~Span()
   {
-    if (on) { (void)hipEventRecord(b, ctx->stream); ctx->spans.push_back({a, b, kind}); }
+    if (on) { (void)hipEventRecord(b, st); ctx->spans.push_back({a, b, kind}); }
   }
 };
 
@@ -1162,20 +1140,30 @@ SceneDev scene_dev(const fh_ctx* ctx)
 
 void pool_release(fh_ctx* ctx)
 {
-  for (void* p : ctx->pool_allocs) (void)hipFree(p);
-  ctx->pool_allocs.clear();
-  ctx->pool = PoolDev{};
+  for (int k = 0; k < 2; ++k) {
+    for (void* p : ctx->pool_allocs[k]) (void)hipFree(p);
+    ctx->pool_allocs[k].clear();
+    ctx->pool[k] = PoolDev{};
+    ctx->counters_in_flight[k] = false;
+  }
 }
 
-int pool_ensure(fh_ctx* ctx, uint32_t capacity)
+int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
 {
-  if (ctx->pool.capacity >= capacity) return FH_OK;
-  pool_release(ctx);
-  PoolDev& P = ctx->pool;
+  if (ctx->pool[slot].capacity >= capacity) return FH_OK;
+  if (ctx->pool[slot].capacity) {  // growing: nothing may still be running out of the old buffers
+    FH_HIP(hipStreamSynchronize(ctx->stream));
+    FH_HIP(hipStreamSynchronize(ctx->stream2));
+    for (void* p : ctx->pool_allocs[slot]) (void)hipFree(p);
+    ctx->pool_allocs[slot].clear();
+    ctx->pool[slot] = PoolDev{};
+    ctx->counters_in_flight[slot] = false;
+  }
+  PoolDev& P = ctx->pool[slot];
   auto alloc = [&](auto*& ptr, size_t count) -> hipError_t {
     void* raw = nullptr;
     const hipError_t e = hipMalloc(&raw, count * sizeof(*ptr));
-    if (e == hipSuccess) { ctx->pool_allocs.push_back(raw); ptr = (decltype(ptr))raw; }
+    if (e == hipSuccess) { ctx->pool_allocs[slot].push_back(raw); ptr = (decltype(ptr))raw; }
     return e;
   };
   const size_t n = capacity;
@@ -1195,13 +1183,10 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (!ctx->scene_loaded || !ctx->bvh_valid) return fail(ctx, FH_E_INVALID, "fh_render: scene not uploaded or BVH not built");
   if (ctx->width == 0 || ctx->height == 0 || !ctx->d_sample_count) return fail(ctx, FH_E_INVALID, "fh_render: resolution not set");
   if (ctx->n_owned == 0 || n_samples == 0) return FH_OK;
-  hipStream_t st = ctx->stream;
-
   uint32_t target = ctx->pool_target > ctx->n_owned ? ctx->pool_target : ctx->n_owned;
   uint32_t batch = target / ctx->n_owned;
   if (batch > n_samples) batch = n_samples;
   if (batch < 1) batch = 1;
-  { const int rc = pool_ensure(ctx, ctx->n_owned * batch); if (rc) return rc; }
 
   FrameDev fr{};
   fr.width = ctx->width; fr.height = ctx->height;
@@ -1236,12 +1221,15 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   L.sample_count = ctx->d_sample_count;
 
   const SceneDev sc = scene_dev(ctx);
-  const PoolDev& pool = ctx->pool;
   const bool count = (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) != 0;
   TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2, ctx->d_trace_counters + 6, ctx->d_trace_counters + 7, ctx->d_trace_counters + 10};
   TraceCounters tc_shadow{ctx->d_trace_counters + 3, ctx->d_trace_counters + 4, ctx->d_trace_counters + 5, ctx->d_trace_counters + 8, ctx->d_trace_counters + 9, ctx->d_trace_counters + 18};
 
-  if (!ctx->render_pending) { (void)hipEventRecord(ctx->ev_render_begin, st); ctx->render_pending = true; }
+  if (!ctx->render_pending) { (void)hipEventRecord(ctx->ev_render_begin, ctx->stream); ctx->render_pending = true; }
+  // whatever the caller queued on the main stream before this call (clears, uploads) comes first on the second stream too
+  FH_HIP(hipEventRecord(ctx->ev_enter, ctx->stream));
+  FH_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_enter, 0));
+  bool used_stream2 = false;
 
   if (max_depth > 64) return fail(ctx, FH_E_INVALID, "fh_render: max_depth > 64 is not supported");
   hipDeviceProp_t prop;
@@ -1258,8 +1246,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const bool stream = coop && !(stream_env && stream_env[0] == '0');
   // 5 blocks (20 waves) per CU: all resident at the kernels' LDS / register budgets, and measured faster than 8 (fewer cache conflicts)
   uint32_t stream_grid = (uint32_t)prop.multiProcessorCount * 5u, stream_refill = 24u;
-  uint32_t xcd_slice = 0u;  // measured: no difference on the 1M-triangle soup (2933 vs 2934 Msamples/s), so the balanced interleave stays the default
-  if (const char* e = getenv("FH_XCD_SLICE")) xcd_slice = (uint32_t)atoi(e);
+  uint32_t stream_chunk = 64u;  // queue entries a wave takes per global atomic (64/128 equal on big launches, 64 better on small ones)
+  if (const char* e = getenv("FH_STREAM_CHUNK")) { const int v = atoi(e); if (v >= 16 && v <= 65536) stream_chunk = (uint32_t)v; }
   uint32_t exp_lds = 0;  // experiment: extra dynamic LDS per block to lower the occupancy
   if (const char* e = getenv("FH_EXP_LDS")) exp_lds = (uint32_t)atoi(e);
   if (const char* e = getenv("FH_STREAM_GRID")) { const int v = atoi(e); if (v >= 8 && v <= 8192) stream_grid = (uint32_t)v & ~7u; }
@@ -1269,19 +1257,33 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
     const uint32_t n_paths = ctx->n_owned * nb;
     const uint32_t grid = grid_for(n_paths);
+    // two passes in flight: pass j lives in pool j % 2 on stream j % 2.  Only two things order consecutive passes: the sample
+    // indices (k_generate reads what k_bump_issued of the pass before wrote) and the running means (k_accumulate of pass j
+    // follows k_accumulate of pass j - 1, so the floating-point result is that of a serial run)
+    const int slot = ctx->pipeline ? (int)(ctx->pass_seq & 1ull) : 0;
+    ctx->pass_seq++;
+    hipStream_t st = slot ? ctx->stream2 : ctx->stream;
+    used_stream2 = used_stream2 || slot == 1;
+    { const int rc = pool_ensure(ctx, slot, ctx->n_owned * batch); if (rc) return rc; }
+    const PoolDev& pool = ctx->pool[slot];
     FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
-    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, fr, pool, L, ctx->d_owned, ctx->n_owned, n_paths);
+    if (ctx->gen_valid[slot ^ 1]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_gen[slot ^ 1], 0));
+    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, n_paths);
+    hipLaunchKernelGGL(k_bump_issued, dim3((ctx->n_owned + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, nb);
+    FH_HIP(hipEventRecord(ctx->ev_gen[slot], st));
+    ctx->gen_valid[slot] = true;
     ctx->stats.paths += n_paths;
     // bounces run as bounce-synchronous wavefront kernels; the survivors are finished by k_tail.  Adaptive mode picks the
     // first depth at which an earlier pass had at most kTailPaths survivors (counts come from an asynchronous snapshot of
     // the device counters: no host/device synchronisation)
     constexpr uint32_t kTailPaths = 65536;
-    if (ctx->counters_in_flight && hipEventQuery(ctx->ev_counters) == hipSuccess) {
-      ctx->counters_in_flight = false;
-      const uint32_t wd = ctx->counters_wave_depth;
+    for (int k = 0; k < 2; ++k) {
+      if (!(ctx->counters_in_flight[k] && hipEventQuery(ctx->ev_counters[k]) == hipSuccess)) continue;
+      ctx->counters_in_flight[k] = false;
+      const uint32_t wd = ctx->counters_wave_depth[k];
       uint32_t pick = wd + 1u;  // too many survivors at the old switch depth: go one bounce deeper
       for (uint32_t d = 1; d <= wd; ++d)
-        if (ctx->h_counters[d * kCounterStride + CNT_RAD] <= kTailPaths) { pick = d; break; }
+        if (ctx->h_counters[k][d * kCounterStride + CNT_RAD] <= kTailPaths) { pick = d; break; }
       ctx->auto_wave_depth = pick;
     }
     uint32_t wave_depth = ctx->tail_depth ? ctx->tail_depth : ctx->auto_wave_depth;
@@ -1289,14 +1291,14 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     if (wave_depth > max_depth) wave_depth = max_depth;
     for (uint32_t depth = 0; depth < wave_depth; ++depth) {
       {
-        Span sp(ctx, 0);
+        Span sp(ctx, st, 0);
         if (wide) {
           if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
           else hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
         } else if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc, pool, depth, tc_closest,
-                               coop_flush, stream_refill, xcd_slice);
+                               coop_flush, stream_refill, stream_chunk);
           }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
@@ -1310,13 +1312,13 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         ctx->stats.n_closest_launches++;
       }
       {
-        Span sp(ctx, 2);
+        Span sp(ctx, st, 2);
         hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, ctx->n_classes);
         for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pool, c, depth);
         if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pool);
       }
       {
-        Span sp(ctx, 1);
+        Span sp(ctx, st, 1);
         if (wide) {
           const bool lights = sc.n_lights > 0;
           if (count && lights) hipLaunchKernelGGL((k_trace_secondary<true, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
@@ -1326,7 +1328,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         } else if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc,
-                               fr, pool, depth, tc_shadow, coop_flush, stream_refill, xcd_slice);
+                               fr, pool, depth, tc_shadow, coop_flush, stream_refill, stream_chunk);
           }); }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
@@ -1343,17 +1345,22 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       }
     }
     if (wave_depth < max_depth) {
-      Span sp(ctx, 3);
+      Span sp(ctx, st, 3);
       hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), 0, st, sc, fr, pool, wave_depth);
     }
+    if (ctx->acc_valid[slot ^ 1]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[slot ^ 1], 0));
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb);
-    if (!ctx->counters_in_flight && ctx->h_counters) {
-      FH_HIP(hipMemcpyAsync(ctx->h_counters, pool.counters, sizeof(uint32_t) * kCounterStride * (max_depth + 1), hipMemcpyDeviceToHost, st));
-      FH_HIP(hipEventRecord(ctx->ev_counters, st));
-      ctx->counters_in_flight = true;
-      ctx->counters_wave_depth = wave_depth;
+    FH_HIP(hipEventRecord(ctx->ev_acc[slot], st));
+    ctx->acc_valid[slot] = true;
+    if (!ctx->counters_in_flight[slot] && ctx->h_counters[slot]) {
+      FH_HIP(hipMemcpyAsync(ctx->h_counters[slot], pool.counters, sizeof(uint32_t) * kCounterStride * (max_depth + 1), hipMemcpyDeviceToHost, st));
+      FH_HIP(hipEventRecord(ctx->ev_counters[slot], st));
+      ctx->counters_in_flight[slot] = true;
+      ctx->counters_wave_depth[slot] = wave_depth;
     }
   }
+  // join: later work on the main stream (pack, post-process, copies, the caller's clears) sees every pass of this call
+  if (used_stream2 && ctx->acc_valid[1]) FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_acc[1], 0));
   FH_HIP(hipGetLastError());
   return FH_OK;
 }
