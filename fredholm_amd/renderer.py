@@ -8,6 +8,7 @@ to the C ABI of libfredholm_hip.so.  Errors surface as FredholmError, the analog
 std::runtime_error the reference throws from CUDA_CHECK / OPTIX_CHECK.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -153,6 +154,7 @@ class Renderer:
         self.m_width = self.m_height = 0
         self.seed = 1  # params.seed = 1 (renderer.h:664)
         self._keep = None
+        self.m_scene = None
 
     # -- OptiX plumbing kept for call-compatibility
     def create_module(self, filepath=None):
@@ -192,11 +194,20 @@ class Renderer:
 
     # -- scene (renderer.h:354-432)
     def load_scene(self, scene, clear=True):
-        """scene: a .obj path (renderer.h:354: load_scene(filepath, clear)) or a dict of flat arrays as produced by
-        fredholm_amd.scenes (the layout Scene exposes, scene.h:103-135)."""
+        """scene: a .obj / .gltf path (renderer.h:354: load_scene(filepath, clear); clear=False appends, as rtcamp8.cpp:114-115 adds
+        a camera .gltf to an .obj), a fredholm_amd.scene.Scene, or a dict of flat arrays as produced by fredholm_amd.scenes (the
+        layout Scene exposes, scene.h:103-135)."""
+        from .scene import Scene
         if isinstance(scene, (str, bytes)) or hasattr(scene, "__fspath__"):
-            from . import scenes as _scenes
-            scene = _scenes.load_obj(str(scene))
+            if self.m_scene is None:
+                self.m_scene = Scene()
+            self.m_scene.load_model(os.fspath(scene) if not isinstance(scene, bytes) else scene.decode(), clear)
+            scene = self.m_scene.as_dict()
+        elif isinstance(scene, Scene):
+            self.m_scene = scene
+            scene = scene.as_dict()
+        else:
+            self.m_scene = None  # flat arrays: no node hierarchy, no camera node
         v = np.ascontiguousarray(scene["vertices"], dtype=np.float32).reshape(-1, 3)
         n = np.ascontiguousarray(scene["normals"], dtype=np.float32).reshape(-1, 3)
         t = np.ascontiguousarray(scene["texcoords"], dtype=np.float32).reshape(-1, 2)
@@ -308,8 +319,21 @@ class Renderer:
         self._ck(N.lib().fh_unpack_shard(self._ctx, C.c_uint32(rank), C.c_uint32(world), C.c_void_p(packed_ptr), C.c_uint32(floats_per_pixel), C.c_void_p(layer_ptr)), "fh_unpack_shard")
 
     # -- the hot path (renderer.h:657-736)
+    def set_time(self, time):
+        """renderer.h:614-640: advance the animation, re-upload the instance transforms, rebuild the acceleration structure"""
+        if self.m_scene is None:
+            raise N.FredholmError("set_time: the scene was not loaded from a file or a Scene")
+        self.m_scene.update_animation(time)
+        o2w, w2o = self.m_scene.transforms_3x4()
+        self.set_transforms(o2w, w2o)
+        self.build_ias()
+
     def render(self, camera, bg_color, render_layer, n_samples, max_depth):
         cam = camera.as_c()
+        if self.m_scene is not None and self.m_scene.m_has_camera_transform:  # renderer.h:670-676: a camera node overrides the pose
+            flat = self.m_scene.camera_transform_3x4().reshape(12)
+            for i in range(12):
+                cam.transform[i] = float(flat[i])
         bg = np.asarray(bg_color, dtype=np.float32)
         layers = render_layer.as_c()
         self._ck(N.lib().fh_render(self._ctx, C.byref(cam), N.ptr(bg), C.byref(layers), C.c_uint32(n_samples), C.c_uint32(max_depth), C.c_uint32(self.seed)), "fh_render")

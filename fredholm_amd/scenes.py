@@ -267,11 +267,9 @@ def load_obj(path):
                 tri = (cs[0], cs[k], cs[k + 1])
                 p = [np.asarray(pos[c[0] - 1 if c[0] > 0 else len(pos) + c[0]], dtype=np.float32) for c in tri]
                 has_n, has_t = all(c[2] for c in tri), all(c[1] for c in tri)
-                if not has_n:
-                    e1, e2 = p[1] - p[0], p[2] - p[0]
-                    e1, e2 = e1 / np.linalg.norm(e1), e2 / np.linalg.norm(e2)
-                    fn = np.cross(e1, e2)
-                    fn = (fn / np.linalg.norm(fn)).astype(np.float32)
+                if not has_n:  # scene.cpp:361-371, in single precision operation by operation (the C++ reader does the same)
+                    e1, e2 = _normalize32(p[1] - p[0]), _normalize32(p[2] - p[0])
+                    fn = _normalize32(np.asarray([e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]], dtype=np.float32))
                 base = len(verts)
                 for j, c in enumerate(tri):
                     verts.append(p[j])
@@ -293,6 +291,12 @@ def load_obj(path):
 _MTL_TEXTURES = {"map_Kd": ("base_color_texture_id", True), "map_Ks": ("specular_color_texture_id", True), "map_Pr": ("specular_roughness_texture_id", False),
                  "map_Pm": ("metalness_texture_id", False), "map_bump": ("heightmap_texture_id", False), "map_Bump": ("heightmap_texture_id", False),
                  "bump": ("heightmap_texture_id", False), "norm": ("normalmap_texture_id", False), "map_d": ("alpha_texture_id", False)}
+
+
+def _normalize32(v):
+    x, y, z = np.float32(v[0]), np.float32(v[1]), np.float32(v[2])
+    l = np.sqrt(np.float32(np.float32(x * x + y * y) + z * z))
+    return np.asarray([x / l, y / l, z / l], dtype=np.float32)
 
 
 def _isnum(s):
@@ -389,3 +393,115 @@ def gradient_ibl(w=64, h=32):
     img[..., :3] += 30.0 * blob[..., None] * np.asarray([1.0, 0.85, 0.6], dtype=np.float32)
     img[..., 3] = 1.0
     return img
+
+
+def write_gltf(scene, path, submeshes, nodes, roots, animations=(), cameras=0, embed=False):
+    """Write a flat scene as glTF 2.0 the way the reference's loader wants it (scene.cpp:692-741: 16-bit indices, float3
+    POSITION / NORMAL, float2 TEXCOORD_0, one buffer).  For tests and tools.
+      submeshes: list of face-index arrays, one glTF mesh each; a mesh gets one primitive per material it uses
+      nodes:     list of dicts with optional keys mesh, translation, rotation (x, y, z, w), scale, matrix (16, column-major),
+                 children, camera
+      roots:     node indices of scene 0
+      animations: list of channel lists; a channel = (node, path, key times, key values)
+    Materials carry base colour, roughness, metalness, emissive factor and the base-colour / normal / emission /
+    metallic-roughness textures (written next to the file as PNG, top row first, so that the loader's v -> 1 - v plus its
+    vertical image flip land on the same texels)."""
+    import base64
+    import json
+    import os
+    base = os.path.splitext(path)[0]
+    blob = bytearray()
+    views, accessors = [], []
+
+    def add(arr, target, ctype, typ, minmax=False):
+        while len(blob) % 4:
+            blob.append(0)
+        raw = np.ascontiguousarray(arr)
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": raw.nbytes, **({"target": target} if target else {})})
+        blob.extend(raw.tobytes())
+        acc = {"bufferView": len(views) - 1, "componentType": ctype, "count": int(raw.shape[0]), "type": typ}
+        if minmax:
+            acc["min"], acc["max"] = [float(v) for v in np.atleast_1d(raw.min(axis=0))], [float(v) for v in np.atleast_1d(raw.max(axis=0))]
+        accessors.append(acc)
+        return len(accessors) - 1
+
+    v, n, t, idx, mid = scene["vertices"], scene["normals"], scene["texcoords"], scene["indices"], scene["material_ids"]
+    meshes = []
+    for faces in submeshes:
+        prims = []
+        faces = np.asarray(faces, dtype=np.int64)
+        for m in sorted(set(int(x) for x in mid[faces])):
+            f = faces[mid[faces] == m]
+            vid = idx[f].reshape(-1)
+            assert len(vid) < 65536
+            uv = t[vid].astype(np.float32).copy()
+            uv[:, 1] = np.float32(1.0) - uv[:, 1]  # undone by the loader (scene.cpp:733)
+            prims.append({"attributes": {"POSITION": add(v[vid].astype(np.float32), 34962, 5126, "VEC3", True), "NORMAL": add(n[vid].astype(np.float32), 34962, 5126, "VEC3"),
+                                         "TEXCOORD_0": add(uv, 34962, 5126, "VEC2")},
+                          "indices": add(np.arange(len(vid), dtype=np.uint16), 34963, 5123, "SCALAR"), "material": m})
+        meshes.append({"primitives": prims})
+    anims = []
+    for channels in animations:
+        samplers, chans = [], []
+        for node, pth, times, values in channels:
+            vals = np.asarray(values, dtype=np.float32)
+            samplers.append({"input": add(np.asarray(times, dtype=np.float32), None, 5126, "SCALAR", True), "output": add(vals, None, 5126, "VEC4" if pth == "rotation" else "VEC3"),
+                             "interpolation": "LINEAR"})
+            chans.append({"sampler": len(samplers) - 1, "target": {"node": node, "path": pth}})
+        anims.append({"samplers": samplers, "channels": chans})
+    textures = scene.get("textures") or []
+    images = []
+    for k, tex in enumerate(textures):
+        image_io.write_png(f"{base}_img{k}.png", np.asarray(tex["rgba8"])[::-1], filter_type=(k + 1) % 5)
+        images.append({"uri": f"{os.path.basename(base)}_img{k}.png"})
+    mats = []
+    for m in scene["materials"]:
+        pmr = {"baseColorFactor": [float(x) for x in m["base_color"]] + [1.0], "roughnessFactor": float(m["specular_roughness"]), "metallicFactor": float(m["metalness"])}
+        g = {"pbrMetallicRoughness": pmr, "emissiveFactor": [float(x) for x in m["emission_color"]]}
+        if m["base_color_texture_id"] >= 0: pmr["baseColorTexture"] = {"index": int(m["base_color_texture_id"])}
+        if m["metallic_roughness_texture_id"] >= 0: pmr["metallicRoughnessTexture"] = {"index": int(m["metallic_roughness_texture_id"])}
+        if m["normalmap_texture_id"] >= 0: g["normalTexture"] = {"index": int(m["normalmap_texture_id"])}
+        if m["emission_texture_id"] >= 0: g["emissiveTexture"] = {"index": int(m["emission_texture_id"])}
+        if m["coat"] > 0: g["extensions"] = {"KHR_materials_clearcoat": {"clearcoatFactor": float(m["coat"]), "clearcoatRoughnessFactor": float(m["coat_roughness"])}}
+        mats.append(g)
+    doc = {"asset": {"version": "2.0", "generator": "fredholm_amd.scenes.write_gltf"}, "scene": 0, "scenes": [{"nodes": list(roots)}], "nodes": [dict(nd) for nd in nodes], "meshes": meshes,
+           "materials": mats, "accessors": accessors, "bufferViews": views,
+           "buffers": [{"byteLength": len(blob), "uri": ("data:application/octet-stream;base64," + base64.b64encode(bytes(blob)).decode()) if embed else os.path.basename(base) + ".bin"}]}
+    if anims: doc["animations"] = anims
+    if images:
+        doc["images"] = images
+        doc["textures"] = [{"source": k} for k in range(len(images))]
+    if cameras:
+        doc["cameras"] = [{"type": "perspective", "perspective": {"yfov": 1.0, "znear": 0.01}} for _ in range(cameras)]
+    if not embed:
+        open(base + ".bin", "wb").write(bytes(blob))
+    json.dump(doc, open(path, "w"), indent=1)
+
+
+def animated_cornell_gltf(path, embed=False, textured=True):
+    """Test asset: the Cornell box as a glTF scene graph -- room (root), a key-framed root node carrying the short block with the
+    tall block as its child (so the child inherits the animation), a static scaled/rotated node, and a camera node."""
+    sc = textured_cornell_box() if textured else cornell_box()
+    if textured:
+        # keep only what glTF can express (scene.cpp:487-549): base colour, metallic-roughness, normal, emission textures
+        for f in ("specular_color_texture_id", "specular_roughness_texture_id", "metalness_texture_id", "coat_texture_id", "coat_roughness_texture_id", "heightmap_texture_id",
+                  "alpha_texture_id"):
+            sc["materials"][f] = -1
+    nf = sc["indices"].shape[0]
+    room, short, tall, rest = np.arange(0, 12), np.arange(12, 24), np.arange(24, 36), np.arange(36, nf)
+    submeshes = [room, short, tall] + ([rest] if len(rest) else [])
+    s = float(np.sin(0.3)), float(np.cos(0.3))
+    nodes = [{"mesh": 0, "name": "room"},
+             {"mesh": 1, "name": "short", "translation": [0.1, 0.0, 0.05], "children": [2]},
+             {"mesh": 2, "name": "tall", "translation": [-0.05, 0.0, 0.1], "rotation": [0.0, s[0], 0.0, s[1]], "scale": [0.9, 1.05, 0.9]},
+             {"camera": 0, "name": "cam", "matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.05, 1.0, 1.2, 1]}]
+    roots = [0, 1, 3]
+    if len(rest):
+        nodes.append({"mesh": 3, "name": "cards", "scale": [1.0, 1.0, 1.0]})
+        roots.append(4)
+    h = np.sqrt(0.5)
+    animations = [[(1, "translation", [0.0, 0.5, 1.5, 2.0], [[0.1, 0.0, 0.05], [0.2, 0.05, 0.0], [0.0, 0.1, 0.1], [0.1, 0.0, 0.05]]),
+                   (1, "rotation", [0.0, 1.0, 2.0], [[0, 0, 0, 1], [0, float(h), 0, float(h)], [0, 1, 0, 0]]),
+                   (1, "scale", [0.0, 2.0], [[1, 1, 1], [0.8, 1.2, 0.8]])]]
+    write_gltf(sc, path, submeshes, nodes, roots, animations, cameras=1, embed=embed)
+    return sc

@@ -9,6 +9,7 @@
 // Conversion conventions follow stb_image's documented behaviour: grey -> r=g=b, missing alpha -> 255 (1.0f for .hdr),
 // 16-bit samples -> high byte, palette -> RGBA through PLTE/tRNS, .hdr texel = mantissa * 2^(exponent - 136).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -426,6 +427,69 @@ inline ImageF load_hdr(const std::filesystem::path& path)  // stbi_loadf(path, .
     }
   }
   return img;
+}
+
+// ---------------------------------------------------------------------------------------------- PNG writer
+// stbi_write_png's role in app/rtcamp8.cpp:287-289.  8-bit RGBA, filter 0, zlib stream of stored (uncompressed) deflate blocks:
+// valid for every PNG reader, no compressor needed.
+inline uint32_t crc32(const uint8_t* p, size_t n, uint32_t crc = 0)
+{
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    init = true;
+  }
+  crc = ~crc;
+  for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+  return ~crc;
+}
+
+inline void write_png_rgba8(const std::filesystem::path& path, int width, int height, const uint8_t* rgba)
+{
+  std::vector<uint8_t> raw;
+  raw.reserve((size_t(width) * 4 + 1) * size_t(height));
+  for (int y = 0; y < height; ++y) {
+    raw.push_back(0);
+    raw.insert(raw.end(), rgba + size_t(y) * width * 4, rgba + size_t(y + 1) * width * 4);
+  }
+  std::vector<uint8_t> z = {0x78, 0x01};
+  uint32_t a = 1, b = 0;  // Adler-32
+  for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+    const size_t n = std::min<size_t>(65535, raw.size() - pos);
+    z.push_back(pos + n >= raw.size() ? 1 : 0);
+    z.push_back(uint8_t(n & 0xff)); z.push_back(uint8_t(n >> 8));
+    z.push_back(uint8_t(~n & 0xff)); z.push_back(uint8_t((~n >> 8) & 0xff));
+    z.insert(z.end(), raw.begin() + long(pos), raw.begin() + long(pos + n));
+    for (size_t i = pos; i < pos + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+    pos += n;
+    if (n == 0) break;
+  }
+  const uint32_t adler = (b << 16) | a;
+  for (int k = 3; k >= 0; --k) z.push_back(uint8_t(adler >> (8 * k)));
+  std::ofstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("failed to write " + path.generic_string());
+  auto be = [](uint32_t v, uint8_t* o) { o[0] = uint8_t(v >> 24); o[1] = uint8_t(v >> 16); o[2] = uint8_t(v >> 8); o[3] = uint8_t(v); };
+  auto chunk = [&](const char* type, const std::vector<uint8_t>& body) {
+    std::vector<uint8_t> c(8 + body.size() + 4);
+    be(uint32_t(body.size()), c.data());
+    std::memcpy(c.data() + 4, type, 4);
+    if (!body.empty()) std::memcpy(c.data() + 8, body.data(), body.size());
+    be(crc32(c.data() + 4, 4 + body.size()), c.data() + 8 + body.size());
+    f.write(reinterpret_cast<const char*>(c.data()), long(c.size()));
+  };
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  f.write(reinterpret_cast<const char*>(sig), 8);
+  std::vector<uint8_t> ihdr(13);
+  be(uint32_t(width), ihdr.data()); be(uint32_t(height), ihdr.data() + 4);
+  ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+  chunk("IHDR", ihdr);
+  chunk("IDAT", z);
+  chunk("IEND", {});
 }
 
 }  // namespace fredholm::image_io

@@ -60,9 +60,12 @@ class Renderer
   void load_arhosek_sky(float turbidity, float albedo) { cwl::check(m_ctx, fh_load_arhosek_sky(m_ctx, turbidity, albedo), "fh_load_arhosek_sky"); }
   void clear_arhosek_sky() { cwl::check(m_ctx, fh_clear_arhosek_sky(m_ctx), "fh_clear_arhosek_sky"); }
 
-  void set_time(float time)  // renderer.h:614-640: animation update + acceleration-structure rebuild
+  void set_time(float time)  // renderer.h:614-640: animation update, transform re-upload, acceleration-structure rebuild
   {
     m_scene.update_animation(time);
+    std::vector<float> o2w, w2o;
+    m_scene.transforms_3x4(o2w, w2o);
+    if (!o2w.empty()) cwl::check(m_ctx, fh_set_transforms(m_ctx, uint32_t(o2w.size() / 12), o2w.data(), w2o.data()), "fh_set_transforms");
     build_ias();
   }
   void set_resolution(uint32_t width, uint32_t height)  // renderer.h:642-648
@@ -96,13 +99,7 @@ class Renderer
   {
     if (!m_scene.is_valid()) throw std::runtime_error("invalid scene");
     std::vector<float> o2w, w2o;
-    for (const Mat4& m : m_scene.m_transforms) {
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 4; ++c) o2w.push_back(m[c][r]);
-      const Mat4 inv = affine_inverse(m);
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 4; ++c) w2o.push_back(inv[c][r]);
-    }
+    m_scene.transforms_3x4(o2w, w2o);
     fh_scene_desc d{};
     d.n_vertices = uint32_t(m_scene.m_vertices.size());
     d.vertices = reinterpret_cast<const float*>(m_scene.m_vertices.data());
@@ -124,23 +121,6 @@ class Renderer
     d.textures = tex.empty() ? nullptr : tex.data();
     cwl::check(m_ctx, fh_scene_upload(m_ctx, &d), "fh_scene_upload");
   }
-  static Mat4 affine_inverse(const Mat4& m)
-  {
-    // inverse of [A t; 0 1] with A the upper-left 3x3 (column-major storage)
-    const float a = m[0][0], b = m[1][0], c = m[2][0], d = m[0][1], e = m[1][1], f = m[2][1], g = m[0][2], h = m[1][2], i = m[2][2];
-    const float det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-    const float id = 1.0f / det;
-    Mat4 r;
-    r[0][0] = (e * i - f * h) * id; r[1][0] = (c * h - b * i) * id; r[2][0] = (b * f - c * e) * id;
-    r[0][1] = (f * g - d * i) * id; r[1][1] = (a * i - c * g) * id; r[2][1] = (c * d - a * f) * id;
-    r[0][2] = (d * h - e * g) * id; r[1][2] = (b * g - a * h) * id; r[2][2] = (a * e - b * d) * id;
-    const float tx = m[3][0], ty = m[3][1], tz = m[3][2];
-    r[3][0] = -(r[0][0] * tx + r[1][0] * ty + r[2][0] * tz);
-    r[3][1] = -(r[0][1] * tx + r[1][1] * ty + r[2][1] * tz);
-    r[3][2] = -(r[0][2] * tx + r[1][2] * ty + r[2][2] * tz);
-    return r;
-  }
-
   fh_ctx* m_ctx = nullptr;
   uint32_t m_width = 0, m_height = 0;
   Scene m_scene;

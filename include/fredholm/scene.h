@@ -6,19 +6,28 @@
 // subsurface*, thin_walled (:183-284); coat_roughness takes clearcoat_thickness as in the reference (:240-242).
 // Texture statements (map_Kd, map_Ks, map_Pr, map_Pm, map_bump/bump, norm, map_d) load PNG / binary PPM files through
 // image_io.h with the reference's conventions (scene.cpp:7-37,144-153: vertical flip, one Texture per distinct file name, its
-// first use fixes COLOR / NONCOLOR).  Not supported in this build: JPEG files and glTF.
+// first use fixes COLOR / NONCOLOR).  glTF (.gltf, JSON + external or data-URI buffers) goes through json.h and follows
+// scene.cpp:445-860 including its quirks (listed in fredholm_amd/scene.py, the Python twin of this file); scene-graph math is
+// done in double and rounded to float once, identically in both front ends.  Not supported in this build: JPEG files, .glb.
 #pragma once
 #include <cmath>
+#include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <array>
+#include <memory>
+
 #include "camera.h"
 #include "image_io.h"
+#include "json.h"
 #include "shared.h"
 
 namespace fredholm
@@ -59,6 +68,77 @@ struct FloatTexture {
   }
 };
 
+// scene-graph math in double, row-major m[row][col]
+struct Mat4d {
+  double m[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  static Mat4d mul(const Mat4d& a, const Mat4d& b)
+  {
+    Mat4d r;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j] + a.m[i][3] * b.m[3][j];
+    return r;
+  }
+  // glm: translate(I, t) * mat4_cast(q) * scale(s), q = (w, x, y, z)
+  static Mat4d trs(const double t[3], const double q[4], const double s[3])
+  {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double r[3][3] = {{1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y - w * z), 2.0 * (x * z + w * y)},
+                            {2.0 * (x * y + w * z), 1.0 - 2.0 * (x * x + z * z), 2.0 * (y * z - w * x)},
+                            {2.0 * (x * z - w * y), 2.0 * (y * z + w * x), 1.0 - 2.0 * (x * x + y * y)}};
+    Mat4d m;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) m.m[i][j] = r[i][j] * s[j];
+      m.m[i][3] = t[i];
+    }
+    return m;
+  }
+  // inverse of [A t; 0 1] by cofactors (same expression order as fredholm_amd/scene.py: affine_inverse)
+  Mat4d affine_inverse() const
+  {
+    const double a = m[0][0], b = m[0][1], c = m[0][2], d = m[1][0], e = m[1][1], f = m[1][2], g = m[2][0], h = m[2][1], i = m[2][2];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    const double inv = 1.0 / det;
+    const double r[3][3] = {{(e * i - f * h) * inv, (c * h - b * i) * inv, (b * f - c * e) * inv},
+                            {(f * g - d * i) * inv, (a * i - c * g) * inv, (c * d - a * f) * inv},
+                            {(d * h - e * g) * inv, (b * g - a * h) * inv, (a * e - b * d) * inv}};
+    Mat4d out;
+    for (int k = 0; k < 3; ++k) {
+      for (int j = 0; j < 3; ++j) out.m[k][j] = r[k][j];
+      out.m[k][3] = -(r[k][0] * m[0][3] + r[k][1] * m[1][3] + r[k][2] * m[2][3]);
+    }
+    return out;
+  }
+  Mat4 to_float() const  // column-major like glm::mat4
+  {
+    Mat4 r;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) r[j][i] = float(m[i][j]);
+    return r;
+  }
+  static Mat4d from_float(const Mat4& f)
+  {
+    Mat4d r;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) r.m[i][j] = double(f[j][i]);
+    return r;
+  }
+};
+
+// scene.h:81-101
+struct Node {
+  int idx = -1;  // glTF node index
+  std::vector<Node> children;
+  Mat4d transform;
+  int camera_id = -1;
+  int submesh_id = -1;
+};
+
+struct Animation {
+  std::vector<float> translation_input, rotation_input, scale_input;
+  std::vector<std::array<double, 3>> translation_output, scale_output;
+  std::vector<std::array<double, 4>> rotation_output;  // (w, x, y, z)
+};
+
 struct Scene {
   bool m_has_camera_transform = false;
   Mat4 m_camera_transform = {};
@@ -73,13 +153,19 @@ struct Scene {
   std::vector<uint> m_submesh_n_faces = {};
   std::vector<uint> m_instance_ids = {};
   std::vector<Mat4> m_transforms = {};
+  std::vector<Mat4d> m_transforms_exact = {};  // the same matrices before rounding to float (scene-graph products are done in double)
+  std::vector<Node> m_nodes = {};
+  std::vector<Animation> m_animations = {};
 
   bool is_valid() const { return !m_vertices.empty() && !m_indices.empty() && !m_normals.empty() && m_vertices.size() == m_normals.size(); }
 
   void clear()
   {
     m_vertices.clear(); m_indices.clear(); m_texcoords.clear(); m_normals.clear(); m_material_ids.clear(); m_materials.clear(); m_textures.clear();
-    m_submesh_offsets.clear(); m_submesh_n_faces.clear(); m_instance_ids.clear(); m_transforms.clear();
+    m_submesh_offsets.clear(); m_submesh_n_faces.clear(); m_instance_ids.clear(); m_transforms.clear(); m_transforms_exact.clear();
+    m_nodes.clear(); m_animations.clear(); m_animation_targets.clear();
+    m_has_camera_transform = false;
+    m_camera_transform = Mat4{};
   }
 
   void load_model(const std::filesystem::path& filepath, bool do_clear)
@@ -87,10 +173,10 @@ struct Scene {
     if (do_clear) clear();
     const std::string ext = filepath.extension().string();
     if (ext == ".obj") load_obj(filepath);
+    else if (ext == ".gltf") load_gltf(filepath);
     else throw std::runtime_error("unsupported model format in this build: " + filepath.generic_string());
   }
 
-  void update_animation(float /*time*/) {}  // .obj scenes have no animation (scene.cpp:862-898 handles glTF only)
 
   void load_obj(const std::filesystem::path& filepath)
   {
@@ -161,8 +247,289 @@ struct Scene {
     (void)material_base;
     m_submesh_offsets.push_back(uint(first_face));
     m_submesh_n_faces.push_back(uint(m_indices.size() - first_face));
-    if (m_transforms.empty()) m_transforms.push_back(Mat4{});
+    m_transforms.push_back(Mat4{});  // scene.cpp:419-421: one identity per shape; every .obj face uses instance 0 (:424-428)
+    m_transforms_exact.push_back(Mat4d{});
   }
+
+
+  // ------------------------------------------------------------------------------------------ glTF (scene.cpp:445-860)
+  void load_gltf(const std::filesystem::path& filepath)
+  {
+    const std::vector<uint8_t> text = image_io::read_file(filepath);
+    const json::Value model = json::parse(std::string(text.begin(), text.end()));
+    const std::filesystem::path folder = filepath.parent_path();
+    std::vector<std::vector<uint8_t>> buffers;
+    if (model.has("buffers"))
+      for (const json::Value& b : model.at("buffers").arr) {
+        const std::string uri = b.has("uri") ? b.at("uri").string() : std::string();
+        if (uri.rfind("data:", 0) == 0) buffers.push_back(base64_decode(uri.substr(uri.find(',') + 1)));
+        else buffers.push_back(image_io::read_file(folder / uri));
+      }
+    struct View { const uint8_t* data; size_t avail; int stride, count; };
+    auto get_buffer = [&](int accessor_id) {  // scene.cpp:921-933
+      const json::Value& acc = model.at("accessors").at(size_t(accessor_id));
+      if (!acc.has("bufferView")) throw std::runtime_error("accessor without bufferView");
+      const json::Value& view = model.at("bufferViews").at(size_t(acc.at("bufferView").integer()));
+      const int comp = component_size(acc.at("componentType").integer()) * type_count(acc.at("type").string());
+      const int bs = view.integer_or("byteStride", 0);
+      const std::vector<uint8_t>& buf = buffers.at(size_t(view.at("buffer").integer()));
+      const size_t start = size_t(view.integer_or("byteOffset", 0)) + size_t(acc.integer_or("byteOffset", 0));
+      if (start > buf.size()) throw std::runtime_error("accessor outside its buffer");
+      return View{buf.data() + start, buf.size() - start, bs ? bs : comp, acc.at("count").integer()};
+    };
+    auto need = [](const View& v, size_t bytes) { if (bytes > v.avail) throw std::runtime_error("accessor outside its buffer"); };
+
+    const uint material_base = uint(m_materials.size());
+    const int texture_base = int(m_textures.size());
+    if (model.has("materials"))
+      for (const json::Value& material : model.at("materials").arr) {
+        Material mat;
+        const json::Value empty;
+        const json::Value& pmr = material.has("pbrMetallicRoughness") ? material.at("pbrMetallicRoughness") : empty;
+        if (pmr.has("baseColorFactor")) mat.base_color = make_float3(float(pmr.at("baseColorFactor").at(0).number()), float(pmr.at("baseColorFactor").at(1).number()), float(pmr.at("baseColorFactor").at(2).number()));
+        else mat.base_color = make_float3(1, 1, 1);
+        if (pmr.has("baseColorTexture")) mat.base_color_texture_id = pmr.at("baseColorTexture").at("index").integer() + texture_base;
+        mat.specular_roughness = float(pmr.number_or("roughnessFactor", 1.0));
+        mat.metalness = float(pmr.number_or("metallicFactor", 1.0));
+        if (pmr.has("metallicRoughnessTexture")) mat.metallic_roughness_texture_id = pmr.at("metallicRoughnessTexture").at("index").integer() + texture_base;
+        if (material.has("extensions") && material.at("extensions").has("KHR_materials_clearcoat")) {
+          const json::Value& cc = material.at("extensions").at("KHR_materials_clearcoat");
+          if (cc.has("clearcoatFactor")) mat.coat = float(cc.at("clearcoatFactor").number());
+          if (cc.has("clearcoatTexture")) mat.coat_texture_id = 0;  // scene.cpp:521-523: GetNumberAsInt() of an object
+          if (cc.has("clearcoatRoughnessFactor")) mat.coat_roughness = float(cc.at("clearcoatRoughnessFactor").number());
+          if (cc.has("clearcoatRoughnessTexture")) mat.coat_roughness_texture_id = 0;
+        }
+        mat.emission = 1.0f;  // scene.cpp:535-541
+        mat.emission_color = make_float3(0, 0, 0);
+        if (material.has("emissiveFactor")) mat.emission_color = make_float3(float(material.at("emissiveFactor").at(0).number()), float(material.at("emissiveFactor").at(1).number()), float(material.at("emissiveFactor").at(2).number()));
+        if (material.has("emissiveTexture")) mat.emission_texture_id = material.at("emissiveTexture").at("index").integer() + texture_base;
+        if (material.has("normalTexture")) mat.normalmap_texture_id = material.at("normalTexture").at("index").integer() + texture_base;
+        m_materials.push_back(mat);
+      }
+    if (model.has("textures"))
+      for (const json::Value& texture : model.at("textures").arr) {
+        const json::Value& image = model.at("images").at(size_t(texture.at("source").integer()));
+        m_textures.push_back(Texture(folder / image.at("uri").string(), TextureType::NONCOLOR));  // scene.cpp:560-567
+      }
+
+    std::function<Node(int)> load_node = [&](int node_idx) {
+      const json::Value& node = model.at("nodes").at(size_t(node_idx));
+      Node n;
+      n.idx = node_idx;
+      double t[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0}, sc[3] = {1, 1, 1};
+      if (node.has("translation")) for (int k = 0; k < 3; ++k) t[k] = double(float(node.at("translation").at(size_t(k)).number()));
+      if (node.has("rotation")) {
+        const json::Value& r = node.at("rotation");
+        q[0] = double(float(r.at(3).number())); q[1] = double(float(r.at(0).number())); q[2] = double(float(r.at(1).number())); q[3] = double(float(r.at(2).number()));
+      }
+      if (node.has("scale")) for (int k = 0; k < 3; ++k) sc[k] = double(float(node.at("scale").at(size_t(k)).number()));
+      n.transform = Mat4d::trs(t, q, sc);
+      if (node.has("matrix"))  // column-major in the file
+        for (int r = 0; r < 4; ++r)
+          for (int c = 0; c < 4; ++c) n.transform.m[r][c] = double(float(node.at("matrix").at(size_t(4 * c + r)).number()));
+      n.camera_id = node.integer_or("camera", -1);
+      if (node.has("mesh")) {
+        const json::Value& mesh = model.at("meshes").at(size_t(node.at("mesh").integer()));
+        n.submesh_id = int(m_submesh_offsets.size());
+        const size_t prev = m_indices.size();
+        for (const json::Value& prim : mesh.at("primitives").arr) {
+          const uint base = uint(m_vertices.size());
+          const View iv = get_buffer(prim.at("indices").integer());
+          if (iv.stride != 2) throw std::runtime_error("indices stride is not ushort");
+          need(iv, size_t(iv.count) * 2);
+          const json::Value& attrs = prim.at("attributes");
+          const View pv = get_buffer(attrs.at("POSITION").integer());
+          if (pv.stride != 12) throw std::runtime_error("positions stride is not float3");
+          const View nv = get_buffer(attrs.at("NORMAL").integer());
+          if (nv.stride != 12) throw std::runtime_error("normals stride is not float3");
+          const View tv = get_buffer(attrs.at("TEXCOORD_0").integer());
+          if (tv.stride != 8) throw std::runtime_error("texcoord stride is not float2");
+          need(pv, size_t(pv.count) * 12); need(nv, size_t(nv.count) * 12); need(tv, size_t(tv.count) * 8);
+          auto f32 = [](const uint8_t* p) { float v; std::memcpy(&v, p, 4); return v; };
+          for (int i = 0; i < pv.count; ++i) m_vertices.push_back(make_float3(f32(pv.data + 12 * i), f32(pv.data + 12 * i + 4), f32(pv.data + 12 * i + 8)));
+          for (int i = 0; i < nv.count; ++i) m_normals.push_back(make_float3(f32(nv.data + 12 * i), f32(nv.data + 12 * i + 4), f32(nv.data + 12 * i + 8)));
+          for (int i = 0; i < tv.count; ++i) m_texcoords.push_back(float2{f32(tv.data + 8 * i), 1.0f - f32(tv.data + 8 * i + 4)});
+          const int material = prim.integer_or("material", -1);
+          for (int i = 0; i < iv.count / 3; ++i) {
+            uint16_t k[3];
+            std::memcpy(k, iv.data + 6 * i, 6);
+            m_indices.push_back(make_uint3(k[0] + base, k[1] + base, k[2] + base));
+            m_material_ids.push_back(material >= 0 ? uint(material) + material_base : 0xffffffffu);
+            m_instance_ids.push_back(uint(m_submesh_offsets.size()));
+          }
+        }
+        m_submesh_offsets.push_back(uint(prev));
+        m_submesh_n_faces.push_back(uint(m_indices.size() - prev));
+      }
+      if (node.has("children"))
+        for (const json::Value& c : node.at("children").arr) n.children.push_back(load_node(c.integer()));
+      return n;
+    };
+    const size_t first_new_node = m_nodes.size();
+    for (const json::Value& root : model.at("scenes").at(0).at("nodes").arr) m_nodes.push_back(load_node(root.integer()));
+    m_transforms.resize(m_submesh_offsets.size());
+    m_transforms_exact.resize(m_submesh_offsets.size());
+    update_transform();
+
+    if (model.has("animations"))
+      for (const json::Value& animation : model.at("animations").arr) {
+        Animation anim;
+        const int target = animation.at("channels").at(0).at("target").at("node").integer();
+        int target_root = -1;  // root nodes only (find_node_node drops the result of its recursion, scene.cpp:900-919)
+        for (size_t k = first_new_node; k < m_nodes.size(); ++k)
+          if (m_nodes[k].idx == target) { target_root = int(k); break; }
+        if (target_root < 0) throw std::runtime_error("invalid target node");
+        for (const json::Value& channel : animation.at("channels").arr) {
+          const json::Value& sampler = animation.at("samplers").at(size_t(channel.at("sampler").integer()));
+          const std::string path = channel.at("target").at("path").string();
+          const View in = get_buffer(sampler.at("input").integer());
+          if (in.stride != 4) throw std::runtime_error("unsupported animation input");
+          const View out = get_buffer(sampler.at("output").integer());
+          if (in.count != out.count) throw std::runtime_error("animation input size is not equal to output size");
+          const int per = path == "rotation" ? 4 : ((path == "translation" || path == "scale") ? 3 : 0);
+          if (per == 0) continue;
+          if (out.stride != 4 * per) throw std::runtime_error("invalid output stride");
+          need(in, size_t(in.count) * 4); need(out, size_t(out.count) * 4 * per);
+          auto f32 = [](const uint8_t* p) { float v; std::memcpy(&v, p, 4); return v; };
+          for (int i = 0; i < in.count; ++i) {
+            const float key = f32(in.data + 4 * i);
+            const uint8_t* o = out.data + size_t(4 * per) * i;
+            if (path == "translation") { anim.translation_input.push_back(key); anim.translation_output.push_back({double(f32(o)), double(f32(o + 4)), double(f32(o + 8))}); }
+            else if (path == "scale") { anim.scale_input.push_back(key); anim.scale_output.push_back({double(f32(o)), double(f32(o + 4)), double(f32(o + 8))}); }
+            else { anim.rotation_input.push_back(key); anim.rotation_output.push_back({double(f32(o + 12)), double(f32(o)), double(f32(o + 4)), double(f32(o + 8))}); }
+          }
+        }
+        m_animations.push_back(anim);
+        m_animation_targets.push_back(target_root);  // an index, not the reference's Node*: m_nodes grows when files are appended
+      }
+  }
+
+  // scene.cpp:836-860
+  void update_transform()
+  {
+    for (const Node& node : m_nodes) visit(node, Mat4d{});
+  }
+
+  // scene.cpp:862-898
+  void update_animation(float time)
+  {
+    for (size_t ai = 0; ai < m_animations.size(); ++ai) {
+      const Animation& a = m_animations[ai];
+      double t[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0}, s[3] = {1, 1, 1};
+      if (!a.translation_input.empty()) { const auto v = interpolate3(a.translation_input, a.translation_output, time); for (int k = 0; k < 3; ++k) t[k] = v[size_t(k)]; }
+      if (!a.rotation_input.empty()) { const auto v = interpolate4(a.rotation_input, a.rotation_output, time); for (int k = 0; k < 4; ++k) q[k] = v[size_t(k)]; }
+      if (!a.scale_input.empty()) { const auto v = interpolate3(a.scale_input, a.scale_output, time); for (int k = 0; k < 3; ++k) s[k] = v[size_t(k)]; }
+      m_nodes.at(size_t(m_animation_targets.at(ai))).transform = Mat4d::trs(t, q, s);
+    }
+    update_transform();
+  }
+
+  std::vector<int> m_animation_targets;  // index into m_nodes of every animation's node
+
+  // instance transforms as the C ABI takes them: 3x4 row-major float, the inverse taken in double before rounding.  A matrix the
+  // caller edited in m_transforms (float) wins over the stored double one.
+  void transforms_3x4(std::vector<float>& o2w, std::vector<float>& w2o) const
+  {
+    for (size_t k = 0; k < m_transforms.size(); ++k) {
+      Mat4d m = Mat4d::from_float(m_transforms[k]);
+      if (k < m_transforms_exact.size()) {
+        const Mat4 f = m_transforms_exact[k].to_float();
+        bool same = true;
+        for (int c = 0; c < 4 && same; ++c)
+          for (int r = 0; r < 4; ++r) same = same && f[c][r] == m_transforms[k][c][r];
+        if (same) m = m_transforms_exact[k];
+      }
+      const Mat4d inv = m.affine_inverse();
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) { o2w.push_back(float(m.m[r][c])); w2o.push_back(float(inv.m[r][c])); }
+    }
+  }
+
+ private:
+  void visit(const Node& node, const Mat4d& parent)
+  {
+    const Mat4d m = Mat4d::mul(parent, node.transform);
+    if (node.camera_id != -1) { m_has_camera_transform = true; m_camera_transform = m.to_float(); }
+    if (node.submesh_id != -1) { m_transforms_exact[size_t(node.submesh_id)] = m; m_transforms[size_t(node.submesh_id)] = m.to_float(); }
+    for (const Node& c : node.children) visit(c, m);
+  }
+  // scene.h:164-178: t = fmod(time, last key); h = t - input[idx0] (not divided by the key interval)
+  static void bracket(const std::vector<float>& input, float time, size_t n_out, size_t& idx0, size_t& idx1, double& h)
+  {
+    const float last = input.back();
+    const float t = last != 0.0f ? std::fmod(time, last) : 0.0f;
+    const size_t lb = size_t(std::lower_bound(input.begin(), input.end(), t) - input.begin());
+    idx0 = lb > 0 ? lb - 1 : 0;
+    idx1 = std::min(lb, n_out - 1);
+    h = double(t - input[idx0]);
+  }
+  static std::array<double, 3> interpolate3(const std::vector<float>& input, const std::vector<std::array<double, 3>>& output, float time)
+  {
+    size_t i0, i1;
+    double h;
+    bracket(input, time, output.size(), i0, i1, h);
+    std::array<double, 3> r;
+    for (size_t k = 0; k < 3; ++k) r[k] = output[i0][k] * (1.0 - h) + output[i1][k] * h;
+    return r;
+  }
+  // glm::mix(quat, quat, a): spherical interpolation without the shortest-path flip; linear when nearly parallel
+  static std::array<double, 4> interpolate4(const std::vector<float>& input, const std::vector<std::array<double, 4>>& output, float time)
+  {
+    size_t i0, i1;
+    double a;
+    bracket(input, time, output.size(), i0, i1, a);
+    const std::array<double, 4>&x = output[i0], &y = output[i1];
+    const double cos_theta = x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    std::array<double, 4> r;
+    if (cos_theta > 1.0 - 1.1920928955078125e-07) {
+      for (size_t k = 0; k < 4; ++k) r[k] = x[k] * (1.0 - a) + y[k] * a;
+      return r;
+    }
+    const double angle = std::acos(cos_theta);
+    const double s0 = std::sin((1.0 - a) * angle), s1 = std::sin(a * angle), sn = std::sin(angle);
+    for (size_t k = 0; k < 4; ++k) r[k] = (s0 * x[k] + s1 * y[k]) / sn;
+    return r;
+  }
+  static int component_size(int component_type)
+  {
+    switch (component_type) {
+      case 5120: case 5121: return 1;
+      case 5122: case 5123: return 2;
+      case 5125: case 5126: return 4;
+      default: throw std::runtime_error("unknown accessor component type");
+    }
+  }
+  static int type_count(const std::string& t)
+  {
+    if (t == "SCALAR") return 1;
+    if (t == "VEC2") return 2;
+    if (t == "VEC3") return 3;
+    if (t == "VEC4" || t == "MAT2") return 4;
+    if (t == "MAT3") return 9;
+    if (t == "MAT4") return 16;
+    throw std::runtime_error("unknown accessor type");
+  }
+  static std::vector<uint8_t> base64_decode(const std::string& in)
+  {
+    std::vector<uint8_t> out;
+    uint32_t acc = 0;
+    int bits = 0;
+    for (char ch : in) {
+      int v;
+      if (ch >= 'A' && ch <= 'Z') v = ch - 'A';
+      else if (ch >= 'a' && ch <= 'z') v = ch - 'a' + 26;
+      else if (ch >= '0' && ch <= '9') v = ch - '0' + 52;
+      else if (ch == '+' || ch == '-') v = 62;
+      else if (ch == '/' || ch == '_') v = 63;
+      else continue;  // padding, whitespace
+      acc = (acc << 6) | uint32_t(v);
+      bits += 6;
+      if (bits >= 8) { bits -= 8; out.push_back(uint8_t((acc >> bits) & 0xffu)); }
+    }
+    return out;
+  }
+
+ public:
 
  private:
   static float3 sub3(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }

@@ -229,6 +229,7 @@ def image_dump(tmp_path_factory):
         w, h = np.frombuffer(p.stdout[:8], dtype=np.int32)
         body = p.stdout[8:]
         return np.frombuffer(body, dtype=np.float32 if mode == "hdr" else np.uint8).reshape(h, w, 4)
+    run.exe = str(exe)
     return run
 
 
@@ -286,6 +287,25 @@ def test_png_decoders_agree_on_every_filter_and_colour_type(tmp_path, image_dump
     assert n == 20
 
 
+def test_png_writer_round_trip(tmp_path, image_dump):
+    """include/fredholm/image_io.h: write_png_rgba8 (stored deflate blocks) is read back by zlib and by the C++ reader"""
+    import zlib
+    from fredholm_amd import image_io as I
+    rng = np.random.default_rng(13)
+    img = rng.integers(0, 256, (131, 257, 4), dtype=np.uint8)  # > 65535 bytes of scanlines: more than one stored block
+    src, dst = tmp_path / "src.png", tmp_path / "dst.png"
+    I.write_png(src, img, 2)
+    assert subprocess.run([image_dump.exe, "rewrite", str(src), str(dst)]).returncode == 0
+    assert np.array_equal(I.load_rgba8(dst, False), img) and np.array_equal(image_dump("rgba8", dst), img)
+    data = dst.read_bytes()
+    pos, crc_ok = 8, True
+    while pos < len(data):
+        n = int.from_bytes(data[pos:pos + 4], "big")
+        crc_ok &= zlib.crc32(data[pos + 4:pos + 8 + n]) == int.from_bytes(data[pos + 8 + n:pos + 12 + n], "big")
+        pos += 12 + n
+    assert crc_ok
+
+
 def test_hdr_and_ppm_decoders_agree(tmp_path, image_dump):
     from fredholm_amd import image_io as I
     rng = np.random.default_rng(12)
@@ -328,3 +348,121 @@ def test_textured_obj_round_trip(tmp_path):
     assert seen >= 7
     srgb_of = {int(back["materials"]["base_color_texture_id"][i]) for i in range(len(back["materials"])) if back["materials"]["base_color_texture_id"][i] >= 0}
     assert all(back["textures"][k]["srgb"] for k in srgb_of)  # map_Kd textures are COLOR textures (scene.cpp:201-202)
+
+
+# ---------------------------------------------------------------- glTF + animation: C++ facade and Python mirror agree bit for bit
+@pytest.fixture(scope="module")
+def scene_dump(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("scenedump") / "scene_dump"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "scene_dump.cpp"), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+    def run(out, time, *files):
+        p = subprocess.run([str(exe), str(out), repr(float(time)), *[str(f) for f in files]], capture_output=True, text=True)
+        if p.returncode != 0:
+            raise ValueError(p.stderr)
+        data = open(out, "rb").read()
+        chunks, pos = [], 0
+        while pos < len(data):
+            n = int(np.frombuffer(data, dtype=np.uint64, count=1, offset=pos)[0])
+            chunks.append(data[pos + 8:pos + 8 + n])
+            pos += 8 + n
+        return chunks
+    return run
+
+
+def _scene_chunks(S):
+    o2w, w2o = S.transforms_3x4()
+    cam = np.concatenate([[np.float32(1.0 if S.m_has_camera_transform else 0.0)], S.camera_transform_3x4().reshape(-1)]).astype(np.float32)
+    hdr = np.asarray([[t["rgba8"].shape[1], t["rgba8"].shape[0], int(t["srgb"])] for t in S.m_textures], dtype=np.uint32).reshape(-1)
+    out = [S.m_vertices, S.m_normals, S.m_texcoords, S.m_indices, S.m_material_ids, S.m_instance_ids, S.m_materials, o2w, w2o, cam,
+           np.asarray(S.m_submesh_offsets, np.uint32), np.asarray(S.m_submesh_n_faces, np.uint32), hdr]
+    out += [t["rgba8"] for t in S.m_textures]
+    return [np.ascontiguousarray(a).tobytes() for a in out]
+
+
+@pytest.mark.parametrize("embed", [False, True])
+def test_gltf_scene_graph_and_animation_match_between_cpp_and_python(tmp_path, scene_dump, embed):
+    from fredholm_amd.scene import Scene
+    gltf = tmp_path / "anim.gltf"
+    scenes.animated_cornell_gltf(str(gltf), embed=embed)
+    names = ["vertices", "normals", "texcoords", "indices", "material_ids", "instance_ids", "materials", "o2w", "w2o", "camera", "submesh_offsets", "submesh_n_faces", "texture headers"]
+    for time in (-1.0, 0.0, 0.3, 0.75, 1.0, 1.9, 2.6, 7.25):
+        S = Scene()
+        S.load_model(str(gltf))
+        if time >= 0:
+            S.update_animation(time)
+        want = _scene_chunks(S)
+        got = scene_dump(tmp_path / "dump.bin", time, gltf)
+        assert len(got) == len(want)
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert a == b, (time, names[k] if k < len(names) else f"texture {k - len(names)}")
+    # structure: 4 sub-meshes, the tall block hangs under the animated short-block node and moves with it
+    S = Scene()
+    S.load_model(str(gltf))
+    assert S.m_submesh_offsets == [0, 12, 24, 36] and S.m_has_camera_transform and len(S.m_animations) == 1
+    assert np.array_equal(np.unique(S.m_instance_ids), [0, 1, 2, 3])
+    before = np.asarray(S.m_transforms[2])
+    S.update_animation(0.75)
+    assert not np.allclose(before, np.asarray(S.m_transforms[2]))
+    assert np.allclose(np.asarray(S.m_transforms[0]), np.eye(4))
+    # the keys are mixed with h = t - input[idx0] (scene.h:174), not with the normalised position inside the interval
+    tr = np.asarray(S.m_transforms[1])[:3, 3]
+    k0, k1, h = np.array([0.2, 0.05, 0.0]), np.array([0.0, 0.1, 0.1]), 0.75 - 0.5
+    assert np.allclose(tr, k0 * (1 - h) + k1 * h, atol=1e-6)
+    # every glTF material is emissive (scene.cpp:535-541); all textures are NONCOLOR (:560-567)
+    assert (S.m_materials["emission"] == 1).all() and not any(t["srgb"] for t in S.m_textures)
+    np.testing.assert_allclose(np.asarray(S.m_camera_transform)[:3, 3], [0.05, 1.0, 1.2])
+
+
+def test_obj_plus_camera_gltf_composition(tmp_path, scene_dump):
+    """rtcamp8.cpp:114-115: load_scene(obj) then load_scene(camera gltf, clear=false)"""
+    from fredholm_amd.scene import Scene
+    obj = tmp_path / "c.obj"
+    scenes.write_obj(scenes.textured_cornell_box(), str(obj))
+    gltf = tmp_path / "cam.gltf"
+    sc = scenes.cornell_box()
+    tri = np.arange(34, 36)
+    scenes.write_gltf(sc, str(gltf), [tri], [{"mesh": 0, "translation": [0.0, 0.5, 0.0]}, {"camera": 0, "translation": [0.0, 1.0, 2.5]}], [0, 1],
+                      animations=[[(1, "translation", [0.0, 4.0], [[0.0, 1.0, 2.5], [0.5, 1.0, 2.0]])]], cameras=1)
+    S = Scene()
+    S.load_model(str(obj))
+    n_obj_mats, n_obj_faces = len(S.m_materials), len(S.m_indices)
+    S.load_model(str(gltf), clear=False)
+    assert len(S.m_indices) == n_obj_faces + 2 and (S.m_material_ids[n_obj_faces:] >= n_obj_mats).all()
+    assert (S.m_instance_ids[:n_obj_faces] == 0).all() and (S.m_instance_ids[n_obj_faces:] == 1).all() and len(S.m_transforms) == 2
+    S.update_animation(2.0)
+    np.testing.assert_allclose(np.asarray(S.m_camera_transform)[:3, 3], [1.0, 1.0, 1.5], atol=1e-6)  # h = 2.0, not 0.5 (scene.h:174)
+    got = scene_dump(tmp_path / "d.bin", 2.0, obj, gltf)
+    for a, b in zip(got, _scene_chunks(S)):
+        assert a == b
+
+
+def test_gltf_loader_rejects_what_the_reference_rejects(tmp_path, scene_dump):
+    import json
+    from fredholm_amd.scene import Scene
+    gltf = tmp_path / "a.gltf"
+    scenes.animated_cornell_gltf(str(gltf), textured=False)
+    doc = json.load(open(gltf))
+    bad = dict(doc)
+    bad["accessors"] = [dict(a) for a in doc["accessors"]]
+    idx_acc = doc["meshes"][0]["primitives"][0]["indices"]
+    bad["accessors"][idx_acc]["componentType"] = 5125  # 32-bit indices: "indices stride is not ushort" (scene.cpp:699-701)
+    json.dump(bad, open(tmp_path / "b.gltf", "w"))
+    (tmp_path / "b.bin").write_bytes((tmp_path / "a.bin").read_bytes())
+    bad["buffers"] = [dict(doc["buffers"][0], uri="a.bin")]
+    json.dump(bad, open(tmp_path / "b.gltf", "w"))
+    for loader in (lambda: Scene().load_model(str(tmp_path / "b.gltf")), lambda: scene_dump(tmp_path / "x.bin", -1, tmp_path / "b.gltf")):
+        with pytest.raises(ValueError, match="ushort"):
+            loader()
+    # an animation whose first channel targets a non-root node: "invalid target node" (scene.cpp:574-577, :900-919)
+    bad = dict(doc)
+    bad["animations"] = [{"samplers": doc["animations"][0]["samplers"], "channels": [dict(c, target=dict(c["target"], node=2)) for c in doc["animations"][0]["channels"]]}]
+    json.dump(bad, open(tmp_path / "c.gltf", "w"))
+    (tmp_path / "c.bin").write_bytes((tmp_path / "a.bin").read_bytes())
+    bad["buffers"] = [dict(doc["buffers"][0], uri="a.bin")]
+    json.dump(bad, open(tmp_path / "c.gltf", "w"))
+    for loader in (lambda: Scene().load_model(str(tmp_path / "c.gltf")), lambda: scene_dump(tmp_path / "x.bin", -1, tmp_path / "c.gltf")):
+        with pytest.raises(ValueError, match="invalid target node"):
+            loader()
