@@ -38,6 +38,9 @@ namespace fh {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef FH_SHADE_BLOCKS
+#define FH_SHADE_BLOCKS 1  // minimum resident workgroups per CU the shade kernels are compiled for (register budget = 512 / that per lane)
+#endif
 
 struct SobolRows {  // rows of the generator matrices this kernel needs, staged in LDS (32 columns each)
   uint32_t m[4][32];
@@ -609,7 +612,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
 }
 
 template <uint32_t LOBES>
-__global__ void __launch_bounds__(kBlock) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
+__global__ void __launch_bounds__(kBlock, FH_SHADE_BLOCKS) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
 {
   __shared__ SobolRows rows;
   BounceSlots bs;

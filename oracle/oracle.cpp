@@ -2,11 +2,14 @@
 // used ONLY as the checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 // Nothing under fredholm_amd/ may call into this library.
 //
-// PARITY STATUS: "parity unpinned" except for the anchor values recorded in SURVEY.md 8(c)
-// (tests/test_oracle_anchors.py).  The reference needs the CUDA toolkit and the OptiX SDK
-// (/root/reference/CMakeLists.txt:2,20-31, fredholm/include/fredholm/shared.h:2-3), neither of
-// which exists in this image, so it is unbuildable here and no oracle/_ref is provided; the
-// reference ships no tests or golden vectors.
+// PARITY STATUS: "parity unpinned" except for (1) the anchor values recorded in SURVEY.md 8(c) and (2) the Hosek-Wilkie sky:
+// its cook (arhosek.h) and device radiance functions (arhosek.cu) include nothing but each other, so oracle/Makefile builds them
+// from where they lie into oracle/_ref/libref_hosek.so (driver: ref_hosek.hip) and the tests compare this restatement with
+// what they output (tests/golden/hosek_reference_states.json, tests/test_oracle_anchors.py, tests/test_gpu_parity.py).
+// Everything else of the reference needs the CUDA toolkit and the OptiX SDK (/root/reference/CMakeLists.txt:2,20-31,
+// fredholm/include/fredholm/shared.h:2-3: <cuda_runtime.h>, <optix.h>; the .cu modules include sutil/vec_math.h ->
+// <vector_types.h>), neither of which exists in this image, so it is unbuildable here; the reference ships no tests or golden
+// vectors.
 //
 // What is restated (reference file:line):
 //   ray generation, Russian roulette, running-mean accumulate   fredholm/modules/pt.cu:418-502
@@ -893,6 +896,13 @@ void orc_bsdf(const void* material180, int entering, int n, const float* wo, con
 void orc_hosek_cook(float turbidity, float albedo, const float* sun_dir, float* out30)
 {
   const float elevation = (float)(0.5f * M_PI - fhe_acos(clampf(sun_dir[1], -1.0f, 1.0f)));  // renderer.h:592-601
+  const HosekState st = hosek_cook(turbidity, albedo, elevation);
+  std::memcpy(out30, &st, sizeof st);
+}
+// same cook with the elevation given directly (what the reference's arhosek_rgb_skymodelstate_alloc_init takes): lets the tests
+// compare against oracle/_ref/libref_hosek.so, the reference's own source built by oracle/Makefile
+void orc_hosek_cook_elevation(float turbidity, float albedo, float elevation, float* out30)
+{
   const HosekState st = hosek_cook(turbidity, albedo, elevation);
   std::memcpy(out30, &st, sizeof st);
 }

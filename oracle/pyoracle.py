@@ -113,6 +113,45 @@ def hosek_cook(turbidity, albedo, sun_dir):
     return out
 
 
+def hosek_cook_elevation(turbidity, albedo, elevation):
+    out = np.zeros(30, dtype=np.float32)
+    lib().orc_hosek_cook_elevation(C.c_float(turbidity), C.c_float(albedo), C.c_float(elevation), _p(out))
+    return out
+
+
+_REF_HOSEK = None
+
+
+def ref_hosek():
+    """oracle/_ref/libref_hosek.so: the reference's own Hosek sources (arhosek.h, arhosek.cu) built by oracle/Makefile; None when it
+    was not built (no /root/reference at build time)"""
+    global _REF_HOSEK
+    if _REF_HOSEK is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_hosek.so")
+        if not os.path.exists(path):
+            return None
+        _REF_HOSEK = C.CDLL(path)
+    return _REF_HOSEK
+
+
+def ref_hosek_state(turbidity, albedo, elevation):
+    """(configs[3][9], radiances[3]) from the reference's arhosek_rgb_skymodelstate_alloc_init (arhosek.h:298-322), run on the host"""
+    cfg, rad = np.zeros(27, dtype=np.float32), np.zeros(3, dtype=np.float32)
+    ref_hosek().ref_hosek_state(C.c_float(turbidity), C.c_float(albedo), C.c_float(elevation), _p(cfg), _p(rad))
+    return cfg.reshape(3, 9), rad
+
+
+def ref_hosek_radiance(turbidity, albedo, elevation, theta, gamma):
+    """arhosek_tristim_skymodel_radiance (arhosek.cu:120-127) for every (theta, gamma), run on the GPU"""
+    theta = np.ascontiguousarray(theta, dtype=np.float32)
+    gamma = np.ascontiguousarray(gamma, dtype=np.float32)
+    out = np.zeros((theta.shape[0], 3), dtype=np.float32)
+    rc = ref_hosek().ref_hosek_radiance(C.c_float(turbidity), C.c_float(albedo), C.c_float(elevation), int(theta.shape[0]), _p(theta), _p(gamma), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"ref_hosek_radiance: HIP error {rc}")
+    return out
+
+
 def hosek_radiance(state30, sun_dir, intensity, dirs):
     d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
     out = np.zeros_like(d)

@@ -309,6 +309,39 @@ def test_directional_light_and_constant_background(oracle):
     _assert_image_parity(gpu["beauty"], ref["beauty"])
 
 
+def test_hosek_radiance_matches_the_reference_device_functions(renderer, oracle):
+    """oracle/_ref/libref_hosek.so runs the reference's own arhosek_tristim_skymodel_radiance (arhosek.cu:103-127) on this GPU, with
+    ROCm's device libm where the reference had CUDA's.  The product (include/fh_elementary.h transcendentals, <= 2 ulp each) has to
+    agree to 2e-5 relative -- the rounding of four chained transcendentals, not an algorithmic difference."""
+    if oracle.ref_hosek() is None:
+        pytest.skip("oracle/_ref/libref_hosek.so was not built (no /root/reference at build time)")
+    for turbidity, albedo, sun in ((3.0, 0.3, scenes.SOUP_SUN), (6.5, 0.8, (0.7, 0.35, -0.2)), (1.5, 0.0, (0.0, 1.0, 0.0))):
+        sun = np.array(sun, np.float32)
+        renderer.set_directional_light((0, 0, 0), sun, 0.0)
+        renderer.clear_directional_light()
+        renderer.set_sky_intensity(1.0)
+        renderer.load_arhosek_sky(turbidity, albedo)
+        st = np.zeros(30, np.float32)
+        _kat(renderer, "fh_kat_hosek_state", N.ptr(st))
+        s32 = sun * (np.float32(1.0) / np.sqrt(sun[0] * sun[0] + sun[1] * sun[1] + sun[2] * sun[2], dtype=np.float32))
+        elevation = np.float32(0.5 * np.pi) - np.arccos(np.clip(s32[1], -1, 1), dtype=np.float32)  # renderer.h:592-601
+        cfg, rad = oracle.ref_hosek_state(float(turbidity), float(albedo), float(elevation))
+        want_state = np.concatenate([cfg.reshape(-1), rad])
+        assert (np.abs(st - want_state) <= 1e-6 * np.abs(want_state) + 1e-7).all()  # the cook, against the reference's host code
+        rng = np.random.default_rng(11)
+        d = _dirs(rng, 20000)
+        d = d[d[:, 1] > 0.02]  # above the horizon (below it the reference evaluates sqrt of a negative number: NaN)
+        out = np.zeros((d.shape[0], 3), np.float32)
+        _kat(renderer, "fh_kat_sky", d.shape[0], N.ptr(np.ascontiguousarray(d)), N.ptr(out))
+        theta = np.arccos(np.clip(d[:, 1], -1, 1)).astype(np.float32)
+        gamma = np.arccos(np.clip((d.astype(np.float64) @ s32.astype(np.float64)), -1, 1)).astype(np.float32)
+        ref = oracle.ref_hosek_radiance(float(turbidity), float(albedo), float(elevation), theta, gamma)
+        assert np.isfinite(ref).all() and (ref > 0).all()
+        rel = np.abs(out - ref) / ref
+        assert rel.max() < 2e-5, rel.max()
+        renderer.clear_arhosek_sky()
+
+
 def test_soup_hosek_sky_all_material_classes(oracle):
     cam = F.Camera(**scenes.SOUP_CAMERA)
 

@@ -1,10 +1,13 @@
 """CPU tests of the checker (oracle/): anchors recorded from the reference, algebraic properties of
 the published algorithms it restates, and self-consistency of its BVH.
 
-The reference ships no tests or golden vectors and cannot be built here
-(needs CUDA + OptiX), so the only reference-derived pins are the values the survey observed when
-it ran the reference's own device functions (SURVEY.md 8(c) "Anchor values").
+The reference ships no tests or golden vectors and, apart from its Hosek sky, cannot be built here
+(needs CUDA + OptiX), so the reference-derived pins are the values the survey observed when it ran the reference's own device
+functions (SURVEY.md 8(c) "Anchor values") and the outputs of the reference's Hosek cook (tests/golden/hosek_reference_states.json,
+from oracle/_ref/libref_hosek.so).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -353,3 +356,28 @@ def test_alpha_cutout_lets_rays_through(oracle):
     assert np.array_equal(tuv[~on_card0].view(np.uint32), tuv0[~on_card0].view(np.uint32))
     tuv_b, prim_b = S.trace(rays, brute=True)
     assert np.array_equal(prim, prim_b)
+
+
+# ---------------------------------------------------------------- pinned against the reference's OWN code (the one part of it that builds here)
+def test_hosek_cook_matches_outputs_of_the_reference_source(oracle):
+    """tests/golden/hosek_reference_states.json holds outputs of the reference's arhosek_rgb_skymodelstate_alloc_init
+    (arhosek.h:298-322), produced by tools/gen_hosek_golden.py from oracle/_ref/libref_hosek.so = the reference's sources built by
+    oracle/Makefile.  The restatement agrees to 2 ulp (it evaluates pow through include/fh_elementary.h, the reference through
+    glibc's powf); most states are bit-identical."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hosek_reference_states.json")))
+    assert len(g["cases"]) >= 100
+    exact = 0
+    for c in g["cases"]:
+        got = oracle.hosek_cook_elevation(c["turbidity"], c["albedo"], c["elevation"])
+        want = np.concatenate([np.asarray(c["configs_bits"], np.uint32), np.asarray(c["radiances_bits"], np.uint32)]).view(np.float32)
+        assert np.isfinite(want).all()
+        rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+        assert rel.max() <= 4e-7, (c["turbidity"], c["albedo"], c["elevation"], rel.max())
+        exact += int(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+    assert exact >= 0.6 * len(g["cases"])
+    # where the reference build is present (this container), the committed fixture must be what it outputs today
+    if oracle.ref_hosek() is not None:
+        for c in g["cases"][::7]:
+            cfg, rad = oracle.ref_hosek_state(c["turbidity"], c["albedo"], c["elevation"])
+            assert [int(x) for x in cfg.reshape(-1).view(np.uint32)] == c["configs_bits"] and [int(x) for x in rad.view(np.uint32)] == c["radiances_bits"]
