@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step (one fh_render call = one presented frame; BASELINE configs[2] presents 1024-spp frames)")
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per step: one fh_render call = one presented frame of BASELINE configs[2] (1080p, 1024 spp)")
     ap.add_argument("--pool-spp", type=int, default=0, help="samples per pixel per pass of the path pool; 0 = half a step per pass (two passes in flight overlap), at most 64 spp of the full frame (132.7 M paths, 49 GB per pool)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-frame", action="store_true", help="N > 1: rank 0 re-renders the whole frame unsharded and compares it bit for bit with the gathered one")
