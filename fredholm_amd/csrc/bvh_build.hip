@@ -259,7 +259,7 @@ __device__ __forceinline__ uint32_t quant_exponent(float extent)
 }
 
 __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* children, const int2* ranges, const float4* node_lo, const float4* node_hi, const float4* leaf_lo,
-                            const float4* leaf_hi, float pad, uint32_t leaf_max, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_map, Work8* next_items, uint32_t* next_count)
+                            const float4* leaf_hi, float pad, uint32_t leaf_max, uint32_t absorb, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_map, Work8* next_items, uint32_t* next_count)
 {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_items) return;
@@ -273,15 +273,43 @@ __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* ch
     child_box(ch.x, node_lo, node_hi, leaf_lo, leaf_hi, lo[0], hi[0]);
     child_box(ch.y, node_lo, node_hi, leaf_lo, leaf_hi, lo[1], hi[1]);
   }
+  // Which child to open next.  Plain rule: the largest one.  With `absorb` (default) small subtrees are treated as units: a child
+  // with at most 8 leaves is opened only when ALL of its leaves fit into the free slots, and is then opened completely before
+  // anything else, so it ends up either as direct leaf children of this node or as ONE full inner child below it, never as a few
+  // 2-3 leaf fragments that each cost a node fetch (the plain rule left 4.5 of 8 slots used on average).
+  uint32_t absorbing = 0;  // slots that belong to a subtree being absorbed
   while (n < 8) {
     int best = -1;
     float best_area = -1.0f;
-    for (int i = 0; i < n; ++i) {
-      if (ref[i] < 0 || ref_count(ref[i], ranges) <= leaf_max) continue;
-      const float a = box_area(lo[i], hi[i]);
-      if (a > best_area) { best_area = a; best = i; }
+    if (absorb) {
+      for (int i = 0; i < n && best < 0; ++i)
+        if ((absorbing >> i) & 1u) { if (ref[i] >= 0 && ref_count(ref[i], ranges) > leaf_max) best = i; else absorbing &= ~(1u << i); }
+      if (best < 0) {
+        for (int i = 0; i < n; ++i) {  // subtrees that cannot become one node: open the largest
+          if (ref[i] < 0 || ref_count(ref[i], ranges) <= 8u * leaf_max) continue;
+          const float a = box_area(lo[i], hi[i]);
+          if (a > best_area) { best_area = a; best = i; }
+        }
+      }
+      if (best < 0) {
+        for (int i = 0; i < n; ++i) {  // small subtrees whose leaves all fit: absorb the largest
+          if (ref[i] < 0) continue;
+          const uint32_t c = ref_count(ref[i], ranges);
+          if (c <= leaf_max || (uint32_t)n + (c + leaf_max - 1u) / leaf_max - 1u > 8u) continue;
+          const float a = box_area(lo[i], hi[i]);
+          if (a > best_area) { best_area = a; best = i; }
+        }
+        if (best >= 0) absorbing |= 1u << best;
+      }
+    } else {
+      for (int i = 0; i < n; ++i) {
+        if (ref[i] < 0 || ref_count(ref[i], ranges) <= leaf_max) continue;
+        const float a = box_area(lo[i], hi[i]);
+        if (a > best_area) { best_area = a; best = i; }
+      }
     }
     if (best < 0) break;
+    if ((absorbing >> best) & 1u) absorbing |= 1u << n;
     const int2 ch = children[ref[best]];
     ref[best] = ch.x;
     child_box(ch.x, node_lo, node_hi, leaf_lo, leaf_hi, lo[best], hi[best]);
@@ -490,6 +518,8 @@ int bvh_build_device(fh_ctx* ctx)
     FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * 5ull * n_inner));
     FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n));
     uint32_t leaf_max8 = 1;  // one triangle per leaf child: box tests are ~4x cheaper than triangle tests (profiles/README.md)
+    uint32_t absorb8 = 1u;  // FH_ABSORB=0: plain largest-child-first collapse
+    if (const char* e = getenv("FH_ABSORB")) absorb8 = e[0] != '0' ? 1u : 0u;
     if (const char* e = getenv("FH_LEAF8")) { const int v = atoi(e); if (v >= 1 && v <= (int)kLeafMax8) leaf_max8 = (uint32_t)v; }
     const Work8 root{0, 0u};
     const uint32_t init_counters[3] = {1u, 0u, 0u};
@@ -501,7 +531,7 @@ int bvh_build_device(fh_ctx* ctx)
     for (int level = 0; level < 64 && level_count > 0; ++level) {
       FH_HIP(hipMemsetAsync(counters.p + 2, 0, 4, st));
       hipLaunchKernelGGL(k_collapse8, dim3((level_count + 63) / 64), dim3(64), 0, st, cur, level_count, children.p, ranges.p, node_lo.p, node_hi.p, leaf_lo.p, leaf_hi.p, pad,
-                         leaf_max8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2);
+                         leaf_max8, absorb8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2);
       FH_HIP(hipMemcpyAsync(&level_count, counters.p + 2, 4, hipMemcpyDeviceToHost, st));
       FH_HIP(hipStreamSynchronize(st));
       Work8* t = cur; cur = nxt; nxt = t;
