@@ -82,6 +82,7 @@ struct FrameDev {
   float dir_disk_radius;  // 1e9 * tan(rad(angle/2)), pt.cu:333-335
   // padded scene bounds: camera rays that miss them skip the traversal queue
   f3 scene_lo, scene_hi;
+  f3 cell_scale;  // 2^kCellBits / (scene_hi - scene_lo)
   // tables
   const uint32_t* sobol;  // 1024 x 52
   BsdfTables lut;
@@ -114,7 +115,16 @@ struct PoolDev {
   uint32_t* q_cls;               // kNumQueues x capacity: hits routed by shading class
   uint32_t* q_sec;               // shaded paths with secondary rays
   uint32_t* counters;            // kCounterStride words per bounce, zeroed once per pass
+  // spatial ordering of the bounce queues (render.hip: sort_queue_by_cell): the shade kernel stores the cell of the hit point next
+  // to every queue entry it appends; a counting sort brings entries of one cell together before the rays are traced
+  uint16_t* key_sec;             // cell of q_sec[i]
+  uint16_t* key_rad;             // cell of the entries appended to the next bounce's radiance queue
+  uint32_t* q_tmp;               // third radiance queue: sorted output rotates with the ping-pong pair
+  uint32_t* q_sec_sorted;
+  uint32_t* bins;                // 2 x kCells words: histogram (left zero by the scan), cursors
 };
+constexpr uint32_t kCellBits = 4;                      // per axis
+constexpr uint32_t kCells = 1u << (3 * kCellBits);     // 4096 cells over the scene bounds, Morton-numbered
 // per-bounce counter block: everything a bounce produces or consumes has its own word, so one
 // memset per pass replaces per-bounce resets
 enum : uint32_t {
@@ -136,6 +146,23 @@ struct LayersDev {
 struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; unsigned long long* rays; unsigned long long* wave_nodes; unsigned long long* wave_tris; unsigned long long* hist; };  // hist: 8 buckets of node steps per ray (<=8, <=16, ... <=512, more)
 
 // ---- wave-aggregated queue append: one atomic per wave (ballot + popcount prefix)
+// same append, storing a 16-bit key at the same position of a parallel array
+FH_D void queue_push_keyed(uint32_t* counter, uint32_t* queue, uint16_t* keys, bool active, uint32_t value, uint32_t key)
+{
+  const unsigned long long mask = __ballot(active);
+  if (mask == 0ull) return;
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (active) {
+    const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    queue[pos] = value;
+    keys[pos] = (uint16_t)key;
+  }
+}
+
 FH_D void queue_push(uint32_t* counter, uint32_t* queue, bool active, uint32_t value)
 {
   const unsigned long long mask = __ballot(active);

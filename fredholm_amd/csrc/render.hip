@@ -612,6 +612,83 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Spatial ordering of the bounce queues.  Rays leaving hit points are incoherent; traced in the order the shade kernels emit them,
+// the lanes of a wave walk unrelated parts of the BVH and every L2 sees all of it.  Sorting 4 M random rays of the 1 M-triangle
+// soup by the Morton cell of their origin made the same traversal kernel 1.4-1.55x faster (tools/sort_probe.py), so the queue
+// entries are brought into cell order first: a counting sort over kCells keys (histogram, scan, scatter), ~0.3 ms for 40 M entries.
+// Only the ORDER of queue entries changes: every path's arithmetic is untouched, so results are bit-identical.
+FH_D uint32_t spread3(uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); }  // 4 bits -> every third bit
+FH_D uint32_t cell_of(const FrameDev& fr, f3 p)
+{
+  const float m = (float)((1u << kCellBits) - 1u);
+  const float fx = fminf(fmaxf((p.x - fr.scene_lo.x) * fr.cell_scale.x, 0.0f), m), fy = fminf(fmaxf((p.y - fr.scene_lo.y) * fr.cell_scale.y, 0.0f), m),
+              fz = fminf(fmaxf((p.z - fr.scene_lo.z) * fr.cell_scale.z, 0.0f), m);
+  return spread3((uint32_t)fx) | (spread3((uint32_t)fy) << 1) | (spread3((uint32_t)fz) << 2);
+}
+
+constexpr int kSortBlock = 1024;
+// contiguous share of block b of n items
+FH_D void block_share(uint32_t n, uint32_t& lo, uint32_t& hi)
+{
+  const uint32_t per = (n + gridDim.x - 1u) / gridDim.x;
+  lo = blockIdx.x * per < n ? blockIdx.x * per : n;
+  hi = lo + per < n ? lo + per : n;
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_cell_hist(const uint32_t* count_ptr, const uint16_t* keys, uint32_t* hist)
+{
+  __shared__ uint32_t h[kCells];
+  for (uint32_t b = threadIdx.x; b < kCells; b += kSortBlock) h[b] = 0u;
+  __syncthreads();
+  uint32_t lo, hi;
+  block_share(*count_ptr, lo, hi);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortBlock) atomicAdd(&h[keys[i] & (kCells - 1u)], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < kCells; b += kSortBlock)
+    if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+
+// exclusive scan of the histogram into the cursors; the histogram is left zero for the next sort
+__global__ void __launch_bounds__(kSortBlock) k_cell_scan(uint32_t* hist, uint32_t* cursor)
+{
+  __shared__ uint32_t part[kSortBlock];
+  constexpr uint32_t per = kCells / kSortBlock;
+  uint32_t v[per], sum = 0;
+  for (uint32_t k = 0; k < per; ++k) { v[k] = hist[threadIdx.x * per + k]; hist[threadIdx.x * per + k] = 0u; sum += v[k]; }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < kSortBlock; off <<= 1) {
+    const uint32_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;
+  for (uint32_t k = 0; k < per; ++k) { cursor[threadIdx.x * per + k] = run; run += v[k]; }
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_cell_scatter(const uint32_t* count_ptr, const uint32_t* q_in, const uint16_t* keys, uint32_t* cursor, uint32_t* q_out)
+{
+  __shared__ uint32_t h[kCells];     // entries of this block per cell, then the running rank inside the block's range of that cell
+  __shared__ uint32_t base[kCells];  // start of this block's range inside the cell's global range
+  for (uint32_t b = threadIdx.x; b < kCells; b += kSortBlock) h[b] = 0u;
+  __syncthreads();
+  uint32_t lo, hi;
+  block_share(*count_ptr, lo, hi);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortBlock) atomicAdd(&h[keys[i] & (kCells - 1u)], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < kCells; b += kSortBlock) {
+    base[b] = h[b] ? atomicAdd(&cursor[b], h[b]) : 0u;
+    h[b] = 0u;
+  }
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+    const uint32_t b = keys[i] & (kCells - 1u);
+    q_out[base[b] + atomicAdd(&h[b], 1u)] = q_in[i];
+  }
+}
+
 template <uint32_t LOBES>
 __global__ void __launch_bounds__(kBlock, FH_SHADE_BLOCKS) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
 {
@@ -630,7 +707,7 @@ __global__ void __launch_bounds__(kBlock, FH_SHADE_BLOCKS) k_shade(SceneDev sc, 
     const uint32_t i = base + threadIdx.x;
     const bool valid = i < count;
     bool shaded = false, cont = false;
-    uint32_t p = 0;
+    uint32_t p = 0, cell = 0;
     if (valid) {
       p = q[i];
       ShadeOut o;
@@ -660,9 +737,10 @@ __global__ void __launch_bounds__(kBlock, FH_SHADE_BLOCKS) k_shade(SceneDev sc, 
         pool.ray_d[p] = mk4(o.next_d, 0.0f);
         pool.thr[p] = mk4(o.T, 0.0f);
       }
+      if (shaded || cont) cell = cell_of(fr, shaded ? o.sec[SEC_SKY].o : o.next_o);  // all rays of a path leave (almost) the same point
     }
-    queue_push(&cnt[CNT_SEC], pool.q_sec, shaded, p);
-    queue_push(&cnt_next[CNT_RAD], pool.q_rad[qnext], cont, p);
+    queue_push_keyed(&cnt[CNT_SEC], pool.q_sec, pool.key_sec, shaded, p, cell);
+    queue_push_keyed(&cnt_next[CNT_RAD], pool.q_rad[qnext], pool.key_rad, cont, p, cell);
   }
 }
 
@@ -1065,6 +1143,14 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(PoolDev pool, LayersDev l
   }
 }
 
+// counting sort of one bounce queue by the cell keys stored next to it (kernels above); `bins` = histogram (zero on entry and exit) + cursors
+void sort_queue_by_cell(hipStream_t st, uint32_t blocks, const uint32_t* count_ptr, const uint32_t* q_in, const uint16_t* keys, uint32_t* bins, uint32_t* q_out)
+{
+  hipLaunchKernelGGL(k_cell_hist, dim3(blocks), dim3(kSortBlock), 0, st, count_ptr, keys, bins);
+  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(kSortBlock), 0, st, bins, bins + kCells);
+  hipLaunchKernelGGL(k_cell_scatter, dim3(blocks), dim3(kSortBlock), 0, st, count_ptr, q_in, keys, bins + kCells, q_out);
+}
+
 template <typename F>
 void with_bool(bool b, F&& f)
 {
@@ -1178,6 +1264,9 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
   FH_HIP(alloc(P.lp_a, n)); FH_HIP(alloc(P.lp_b, n));
   FH_HIP(alloc(P.q_rad[0], n)); FH_HIP(alloc(P.q_rad[1], n)); FH_HIP(alloc(P.q_cls, n * kNumQueues)); FH_HIP(alloc(P.q_sec, n));
   FH_HIP(alloc(P.counters, (size_t)kCounterStride * 66));  // up to 65 bounces per pass
+  FH_HIP(alloc(P.key_sec, n)); FH_HIP(alloc(P.key_rad, n)); FH_HIP(alloc(P.q_tmp, n)); FH_HIP(alloc(P.q_sec_sorted, n));
+  FH_HIP(alloc(P.bins, (size_t)2 * kCells));
+  FH_HIP(hipMemset(P.bins, 0, sizeof(uint32_t) * 2 * kCells));
   P.capacity = capacity;
   return FH_OK;
 }
@@ -1215,6 +1304,11 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   fr.dir_disk_radius = 1e9f * tanf(0.5f * ctx->dir_angle * kPi / 180.0f);
   fr.scene_lo = mk3(ctx->scene_lo[0], ctx->scene_lo[1], ctx->scene_lo[2]);
   fr.scene_hi = mk3(ctx->scene_hi[0], ctx->scene_hi[1], ctx->scene_hi[2]);
+  {
+    const float cells = (float)(1u << kCellBits);
+    const float ex = ctx->scene_hi[0] - ctx->scene_lo[0], ey = ctx->scene_hi[1] - ctx->scene_lo[1], ez = ctx->scene_hi[2] - ctx->scene_lo[2];
+    fr.cell_scale = mk3(ex > 0.0f ? cells / ex : 0.0f, ey > 0.0f ? cells / ey : 0.0f, ez > 0.0f ? cells / ez : 0.0f);
+  }
   fr.sobol = ctx->d_sobol;
   fr.lut.reflection = ctx->d_lut_refl;
   fr.lut.sheen = ctx->d_lut_sheen;
@@ -1250,6 +1344,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const bool stream = coop && !(stream_env && stream_env[0] == '0');
   // 5 blocks (20 waves) per CU: all resident at the kernels' LDS / register budgets, and measured faster than 8 (fewer cache conflicts)
   uint32_t stream_grid = (uint32_t)prop.multiProcessorCount * 5u, stream_refill = 24u;
+  bool sort_queues = true;  // FH_SORT=0: trace the bounce queues in the order the shade kernels emit them
+  if (const char* e = getenv("FH_SORT")) sort_queues = e[0] != '0';
   uint32_t stream_chunk = 64u;  // queue entries a wave takes per global atomic (64/128 equal on big launches, 64 better on small ones)
   if (const char* e = getenv("FH_STREAM_CHUNK")) { const int v = atoi(e); if (v >= 16 && v <= 65536) stream_chunk = (uint32_t)v; }
   uint32_t exp_lds = 0;  // experiment: extra dynamic LDS per block to lower the occupancy
@@ -1293,55 +1389,71 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     uint32_t wave_depth = ctx->tail_depth ? ctx->tail_depth : ctx->auto_wave_depth;
     if (wave_depth < 1u) wave_depth = 1u;
     if (wave_depth > max_depth) wave_depth = max_depth;
+    PoolDev pd = pool, ps = pool;  // per-bounce views: pd rotates the radiance queues through the sorted buffers, ps reads the sorted secondary queue
+    uint32_t* q_spare = pool.q_tmp;
+    const uint32_t sort_blocks = n_paths / 16384u < 1u ? 1u : (n_paths / 16384u > 512u ? 512u : n_paths / 16384u);
     for (uint32_t depth = 0; depth < wave_depth; ++depth) {
       {
         Span sp(ctx, st, 0);
         if (wide) {
-          if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
-          else hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+          if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pd, depth, tc_closest);
+          else hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pd, depth, tc_closest);
         } else if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc, pool, depth, tc_closest,
+            hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc, pd, depth, tc_closest,
                                coop_flush, stream_refill, stream_chunk);
           }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_closest_coop<decltype(C)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest, coop_flush);
+            hipLaunchKernelGGL((k_trace_closest_coop<decltype(C)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, pd, depth, tc_closest, coop_flush);
           }); });
         } else {
           with_bool(count, [&](auto C) { with_bool(sc.use_bvh8 != 0, [&](auto W) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_closest_static<decltype(C)::value, decltype(W)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, tc_closest);
+            hipLaunchKernelGGL((k_trace_closest_static<decltype(C)::value, decltype(W)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, pd, depth, tc_closest);
           }); }); });
         }
         ctx->stats.n_closest_launches++;
       }
       {
         Span sp(ctx, st, 2);
-        hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pool, depth, ctx->n_classes);
-        for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pool, c, depth);
-        if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pool);
+        hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pd, depth, ctx->n_classes);
+        for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pd, c, depth);
+        if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pd);
+        if (sort_queues) {
+          // secondary rays of this bounce and the radiance rays of the next one, each into cell order
+          sort_queue_by_cell(st, sort_blocks, pool.counters + depth * kCounterStride + CNT_SEC, pool.q_sec, pool.key_sec, pool.bins, pool.q_sec_sorted);
+          ps = pd;
+          ps.q_sec = pool.q_sec_sorted;
+          const uint32_t nxt = (depth + 1u) & 1u;
+          sort_queue_by_cell(st, sort_blocks, pool.counters + (depth + 1u) * kCounterStride + CNT_RAD, pd.q_rad[nxt], pool.key_rad, pool.bins, q_spare);
+          uint32_t* const unsorted = pd.q_rad[nxt];
+          pd.q_rad[nxt] = q_spare;  // the next bounce reads the sorted queue ...
+          q_spare = unsorted;       // ... and the buffer it came from is the next scratch target
+        } else {
+          ps = pd;
+        }
       }
       {
         Span sp(ctx, st, 1);
         if (wide) {
           const bool lights = sc.n_lights > 0;
-          if (count && lights) hipLaunchKernelGGL((k_trace_secondary<true, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
-          else if (count) hipLaunchKernelGGL((k_trace_secondary<true, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
-          else if (lights) hipLaunchKernelGGL((k_trace_secondary<false, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
-          else hipLaunchKernelGGL((k_trace_secondary<false, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow);
+          if (count && lights) hipLaunchKernelGGL((k_trace_secondary<true, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow);
+          else if (count) hipLaunchKernelGGL((k_trace_secondary<true, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow);
+          else if (lights) hipLaunchKernelGGL((k_trace_secondary<false, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow);
+          else hipLaunchKernelGGL((k_trace_secondary<false, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow);
         } else if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc,
-                               fr, pool, depth, tc_shadow, coop_flush, stream_refill, stream_chunk);
+                               fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk);
           }); }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, depth, tc_shadow,
+            hipLaunchKernelGGL((k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow,
                                coop_flush);
           }); }); });
         } else {
           with_bool(count, [&](auto C) { with_bool(sc.use_bvh8 != 0, [&](auto W) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_static<decltype(C)::value, decltype(W)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, fr, pool,
+            hipLaunchKernelGGL((k_trace_secondary_static<decltype(C)::value, decltype(W)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, fr, ps,
                                depth, tc_shadow);
           }); }); }); });
         }
@@ -1350,7 +1462,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     }
     if (wave_depth < max_depth) {
       Span sp(ctx, st, 3);
-      hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), 0, st, sc, fr, pool, wave_depth);
+      hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), 0, st, sc, fr, pd, wave_depth);
     }
     if (ctx->acc_valid[slot ^ 1]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[slot ^ 1], 0));
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb);
