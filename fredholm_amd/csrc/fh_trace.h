@@ -631,115 +631,6 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Resumable BVH8 traversal for the persistent kernels: one call to step() advances the lane by
-// at most one node test and one triangle test, so a wave can interleave lanes that are in
-// different phases and replace finished lanes with new rays (dynamic fetch) instead of idling
-// until the slowest ray of the wave is done.
-// ---------------------------------------------------------------------------------------------
-struct Trav8 {
-  RayPre rp;
-  Ray8 r8;
-  uint2 group, tg;
-  float tmax;
-  HitRec best;
-  bool found;
-  int sp;
-  uint2 stack[kBvh8Stack];
-
-  FH_D void init(f3 o, f3 d, float tmax_)
-  {
-    rp = ray_prepare(o, d);
-    r8 = ray8_prepare(rp, d);
-    group = make_uint2(0u, 0x80000000u);
-    tg = make_uint2(0u, 0u);
-    tmax = tmax_;
-    best.t = tmax_; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu;
-    found = false;
-    sp = 0;
-  }
-
-  // returns true when the ray is finished (best / found hold the result)
-  template <bool ANY_HIT, bool COUNT>
-  FH_D bool step(const Bvh8Dev& bvh, uint32_t& n_nodes, uint32_t& n_tris)
-  {
-    if (tg.y == 0u) {
-      if ((group.y & 0xff000000u) == 0u) {
-        if (sp == 0) return true;
-        group = stack[--sp];
-      }
-      if (group.y & 0xff000000u) {
-        const uint32_t hits_imask = group.y;
-        const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
-        group.y &= ~(1u << bit);
-        if ((group.y & 0xff000000u) && sp < kBvh8Stack) stack[sp++] = group;
-        const uint32_t slot = (bit - 24u) ^ (r8.oct4 & 7u);
-        const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
-        const size_t ni = 5 * (size_t)(group.x + rel);
-        const uint4 n0 = bvh.nodes[ni], n1 = bvh.nodes[ni + 1], n2 = bvh.nodes[ni + 2], n3 = bvh.nodes[ni + 3], n4 = bvh.nodes[ni + 4];
-        if (COUNT) n_nodes++;
-        const uint32_t hm = node8_test(r8, n0, n1, n2, n3, n4, best.t);
-        group = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
-        tg = make_uint2(n1.y, hm & 0x00ffffffu);
-      }
-    }
-    if (tg.y) {
-      const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
-      tg.y &= tg.y - 1u;
-      const size_t ti = 3 * (size_t)(tg.x + b);
-      const float4 a = bvh.tris[ti], bb = bvh.tris[ti + 1], c = bvh.tris[ti + 2];
-      if (COUNT) n_tris++;
-      float t, bu, bv;
-      if (tri_test(rp, mk3(a), mk3(bb), mk3(c), t, bu, bv) && !(t > tmax)) {
-        const uint32_t prim = __float_as_uint(a.w);
-        if (!found || closer(t, prim, best)) {
-          best.t = t; best.u = bu; best.v = bv; best.prim = prim;
-          found = true;
-          if (ANY_HIT) return true;
-        }
-      }
-    }
-    return tg.y == 0u && (group.y & 0xff000000u) == 0u && sp == 0;
-  }
-};
-
-// Wave-level work distribution for persistent kernels: every wave owns a private chunk of the
-// work list, taken from a global cursor with ONE atomic per kChunk items, and hands items to
-// its idle lanes without further atomics.
-constexpr uint32_t kChunk = 256;
-struct WaveFeeder {
-  uint32_t next = 0, end = 0;  // wave-uniform
-  bool exhausted = false;      // wave-uniform
-  // Assign work indices to the lanes with want == true.  Returns the index for this lane or 0xffffffff.
-  FH_D uint32_t fetch(uint32_t* cursor, uint32_t count, bool want)
-  {
-    uint32_t mine = 0xffffffffu;
-    const unsigned long long need = __ballot(want);
-    if (need == 0ull || exhausted) return mine;
-    const uint32_t lane = __lane_id();
-    const uint32_t n_need = (uint32_t)__popcll(need);
-    const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-    uint32_t served = 0;
-    while (served < n_need) {
-      if (next == end) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(cursor, kChunk);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        if (b >= count) { exhausted = true; break; }
-        next = b;
-        end = b + kChunk < count ? b + kChunk : count;
-      }
-      const uint32_t avail = end - next;
-      const uint32_t take = avail < n_need - served ? avail : n_need - served;
-      if (want && rank >= served && rank < served + take) mine = next + (rank - served);
-      next += take;
-      served += take;
-    }
-    return mine;
-  }
-};
-
-// dispatch on the layout the scene was built with
 template <bool ANY_HIT, bool COUNT>
 FH_D bool traverse(const SceneDev& sc, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr)
 {

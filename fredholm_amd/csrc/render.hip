@@ -4,22 +4,23 @@
 // (__raygen__rg :418-502, __closesthit__radiance :680-944, __closesthit__light :952-999,
 // __miss__* :504-543).  One reference launch thread = one pixel looping over samples and bounces;
 // here a pass starts `B` samples for every owned pixel as independent path slots and advances all
-// of them one bounce at a time through five kernels:
+// of them one bounce at a time:
 //
-//   k_generate        CMJ slots 0/1 -> thin-lens camera ray, throughput 1           (pt.cu:433-454)
-//   k_trace_closest   closest hit for the radiance-ray queue.  Persistent waves: every wave pulls
-//                     chunks of the queue from a device cursor and refills idle lanes (dynamic
-//                     fetch) while the others keep traversing the 8-wide BVH
-//   k_route           sorts the hits into one queue per shading class (BSDF-sorted shading) with
-//                     block-aggregated appends: ballot + popcount per wave, LDS prefix per block,
-//                     one atomic per block and class
-//   k_shade<LOBES>    surface + BSDF + NEE samples + light ray + next direction + Russian roulette for
-//                     the next bounce; emits secondary rays with their pre-weighted contributions
-//   k_miss_primary    sky / background for paths that leave the scene at depth 0      (pt.cu:504-523)
-//   k_trace_secondary any-hit shadow rays (and the BSDF-sampled light ray) of every shaded path, in
-//                     the reference's order; adds the contributions that turn out unoccluded.
-//                     Persistent waves with dynamic fetch, like k_trace_closest
-//   k_accumulate      NaN guard + running mean of the 6 AOVs, sample_count += B       (pt.cu:474-501)
+//   k_generate               CMJ slots 0/1 -> thin-lens camera ray, throughput 1; rays that miss the scene bounds are
+//                            finished here (sky / background) and never enter a queue            (pt.cu:433-454, :504-523)
+//   k_trace_closest_stream   closest hit for the radiance-ray queue: waves draw chunks of the queue, refill idle lanes in
+//                            flight and test candidate triangles cooperatively (fh_trace.h: traverse_stream)
+//   k_route                  sorts the hits into one queue per shading class (BSDF-sorted shading) with block-aggregated
+//                            appends: ballot + popcount per wave, LDS prefix per block, one atomic per block and class
+//   k_shade<LOBES>           surface + BSDF + NEE samples + light ray + next direction + Russian roulette for the next bounce;
+//                            emits secondary rays with their pre-weighted contributions and the cell key of the hit point
+//   k_miss_primary           sky / background for paths that leave the scene at depth 0               (pt.cu:504-523)
+//   k_cell_hist/scan/scatter counting sort of the secondary and next-bounce queues by the cell of the ray origin
+//   k_trace_secondary_stream any-hit shadow rays (and the BSDF-sampled light ray) of every shaded path, in the reference's
+//                            order; adds the contributions that turn out unoccluded
+//   k_tail                   all remaining bounces of the few paths still alive after the wavefront bounces, one kernel
+//   k_accumulate             NaN guard + running mean of the 6 AOVs, sample_count += B                (pt.cu:474-501)
+// The *_static and *_coop kernels are the fixed-batch forms (binary-BVH fallback of tiny scenes, FH_STREAM=0 / FH_COOP=0).
 //
 // Sampler slots are addressed absolutely (fh_sampler.h): at bounce b the Sobol' dimension base is
 // 1 + b*n1 and the CMJ slot base is 2 + b*n2 with n1 = 3 + [lights], n2 = 3 + [directional] + [lights],
@@ -267,47 +268,6 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, Po
     pol.hp.flush(tc.hist);
     if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
     if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
-  }
-}
-
-// closest hit over the 8-wide BVH: persistent waves with dynamic fetch
-constexpr uint32_t kRefill = 20;  // refill a wave's idle lanes once this many are idle
-
-template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc)
-{
-  uint32_t* cnt = pool.counters + depth * kCounterStride;
-  const uint32_t count = cnt[CNT_RAD];
-  const uint32_t* q = pool.q_rad[depth & 1u];
-  uint32_t nn = 0, nt = 0, nr = 0;
-  WaveFeeder feed;
-  Trav8 tr;
-  bool active = false;
-  uint32_t p = 0;
-  for (;;) {
-    const uint32_t idx = feed.fetch(&cnt[CNT_CUR_CLOSEST], count, !active);
-    if (idx != 0xffffffffu) {
-      p = q[idx];
-      const float4 o = pool.ray_o[p], d = pool.ray_d[p];
-      tr.init(mk3(o), mk3(d), o.w);
-      active = true;
-      if (COUNT) nr++;
-    }
-    if (__ballot(active) == 0ull) break;
-    const uint32_t limit = feed.exhausted ? 64u : kRefill;
-    uint32_t idle;
-    do {
-      if (active && tr.template step<false, COUNT>(sc.bvh8, nn, nt)) {
-        pool.hit[p] = make_float4(tr.best.t, tr.best.u, tr.best.v, __uint_as_float(tr.best.prim));
-        active = false;
-      }
-      idle = (uint32_t)__popcll(__ballot(!active));
-    } while (idle < limit);
-  }
-  if (COUNT) {
-    atomicAdd(tc.nodes, (unsigned long long)nn);
-    atomicAdd(tc.tris, (unsigned long long)nt);
-    atomicAdd(tc.rays, (unsigned long long)nr);
   }
 }
 
@@ -966,76 +926,6 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, 
   }
 }
 
-// secondary rays over the 8-wide BVH: persistent waves, a lane owns one shaded path at a time and
-// walks its secondary-ray slots in order, so the additions into the path's radiance keep the
-// reference's order (directional, sky, area, BSDF-sampled) without atomics.
-template <bool COUNT, bool LIGHTS>
-__global__ void __launch_bounds__(kBlock) k_trace_secondary(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc)
-{
-  uint32_t* cnt = pool.counters + depth * kCounterStride;
-  const uint32_t count = cnt[CNT_SEC];
-  constexpr bool has_lights = LIGHTS;  // scenes without emitters never need the closest hit of the light ray
-  uint32_t nn = 0, nt = 0, nr = 0;
-  WaveFeeder feed;
-  Trav8 tr;
-  bool active = false;     // lane owns a path
-  bool tracing = false;    // lane has a ray in flight
-  uint32_t p = 0, slot = 0;
-  f3 L = mk3(0.0f);
-  for (;;) {
-    const uint32_t idx = feed.fetch(&cnt[CNT_CUR_SEC], count, !active);
-    if (idx != 0xffffffffu) {
-      p = pool.q_sec[idx];
-      L = mk3(pool.rad[p]);
-      slot = SEC_DIR;
-      active = true;
-      tracing = false;
-    }
-    if (__ballot(active) == 0ull) break;
-    const uint32_t limit = feed.exhausted ? 64u : kRefill;
-    uint32_t idle;
-    do {
-      if (active) {
-        if (!tracing) {
-          // advance to the next enabled, active slot of this path
-          while (slot <= SEC_LIGHT) {
-            const bool enabled = !(slot == SEC_DIR && !fr.has_dir) && !(slot == SEC_AREA && !has_lights);
-            if (enabled && pool.sec_d[(size_t)slot * pool.capacity + p].w != 0.0f) break;
-            ++slot;
-          }
-          if (slot > SEC_LIGHT) {
-            pool.rad[p] = mk4(L, 0.0f);
-            active = false;
-          } else {
-            const size_t k = (size_t)slot * pool.capacity + p;
-            const float4 o = pool.sec_o[k], d = pool.sec_d[k];
-            tr.init(mk3(o), mk3(d), o.w);
-            tracing = true;
-            if (COUNT) nr++;
-          }
-        }
-        if (tracing) {
-          const bool closest = (slot == SEC_LIGHT) && has_lights;
-          const bool done = closest ? tr.template step<false, COUNT>(sc.bvh8, nn, nt) : tr.template step<true, COUNT>(sc.bvh8, nn, nt);
-          if (done) {
-            const size_t k = (size_t)slot * pool.capacity + p;
-            if (closest) { const float4 la = pool.lp_a[p], lb = pool.lp_b[p]; L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, tr.rp.o, mk3(pool.sec_d[k]), tr.found, tr.best); }
-            else if (!tr.found) L += mk3(pool.sec_c[k]);
-            tracing = false;
-            ++slot;
-          }
-        }
-      }
-      idle = (uint32_t)__popcll(__ballot(!active));
-    } while (idle < limit);
-  }
-  if (COUNT) {
-    atomicAdd(tc.nodes, (unsigned long long)nn);
-    atomicAdd(tc.tris, (unsigned long long)nt);
-    atomicAdd(tc.rays, (unsigned long long)nr);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Tail: after the first bounces only a few thousand of the millions of paths of a pass are still alive,
 // and a bounce-synchronous wavefront then costs one worst-case ray latency per kernel and bounce.
@@ -1332,13 +1222,11 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (max_depth > 64) return fail(ctx, FH_E_INVALID, "fh_render: max_depth > 64 is not supported");
   hipDeviceProp_t prop;
   FH_HIP(hipGetDeviceProperties(&prop, ctx->device));
-  const uint32_t persistent_grid = (uint32_t)prop.multiProcessorCount * 8u;  // 8 blocks of 4 waves per CU: every wave resident
-  const bool wide = sc.use_bvh8 != 0 && getenv("FH_PERSISTENT") != nullptr;  // experimental persistent/dynamic-fetch kernels
   // wave-cooperative triangle tests (default for the wide BVH); FH_COOP=0 selects the per-lane loop, FH_COOP_T the flush threshold
   uint32_t coop_flush = 8u;
   if (const char* e = getenv("FH_COOP_T")) { const int v = atoi(e); if (v >= 1 && v <= 64) coop_flush = (uint32_t)v; }
   const char* coop_env = getenv("FH_COOP");
-  const bool coop = sc.use_bvh8 != 0 && !wide && sc.bvh8.n_tris < kCoopMaxTris && !(coop_env && coop_env[0] == '0');
+  const bool coop = sc.use_bvh8 != 0 && sc.bvh8.n_tris < kCoopMaxTris && !(coop_env && coop_env[0] == '0');
   // streaming form: FH_STREAM=0 falls back to one fixed batch per wave; FH_STREAM_GRID blocks, FH_STREAM_REFILL idle lanes
   const char* stream_env = getenv("FH_STREAM");
   const bool stream = coop && !(stream_env && stream_env[0] == '0');
@@ -1348,8 +1236,6 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (const char* e = getenv("FH_SORT")) sort_queues = e[0] != '0';
   uint32_t stream_chunk = 64u;  // queue entries a wave takes per global atomic (64/128 equal on big launches, 64 better on small ones)
   if (const char* e = getenv("FH_STREAM_CHUNK")) { const int v = atoi(e); if (v >= 16 && v <= 65536) stream_chunk = (uint32_t)v; }
-  uint32_t exp_lds = 0;  // experiment: extra dynamic LDS per block to lower the occupancy
-  if (const char* e = getenv("FH_EXP_LDS")) exp_lds = (uint32_t)atoi(e);
   if (const char* e = getenv("FH_STREAM_GRID")) { const int v = atoi(e); if (v >= 8 && v <= 8192) stream_grid = (uint32_t)v & ~7u; }
   if (const char* e = getenv("FH_STREAM_REFILL")) { const int v = atoi(e); if (v >= 1 && v <= 64) stream_refill = (uint32_t)v; }
 
@@ -1395,12 +1281,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     for (uint32_t depth = 0; depth < wave_depth; ++depth) {
       {
         Span sp(ctx, st, 0);
-        if (wide) {
-          if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pd, depth, tc_closest);
-          else hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid), dim3(kBlock), 0, st, sc, pd, depth, tc_closest);
-        } else if (stream) {
+        if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc, pd, depth, tc_closest,
+            hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), 0, st, sc, pd, depth, tc_closest,
                                coop_flush, stream_refill, stream_chunk);
           }); });
         } else if (coop) {
@@ -1435,15 +1318,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       }
       {
         Span sp(ctx, st, 1);
-        if (wide) {
-          const bool lights = sc.n_lights > 0;
-          if (count && lights) hipLaunchKernelGGL((k_trace_secondary<true, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow);
-          else if (count) hipLaunchKernelGGL((k_trace_secondary<true, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow);
-          else if (lights) hipLaunchKernelGGL((k_trace_secondary<false, true>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow);
-          else hipLaunchKernelGGL((k_trace_secondary<false, false>), dim3(persistent_grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow);
-        } else if (stream) {
+        if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), exp_lds, st, sc,
+            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), 0, st, sc,
                                fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk);
           }); }); });
         } else if (coop) {
