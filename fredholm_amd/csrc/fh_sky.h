@@ -61,7 +61,7 @@ FH_HD f3 hosek_radiance(const HosekSky& st, f3 sun_dir, float intensity, f3 v)
   for (int ch = 0; ch < 3; ++ch) {
     const float* c = st.cfg[ch];
     const float expM = fhe_exp(c[4] * gamma);
-    const float mieM = (1.0f + cg * cg) / fhe_pow((1.0f + c[8] * c[8] - 2.0f * c[8] * cg), 1.5f);
+    const float mieM = (1.0f + cg * cg) / fhe_pow1p5(1.0f + c[8] * c[8] - 2.0f * c[8] * cg);  // arhosek.cu:109-110: pow(x, 1.5)
     out[ch] = (1.0f + c[0] * fhe_exp(c[1] / (ct + 0.01f))) * (c[2] + c[3] * expM + c[5] * rayM + c[6] * mieM + c[7] * zenith) * st.rad[ch];
   }
   return intensity * mk3(out[0], out[1], out[2]);

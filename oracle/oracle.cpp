@@ -364,7 +364,7 @@ static float hosek_channel(const HosekState& st, int ch, float theta, float gamm
   const float cg = fhe_cos(gamma), ct = fhe_cos(theta);
   const float expM = fhe_exp(c[4] * gamma);
   const float rayM = cg * cg;
-  const float mieM = (1.0f + cg * cg) / fhe_pow((1.0f + c[8] * c[8] - 2.0f * c[8] * cg), 1.5f);
+  const float mieM = (1.0f + cg * cg) / fhe_pow1p5(1.0f + c[8] * c[8] - 2.0f * c[8] * cg);  // arhosek.cu:109-110: pow(x, 1.5)
   const float zenith = sqrtf(ct);
   return (1.0f + c[0] * fhe_exp(c[1] / (ct + 0.01f))) * (c[2] + c[3] * expM + c[5] * rayM + c[6] * mieM + c[7] * zenith) * st.rad[ch];
 }
