@@ -381,3 +381,22 @@ def test_hosek_cook_matches_outputs_of_the_reference_source(oracle):
         for c in g["cases"][::7]:
             cfg, rad = oracle.ref_hosek_state(c["turbidity"], c["albedo"], c["elevation"])
             assert [int(x) for x in cfg.reshape(-1).view(np.uint32)] == c["configs_bits"] and [int(x) for x in rad.view(np.uint32)] == c["radiances_bits"]
+
+
+def test_committed_tables_are_what_the_reference_tabulates(tmp_path):
+    """fredholm_amd/data/*.{u32,f32} (Sobol' matrices, albedo LUTs, Hosek coefficients) are data extracted from the reference by
+    tools/extract_tables.py; where the reference is present, re-extract and compare byte for byte"""
+    import importlib.util
+    import shutil
+    if not os.path.isdir("/root/reference/fredholm/modules"):
+        pytest.skip("/root/reference not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("extract_tables", os.path.join(root, "tools", "extract_tables.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.OUT = str(tmp_path)
+    mod.main()
+    data = os.path.join(root, "fredholm_amd", "data")
+    names = ["sobol_1024x52.u32", "lut_reflection.f32", "lut_sheen.f32", "hosek_rgb.f32"]
+    for n in names:
+        assert open(os.path.join(data, n), "rb").read() == open(os.path.join(str(tmp_path), n), "rb").read(), n
