@@ -347,6 +347,11 @@ int fh_set_transforms(fh_ctx* ctx, uint32_t n, const float* o2w, const float* w2
 {
   CTX_CHECK(ctx);
   if (!ctx->scene_loaded || !o2w || !w2o || n == 0) return fail(ctx, FH_E_INVALID, "fh_set_transforms: no scene / null arrays");
+  // a frame of an animation that only moves the camera (rtcamp8's scene) leaves every instance where it was: keep the world-space
+  // geometry and the acceleration structure (fh_bvh_build returns at once while bvh_valid holds)
+  if (ctx->h_o2w.size() == 12ull * n && ctx->h_w2o.size() == 12ull * n && std::memcmp(ctx->h_o2w.data(), o2w, 48ull * n) == 0 &&
+      std::memcmp(ctx->h_w2o.data(), w2o, 48ull * n) == 0)
+    return FH_OK;
   (void)hipStreamSynchronize(ctx->stream);
   ctx->h_o2w.assign(o2w, o2w + 12ull * n);
   ctx->h_w2o.assign(w2o, w2o + 12ull * n);
@@ -357,6 +362,7 @@ int fh_bvh_build(fh_ctx* ctx)
 {
   CTX_CHECK(ctx);
   if (!ctx->scene_loaded) return fail(ctx, FH_E_INVALID, "fh_bvh_build: no scene");
+  if (ctx->bvh_valid) return FH_OK;  // geometry unchanged since the last build
   return bvh_build_device(ctx);
 }
 
