@@ -591,6 +591,12 @@ int fh_copy_to_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes)
   FH_HIP(hipStreamSynchronize(ctx->stream));
   return FH_OK;
 }
+int fh_copy_on_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+  CTX_CHECK(ctx);
+  FH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return FH_OK;
+}
 int fh_copy_to_host(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes)
 {
   CTX_CHECK(ctx);

@@ -21,9 +21,7 @@ class Denoiser
   void denoise()
   {
     fh_ctx* ctx = cwl::require_context();
-    std::vector<float4> tmp(size_t(m_width) * m_height);
-    cwl::check(ctx, fh_copy_to_host(ctx, tmp.data(), m_in, tmp.size() * sizeof(float4)), "fh_copy_to_host");
-    cwl::check(ctx, fh_copy_to_device(ctx, m_out, tmp.data(), tmp.size() * sizeof(float4)), "fh_copy_to_device");
+    cwl::check(ctx, fh_copy_on_device(ctx, m_out, m_in, size_t(m_width) * m_height * sizeof(float4)), "fh_copy_on_device");
   }
   void wait_for_completion() { CUDA_SYNC_CHECK(); }
 

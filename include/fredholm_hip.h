@@ -176,6 +176,7 @@ int fh_free(fh_ctx* ctx, void* ptr);
 int fh_memset(fh_ctx* ctx, void* ptr, int value, uint64_t bytes);
 int fh_copy_to_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int fh_copy_to_host(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int fh_copy_on_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes); /* asynchronous, ordered on the context stream (cwl::CUDABuffer device-to-device copies) */
 void* fh_stream(fh_ctx* ctx); /* hipStream_t of the context */
 
 /* -- batch queries used by the parity tests (device evaluation of the same code the kernels run) */
