@@ -53,7 +53,7 @@ struct SceneDev {
   const uint8_t* face_cls;      // shading class of the face's material | 0x80 if emissive
   const MaterialDev* materials;
   const AreaLightDev* lights;
-  uint32_t n_faces, n_lights;
+  uint32_t n_faces, n_lights, n_materials;
   const fht_texture* textures;  // software texture unit (include/fh_texture_unit.h)
   const float* srgb_lut;        // 256-entry sRGB -> linear table
   uint32_t n_textures;

@@ -39,6 +39,8 @@ namespace fh {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kLutReflFloats = 16 * 16 * 2, kLutSheenFloats = 16 * 16;  // lut.cu:5-93, :917-955
+constexpr uint32_t kMatLds = 32;  // material records staged in LDS by the shade kernels when the scene has at most this many
 #ifndef FH_SHADE_BLOCKS
 #define FH_SHADE_BLOCKS 1  // minimum resident workgroups per CU the shade kernels are compiled for (register budget = 512 / that per lane)
 #endif
@@ -653,9 +655,23 @@ template <uint32_t LOBES>
 __global__ void __launch_bounds__(kBlock, FH_SHADE_BLOCKS) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
 {
   __shared__ SobolRows rows;
+  // the shade kernels run one wave per SIMD (512 registers per lane), so nothing hides a dependent global load: the small tables every
+  // hit reads -- the two albedo LUTs and, when there are few of them, the material records -- are staged in LDS once per workgroup
+  __shared__ float s_lut[kLutReflFloats + kLutSheenFloats];
+  __shared__ MaterialDev s_mat[kMatLds];
+  for (uint32_t i = threadIdx.x; i < kLutReflFloats; i += blockDim.x) s_lut[i] = fr.lut.reflection[i];
+  for (uint32_t i = threadIdx.x; i < kLutSheenFloats; i += blockDim.x) s_lut[kLutReflFloats + i] = fr.lut.sheen[i];
+  fr.lut.reflection = s_lut;
+  fr.lut.sheen = s_lut + kLutReflFloats;
+  if (sc.n_materials <= kMatLds) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.materials);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_mat);
+    for (uint32_t i = threadIdx.x; i < sc.n_materials * (uint32_t)(sizeof(MaterialDev) / 4); i += blockDim.x) dst[i] = src[i];
+    sc.materials = s_mat;
+  }
   BounceSlots bs;
   bs.set(fr, sc.n_lights, depth);
-  bs.load_rows(rows, fr.sobol);
+  bs.load_rows(rows, fr.sobol);  // (ends with the workgroup barrier that also publishes the tables above)
 
   uint32_t* cnt = pool.counters + depth * kCounterStride;
   uint32_t* cnt_next = cnt + kCounterStride;
@@ -1102,6 +1118,7 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.lights = ctx->d_lights;
   s.n_faces = ctx->n_faces;
   s.n_lights = ctx->n_lights;
+  s.n_materials = ctx->n_materials;
   s.textures = ctx->d_textures;
   s.srgb_lut = ctx->d_srgb_lut;
   s.n_textures = ctx->n_textures;
@@ -1262,7 +1279,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     // bounces run as bounce-synchronous wavefront kernels; the survivors are finished by k_tail.  Adaptive mode picks the
     // first depth at which an earlier pass had at most kTailPaths survivors (counts come from an asynchronous snapshot of
     // the device counters: no host/device synchronisation)
-    constexpr uint32_t kTailPaths = 65536;
+    uint32_t kTailPaths = 65536;
+    if (const char* e = getenv("FH_TAIL_PATHS")) { const int v = atoi(e); if (v >= 64) kTailPaths = (uint32_t)v; }
     for (int k = 0; k < 2; ++k) {
       if (!(ctx->counters_in_flight[k] && hipEventQuery(ctx->ev_counters[k]) == hipSuccess)) continue;
       ctx->counters_in_flight[k] = false;
