@@ -952,6 +952,19 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, 
 __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth)
 {
   __shared__ SobolRows rows;
+  __shared__ float s_lut[kLutReflFloats + kLutSheenFloats];  // as in k_shade: small tables every hit reads live in LDS
+  __shared__ MaterialDev s_mat[kMatLds];
+  for (uint32_t i = threadIdx.x; i < kLutReflFloats; i += blockDim.x) s_lut[i] = fr.lut.reflection[i];
+  for (uint32_t i = threadIdx.x; i < kLutSheenFloats; i += blockDim.x) s_lut[kLutReflFloats + i] = fr.lut.sheen[i];
+  fr.lut.reflection = s_lut;
+  fr.lut.sheen = s_lut + kLutReflFloats;
+  if (sc.n_materials <= kMatLds) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.materials);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_mat);
+    for (uint32_t i = threadIdx.x; i < sc.n_materials * (uint32_t)(sizeof(MaterialDev) / 4); i += blockDim.x) dst[i] = src[i];
+    sc.materials = s_mat;
+  }
+  __syncthreads();
   const uint32_t count = pool.counters[first_depth * kCounterStride + CNT_RAD];
   const uint32_t* q = pool.q_rad[first_depth & 1u];
   const bool has_lights = sc.n_lights > 0;
