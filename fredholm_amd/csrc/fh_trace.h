@@ -248,7 +248,7 @@ FH_D bool first_active_lane() { return __lane_id() == (uint32_t)__ffsll((long lo
 // Traversal stack of node groups: the first kLdsStack entries of every lane live in LDS (column layout
 // [entry][thread], conflict-free), deeper entries in the lane's private (scratch) array.  A wide tree of a
 // million triangles is ~8 levels deep and each level leaves at most one pending group, so the spill part is cold.
-constexpr int kLdsStack = 8;
+constexpr int kLdsStack = 6;  // 6 entries x 256 lanes x 8 B + the cooperative-test records = 26 KB per workgroup: six workgroups per CU
 template <bool LDS>
 struct GroupStack;
 template <>

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, Po
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, chunk), tc.hist);
-  __shared__ uint2 lds_stack[kLdsStack * kBlock];  // first 8 stack entries per lane in LDS: 39.0 -> 33.4 ms per 256 spp against a scratch-only stack
+  __shared__ uint2 lds_stack[kLdsStack * kBlock];  // first stack entries of every lane in LDS: 39.0 -> 33.4 ms per 256 spp against a scratch-only stack
   traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
@@ -1260,8 +1260,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   // streaming form: FH_STREAM=0 falls back to one fixed batch per wave; FH_STREAM_GRID blocks, FH_STREAM_REFILL idle lanes
   const char* stream_env = getenv("FH_STREAM");
   const bool stream = coop && !(stream_env && stream_env[0] == '0');
-  // 5 blocks (20 waves) per CU: all resident at the kernels' LDS / register budgets, and measured faster than 8 (fewer cache conflicts)
-  uint32_t stream_grid = (uint32_t)prop.multiProcessorCount * 5u, stream_refill = 24u;
+  // 6 workgroups (24 waves) per CU: all resident at the kernels' LDS budget (26 KB each)
+  uint32_t stream_grid = (uint32_t)prop.multiProcessorCount * 6u, stream_refill = 24u;
   bool sort_queues = true;  // FH_SORT=0: trace the bounce queues in the order the shade kernels emit them
   if (const char* e = getenv("FH_SORT")) sort_queues = e[0] != '0';
   uint32_t stream_chunk = 64u;  // queue entries a wave takes per global atomic (64/128 equal on big launches, 64 better on small ones)
