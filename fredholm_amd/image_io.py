@@ -2,7 +2,7 @@
 
 The reference decodes images with stb_image (fredholm/src/scene.cpp:7-66): 8-bit RGBA with a vertical flip for material
 textures, float RGBA without a flip for the IBL.  PNG (non-interlaced), binary PPM/PGM and Radiance .hdr are read here from
-their published specifications; JPEG is rejected.  Writers exist for tests and tools."""
+their published specifications (baseline JPEG included; progressive JPEG is rejected).  Writers exist for tests and tools."""
 import struct
 import zlib
 
@@ -146,7 +146,12 @@ def load_rgba8(path, flip_vertically=True):
     data = _read(path)
     if data[:2] == b"\x89P": img = decode_png(data)
     elif data[:2] in (b"P5", b"P6"): img = decode_pnm(data)
-    else: raise ValueError(f"failed to load {path}: only PNG and binary PPM/PGM images are supported in this build")
+    elif data[:2] == b"\xff\xd8":
+        try:
+            img = decode_jpeg(data)
+        except (IndexError, KeyError, StopIteration) as e:  # ran off the end of the file / a table or component that was never defined
+            raise ValueError(f"jpeg: truncated or inconsistent file {path}") from e
+    else: raise ValueError(f"failed to load {path}: only PNG, baseline JPEG and binary PPM/PGM images are supported in this build")
     return np.ascontiguousarray(img[::-1] if flip_vertically else img)
 
 
@@ -263,3 +268,341 @@ def write_hdr(path, rgb, rle=False):
                             f.write(bytes([n]) + row[x:x + n].tobytes()); x += n
             else:
                 f.write(rgbe[y].tobytes())
+
+
+# ------------------------------------------------------------------------------------------------ baseline JPEG (ITU-T T.81)
+_ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
+
+
+def _idct_block(coef):
+    """8x8 integer IDCT of dequantised coefficients (natural order, int64) -> uint8 samples; the arithmetic of
+    include/fredholm/image_io.h: JpegDecoder::idct, vectorised over the 8 lines of each pass."""
+    F0298, F0390, F0541, F0765, F0899, F1175, F1501, F1847, F1961, F2053, F2562, F3072 = 2446, 3196, 4433, 6270, 7373, 9633, 12299, 15137, 16069, 16819, 20995, 25172
+    CB, P1 = 13, 2
+
+    def one_d(d, sh):  # d[k] = array of the k-th input over 8 lines
+        z1 = (d[2] + d[6]) * F0541
+        t2, t3 = z1 + d[6] * (-F1847), z1 + d[2] * F0765
+        t0, t1 = (d[0] + d[4]) << CB, (d[0] - d[4]) << CB
+        t10, t13, t11, t12 = t0 + t3, t0 - t3, t1 + t2, t1 - t2
+        a0, a1, a2, a3 = d[7], d[5], d[3], d[1]
+        z1, z2, z3, z4 = a0 + a3, a1 + a2, a0 + a2, a1 + a3
+        z5 = (z3 + z4) * F1175
+        a0, a1, a2, a3 = a0 * F0298, a1 * F2053, a2 * F3072, a3 * F1501
+        z1, z2, z3, z4 = z1 * -F0899, z2 * -F2562, z3 * -F1961 + z5, z4 * -F0390 + z5
+        a0, a1, a2, a3 = a0 + z1 + z3, a1 + z2 + z4, a2 + z2 + z3, a3 + z1 + z4
+        rnd = 1 << (sh - 1)
+        return [(v + rnd) >> sh for v in (t10 + a3, t11 + a2, t12 + a1, t13 + a0, t13 - a0, t12 - a1, t11 - a2, t10 - a3)]
+    c = np.asarray(coef, dtype=np.int64).reshape(8, 8)
+    ws = np.stack(one_d([c[k, :] for k in range(8)], CB - P1), axis=0)          # pass 1: columns; ws[k, i]
+    out = np.stack(one_d([ws[:, k] for k in range(8)], CB + P1 + 3), axis=1)    # pass 2: rows; out[i, k]
+    return np.clip(out + 128, 0, 255).astype(np.uint8)
+
+
+def decode_jpeg(data):
+    """bytes -> uint8 [h, w, 4]; bit-identical to the C++ decoder (integer IDCT, triangle upsampling, fixed-point colour)."""
+    if data[:2] != b"\xff\xd8":
+        raise ValueError("jpeg: bad signature")
+    pos = 2
+    q, dc, ac = {}, {}, {}
+    comps, width, height, restart, adobe = [], 0, 0, 0, None
+
+    def tables(d, store):
+        p = 0
+        while p < len(d):
+            tc, th = d[p] >> 4, d[p] & 15
+            counts = list(d[p + 1:p + 17])
+            total = sum(counts)
+            syms = d[p + 17:p + 17 + total]
+            if tc > 1 or th > 3 or len(syms) != total:
+                raise ValueError("jpeg: bad DHT")
+            store[tc][th] = (counts, syms)
+            p += 17 + total
+    while True:
+        while not (data[pos] == 0xFF and data[pos + 1] not in (0x00, 0xFF)):
+            pos += 1
+        marker = data[pos + 1]
+        pos += 2
+        if marker == 0xD9:
+            raise ValueError("jpeg: no image data")
+        n = (data[pos] << 8) | data[pos + 1]
+        d = data[pos + 2:pos + n]
+        if marker == 0xDA:
+            break
+        if marker in (0xC0, 0xC1):
+            if d[0] != 8: raise ValueError("jpeg: only 8-bit samples are supported")
+            height, width, nc = (d[1] << 8) | d[2], (d[3] << 8) | d[4], d[5]
+            if nc not in (1, 3): raise ValueError("jpeg: only 1- and 3-component images are supported")
+            comps = [{"id": d[6 + 3 * i], "h": d[7 + 3 * i] >> 4, "v": d[7 + 3 * i] & 15, "tq": d[8 + 3 * i], "pred": 0} for i in range(nc)]
+            if any(not (1 <= c["h"] <= 2 and 1 <= c["v"] <= 2) for c in comps): raise ValueError("jpeg: unsupported sampling factors")
+            if nc == 1: comps[0]["h"] = comps[0]["v"] = 1
+        elif marker == 0xC2: raise ValueError("jpeg: progressive files are not supported")
+        elif 0xC3 <= marker <= 0xCF and marker not in (0xC4, 0xC8, 0xCC): raise ValueError("jpeg: unsupported coding process")
+        elif marker == 0xC4: tables(d, {0: dc, 1: ac})
+        elif marker == 0xDB:
+            p = 0
+            while p < len(d):
+                pq, tq = d[p] >> 4, d[p] & 15
+                p += 1
+                tab = np.zeros(64, dtype=np.int64)
+                for i in range(64):
+                    tab[_ZIGZAG[i]] = ((d[p] << 8) | d[p + 1]) if pq else d[p]
+                    p += pq + 1
+                q[tq] = tab
+        elif marker == 0xDD: restart = (d[0] << 8) | d[1]
+        elif marker == 0xEE and d[:5] == b"Adobe": adobe = d[11]
+        pos += n
+    ns = d[0]
+    if ns != len(comps): raise ValueError("jpeg: non-interleaved scans are not supported")
+    for i in range(ns):
+        c = next(c for c in comps if c["id"] == d[1 + 2 * i])
+        c["td"], c["ta"] = d[2 + 2 * i] >> 4, d[2 + 2 * i] & 15
+    pos += n
+    hmax, vmax = max(c["h"] for c in comps), max(c["v"] for c in comps)
+    mx, my = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    for c in comps:
+        c["bw"], c["bh"] = mx * c["h"] * 8, my * c["v"] * 8
+        c["plane"] = np.zeros((c["bh"], c["bw"]), dtype=np.uint8)
+    state = {"bits": 0, "n": 0, "pos": pos, "marker": False}
+
+    def bit():
+        if state["n"] == 0:
+            b = 0
+            if not state["marker"] and state["pos"] < len(data):
+                b = data[state["pos"]]
+                if b == 0xFF:
+                    b2 = data[state["pos"] + 1] if state["pos"] + 1 < len(data) else 0xD9
+                    if b2 == 0: state["pos"] += 2
+                    else: state["marker"], b = True, 0
+                else: state["pos"] += 1
+            state["bits"], state["n"] = b, 8
+        state["n"] -= 1
+        return (state["bits"] >> state["n"]) & 1
+
+    def receive(k):
+        v = 0
+        for _ in range(k): v = (v << 1) | bit()
+        return v
+
+    def extend(v, k):
+        return 0 if k == 0 else (v - (1 << k) + 1 if v < (1 << (k - 1)) else v)
+
+    def decode(tab):
+        counts, syms = tab
+        code = first = index = 0
+        for ln in range(16):
+            code |= bit()
+            cnt = counts[ln]
+            if code - cnt < first: return syms[index + (code - first)]
+            index += cnt
+            first = (first + cnt) << 1
+            code <<= 1
+        raise ValueError("jpeg: bad Huffman code")
+    count = 0
+    for y in range(my):
+        for x in range(mx):
+            if restart and count and count % restart == 0:
+                state["n"], state["marker"] = 0, False
+                while not (data[state["pos"]] == 0xFF and 0xD0 <= data[state["pos"] + 1] <= 0xD7): state["pos"] += 1
+                state["pos"] += 2
+                for c in comps: c["pred"] = 0
+            count += 1
+            for c in comps:
+                for by in range(c["v"]):
+                    for bx in range(c["h"]):
+                        coef = np.zeros(64, dtype=np.int64)
+                        t = decode(dc[c["td"]])
+                        c["pred"] += extend(receive(t), t)
+                        coef[0] = c["pred"] * q[c["tq"]][0]
+                        k = 1
+                        while k < 64:
+                            rs = decode(ac[c["ta"]])
+                            r, sz = rs >> 4, rs & 15
+                            if sz == 0:
+                                if r == 15:
+                                    k += 16
+                                    continue
+                                break
+                            k += r
+                            if k > 63: raise ValueError("jpeg: bad AC run")
+                            coef[_ZIGZAG[k]] = extend(receive(sz), sz) * q[c["tq"]][_ZIGZAG[k]]
+                            k += 1
+                        y0, x0 = (y * c["v"] + by) * 8, (x * c["h"] + bx) * 8
+                        c["plane"][y0:y0 + 8, x0:x0 + 8] = _idct_block(coef)
+
+    def upsampled(c):
+        fx, fy = hmax // c["h"], vmax // c["v"]
+        p = c["plane"].astype(np.int32)
+        if fx == 1 and fy == 1:
+            return p
+        H, W = p.shape
+
+        def shifted(a, dy, dx):  # a[y + dy, x + dx] with edge replication
+            ys = np.clip(np.arange(H) + dy, 0, H - 1)
+            xs = np.clip(np.arange(W) + dx, 0, W - 1)
+            return a[np.ix_(ys, xs)]
+        if fx == 2 and fy == 1:
+            out = np.zeros((H, 2 * W), np.int32)
+            out[:, 0::2] = (3 * p + shifted(p, 0, -1) + 1) >> 2
+            out[:, 1::2] = (3 * p + shifted(p, 0, 1) + 2) >> 2
+            return out
+        if fx == 1 and fy == 2:
+            out = np.zeros((2 * H, W), np.int32)
+            out[0::2] = (3 * p + shifted(p, -1, 0) + 1) >> 2
+            out[1::2] = (3 * p + shifted(p, 1, 0) + 2) >> 2
+            return out
+        out = np.zeros((2 * H, 2 * W), np.int32)
+        for oy, dy in ((0, -1), (1, 1)):
+            near_col = 3 * p + shifted(p, dy, 0)
+            for ox, dx, rnd in ((0, -1, 8), (1, 1, 7)):
+                far_col = 3 * shifted(p, 0, dx) + shifted(p, dy, dx)
+                out[oy::2, ox::2] = (3 * near_col + far_col + rnd) >> 4
+        return out
+    img = np.full((height, width, 4), 255, dtype=np.uint8)
+    if len(comps) == 1:
+        img[..., :3] = comps[0]["plane"][:height, :width, None]
+        return img
+    Y, cb, cr = (upsampled(c)[:height, :width].astype(np.int64) for c in comps)
+    if adobe is None or adobe != 0:
+        cb, cr = cb - 128, cr - 128
+        img[..., 0] = np.clip(Y + ((91881 * cr + 32768) >> 16), 0, 255)
+        img[..., 1] = np.clip(Y + ((-22554 * cb - 46802 * cr + 32768) >> 16), 0, 255)
+        img[..., 2] = np.clip(Y + ((116130 * cb + 32768) >> 16), 0, 255)
+    else:
+        img[..., 0], img[..., 1], img[..., 2] = Y, cb, cr
+    return img
+
+
+_STD_LUMA_Q = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                        18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99])
+_STD_CHROMA_Q = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32)
+# Annex K.3 typical Huffman tables: (BITS[1..16], HUFFVAL)
+_STD_DC_L = ([0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0], list(range(12)))
+_STD_DC_C = ([0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0], list(range(12)))
+_STD_AC_L = ([0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7D],
+             [0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xA1, 0x08, 0x23, 0x42, 0xB1, 0xC1, 0x15, 0x52,
+              0xD1, 0xF0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0A, 0x16, 0x17, 0x18, 0x19, 0x1A, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2A, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3A, 0x43, 0x44, 0x45,
+              0x46, 0x47, 0x48, 0x49, 0x4A, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5A, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6A, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7A, 0x83,
+              0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8A, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9A, 0xA2, 0xA3, 0xA4, 0xA5, 0xA6, 0xA7, 0xA8, 0xA9, 0xAA, 0xB2, 0xB3, 0xB4, 0xB5, 0xB6,
+              0xB7, 0xB8, 0xB9, 0xBA, 0xC2, 0xC3, 0xC4, 0xC5, 0xC6, 0xC7, 0xC8, 0xC9, 0xCA, 0xD2, 0xD3, 0xD4, 0xD5, 0xD6, 0xD7, 0xD8, 0xD9, 0xDA, 0xE1, 0xE2, 0xE3, 0xE4, 0xE5, 0xE6, 0xE7, 0xE8,
+              0xE9, 0xEA, 0xF1, 0xF2, 0xF3, 0xF4, 0xF5, 0xF6, 0xF7, 0xF8, 0xF9, 0xFA])
+_STD_AC_C = ([0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77],
+             [0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xA1, 0xB1, 0xC1, 0x09, 0x23, 0x33,
+              0x52, 0xF0, 0x15, 0x62, 0x72, 0xD1, 0x0A, 0x16, 0x24, 0x34, 0xE1, 0x25, 0xF1, 0x17, 0x18, 0x19, 0x1A, 0x26, 0x27, 0x28, 0x29, 0x2A, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3A, 0x43, 0x44,
+              0x45, 0x46, 0x47, 0x48, 0x49, 0x4A, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5A, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6A, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7A,
+              0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8A, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9A, 0xA2, 0xA3, 0xA4, 0xA5, 0xA6, 0xA7, 0xA8, 0xA9, 0xAA, 0xB2, 0xB3, 0xB4,
+              0xB5, 0xB6, 0xB7, 0xB8, 0xB9, 0xBA, 0xC2, 0xC3, 0xC4, 0xC5, 0xC6, 0xC7, 0xC8, 0xC9, 0xCA, 0xD2, 0xD3, 0xD4, 0xD5, 0xD6, 0xD7, 0xD8, 0xD9, 0xDA, 0xE2, 0xE3, 0xE4, 0xE5, 0xE6, 0xE7,
+              0xE8, 0xE9, 0xEA, 0xF2, 0xF3, 0xF4, 0xF5, 0xF6, 0xF7, 0xF8, 0xF9, 0xFA])
+
+
+def write_jpeg(path, img, quality=90, subsampling=(1, 1), restart_interval=0):
+    """Minimal baseline JPEG writer for tests and tools: uint8 [h, w, 3] (YCbCr 4:4:4, 4:2:2, 4:2:0 via subsampling=(h, v) of luma) or
+    [h, w] (grey); Annex K quantisation tables scaled by `quality`, Annex K Huffman tables, optional restart markers."""
+    img = np.asarray(img, dtype=np.uint8)
+    grey = img.ndim == 2
+    h, w = img.shape[:2]
+    scale = 5000 // quality if quality < 50 else 200 - 2 * quality
+    qt = [np.clip((t * scale + 50) // 100, 1, 255).astype(np.int64) for t in (_STD_LUMA_Q, _STD_CHROMA_Q)]
+    if grey:
+        planes, samp = [img.astype(np.float64)], [(1, 1)]
+    else:
+        r, g, b = (img[..., k].astype(np.float64) for k in range(3))
+        planes = [0.299 * r + 0.587 * g + 0.114 * b, -0.168736 * r - 0.331264 * g + 0.5 * b + 128.0, 0.5 * r - 0.418688 * g - 0.081312 * b + 128.0]
+        samp = [tuple(subsampling), (1, 1), (1, 1)]
+    hmax, vmax = samp[0]
+    mx, my = -(-w // (8 * hmax)), -(-h // (8 * vmax))
+    padded = []
+    for p, (sh, sv) in zip(planes, samp):
+        fx, fy = hmax // sh, vmax // sv
+        full = np.pad(p, ((0, my * 8 * vmax - h), (0, mx * 8 * hmax - w)), mode="edge")
+        padded.append(full.reshape(full.shape[0] // fy, fy, full.shape[1] // fx, fx).mean(axis=(1, 3)))
+    k = np.arange(8)
+    C = np.sqrt(2.0 / 8) * np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16)
+    C[0] /= np.sqrt(2.0)
+
+    def codes(bits, vals):
+        out, code, i = {}, 0, 0
+        for ln in range(1, 17):
+            for _ in range(bits[ln - 1]):
+                out[vals[i]] = (code, ln)
+                code += 1
+                i += 1
+            code <<= 1
+        return out
+    hd = [codes(*_STD_DC_L), codes(*_STD_DC_C)]
+    ha = [codes(*_STD_AC_L), codes(*_STD_AC_C)]
+    stream, acc, nacc = bytearray(), 0, 0
+
+    def put(code, ln):
+        nonlocal acc, nacc
+        acc, nacc = (acc << ln) | code, nacc + ln
+        while nacc >= 8:
+            byte = (acc >> (nacc - 8)) & 0xFF
+            stream.append(byte)
+            if byte == 0xFF: stream.append(0)
+            nacc -= 8
+        acc &= (1 << nacc) - 1
+
+    def flush():
+        nonlocal acc, nacc
+        if nacc: put((1 << (8 - nacc)) - 1, 8 - nacc)
+        acc = nacc = 0
+
+    def size_bits(v):
+        a = abs(int(v))
+        n = a.bit_length()
+        return n, (v if v >= 0 else v + (1 << n) - 1) & ((1 << n) - 1)
+    pred = [0] * len(planes)
+    count = 0
+    for y in range(my):
+        for x in range(mx):
+            if restart_interval and count and count % restart_interval == 0:
+                flush()
+                stream.extend([0xFF, 0xD0 + ((count // restart_interval - 1) & 7)])
+                pred = [0] * len(planes)
+            count += 1
+            for ci, (p, (sh, sv)) in enumerate(zip(padded, samp)):
+                t = 0 if ci == 0 else 1
+                for by in range(sv):
+                    for bx in range(sh):
+                        blk = p[(y * sv + by) * 8:(y * sv + by) * 8 + 8, (x * sh + bx) * 8:(x * sh + bx) * 8 + 8] - 128.0
+                        coef = np.rint((C @ blk @ C.T).reshape(64) / qt[t]).astype(np.int64)[_ZIGZAG]
+                        n, bits = size_bits(coef[0] - pred[ci])
+                        pred[ci] = int(coef[0])
+                        put(*hd[t][n])
+                        if n: put(bits, n)
+                        run = 0
+                        last = max([i for i in range(1, 64) if coef[i]] or [0])
+                        for i in range(1, last + 1):
+                            if coef[i] == 0:
+                                run += 1
+                                continue
+                            while run > 15:
+                                put(*ha[t][0xF0])
+                                run -= 16
+                            n, bits = size_bits(coef[i])
+                            put(*ha[t][(run << 4) | n])
+                            put(bits, n)
+                            run = 0
+                        if last < 63: put(*ha[t][0x00])
+    flush()
+
+    def seg(marker, body):
+        return bytes([0xFF, marker]) + struct.pack(">H", len(body) + 2) + bytes(body)
+    out = bytearray(b"\xff\xd8" + seg(0xE0, b"JFIF\0\x01\x01\0\0\x01\0\x01\0\0"))
+    for t in range(1 if grey else 2):
+        out += seg(0xDB, bytes([t]) + bytes(int(v) for v in qt[t][_ZIGZAG]))
+    sof = struct.pack(">BHHB", 8, h, w, len(planes))
+    for ci, (sh, sv) in enumerate(samp):
+        sof += bytes([ci + 1, (sh << 4) | sv, 0 if ci == 0 else 1])
+    out += seg(0xC0, sof)
+    for cls, tid, (bits, vals) in ((0, 0, _STD_DC_L), (1, 0, _STD_AC_L)) + (() if grey else ((0, 1, _STD_DC_C), (1, 1, _STD_AC_C))):
+        out += seg(0xC4, bytes([(cls << 4) | tid]) + bytes(bits) + bytes(vals))
+    if restart_interval:
+        out += seg(0xDD, struct.pack(">H", restart_interval))
+    sos = bytes([len(planes)])
+    for ci in range(len(planes)):
+        sos += bytes([ci + 1, 0x00 if ci == 0 else 0x11])
+    out += seg(0xDA, sos + b"\0\x3f\0") + bytes(stream) + b"\xff\xd9"
+    open(path, "wb").write(bytes(out))

@@ -4,8 +4,9 @@
 //   Texture      (fredholm/src/scene.cpp:7-37):  stbi_load(..., STBI_rgb_alpha) with stbi_set_flip_vertically_on_load(true)
 //   FloatTexture (fredholm/src/scene.cpp:39-66): stbi_loadf(..., STBI_rgb_alpha) without the flip (IBL)
 // This header restates the published formats it needs from their specifications: PNG (W3C PNG 2nd ed.: zlib/deflate RFC 1950/1951,
-// the five scanline filters, colour types 0/2/3/4/6 at 8 or 16 bits, non-interlaced), binary PPM/PGM, and Radiance RGBE .hdr
-// (flat and new-style run-length scanlines).  JPEG and interlaced PNG are rejected with an exception, never decoded wrongly.
+// the five scanline filters, colour types 0/2/3/4/6 at 8 or 16 bits, non-interlaced), baseline JPEG (ITU-T T.81 sequential Huffman),
+// binary PPM/PGM, and Radiance RGBE .hdr (flat and new-style run-length scanlines).  Progressive JPEG and interlaced PNG are
+// rejected with an exception, never decoded wrongly.
 // Conversion conventions follow stb_image's documented behaviour: grey -> r=g=b, missing alpha -> 255 (1.0f for .hdr),
 // 16-bit samples -> high byte, palette -> RGBA through PLTE/tRNS, .hdr texel = mantissa * 2^(exponent - 136).
 #pragma once
@@ -335,6 +336,320 @@ inline Image8 decode_pnm(const std::vector<uint8_t>& file)  // binary P5 / P6, m
   return img;
 }
 
+// ---------------------------------------------------------------------------------------------- baseline JPEG (ITU-T T.81)
+// Sequential Huffman DCT frames (SOF0 / SOF1, 8-bit), 1 or 3 components, sampling factors 1 and 2, restart intervals, JFIF YCbCr.
+// Progressive, arithmetic-coded, 12-bit and 4-component files are rejected.  Everything after entropy decoding is integer arithmetic,
+// so that this decoder and fredholm_amd/image_io.py produce identical bytes:
+//   IDCT      Loeffler-Ligtenberg-Moschytz 1-D flow graph, 13-bit constants, two passes (the scaling of the IJG "slow integer" IDCT)
+//   upsample  triangle filter: 3/4 nearer + 1/4 farther sample per axis, rounding constants 1,2 (one axis) and 8,7 (two axes)
+//   colour    R = Y + 1.402 Cr', G = Y - 0.344136 Cb' - 0.714136 Cr', B = Y + 1.772 Cb' in 16-bit fixed point, clamped
+// stb_image, which the reference uses, has its own IDCT and resampling code: decoded texels can differ by a unit in the last place.
+class JpegDecoder {
+ public:
+  explicit JpegDecoder(const std::vector<uint8_t>& file) : m_f(file) {}
+
+  Image8 run()
+  {
+    if (m_f.size() < 4 || m_f[0] != 0xff || m_f[1] != 0xd8) throw std::runtime_error("jpeg: bad signature");
+    m_pos = 2;
+    for (;;) {
+      const int marker = next_marker();
+      if (marker == 0xd9) throw std::runtime_error("jpeg: no image data");
+      if (marker == 0xda) break;
+      const size_t len = seg_length();
+      const uint8_t* d = &m_f[m_pos + 2];
+      const size_t n = len - 2;
+      if (marker == 0xc0 || marker == 0xc1) frame(d, n);
+      else if (marker == 0xc2) throw std::runtime_error("jpeg: progressive files are not supported");
+      else if (marker >= 0xc3 && marker <= 0xcf && marker != 0xc4 && marker != 0xc8 && marker != 0xcc) throw std::runtime_error("jpeg: unsupported coding process");
+      else if (marker == 0xc4) huffman_tables(d, n);
+      else if (marker == 0xdb) quant_tables(d, n);
+      else if (marker == 0xdd) { if (n < 2) throw std::runtime_error("jpeg: bad DRI"); m_restart = (d[0] << 8) | d[1]; }
+      else if (marker == 0xee && n >= 12 && std::memcmp(d, "Adobe", 5) == 0) { m_adobe = true; m_adobe_transform = d[11]; }
+      m_pos += len;
+    }
+    scan();
+    return finish();
+  }
+
+ private:
+  struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0, bw = 0, bh = 0; std::vector<uint8_t> plane; };
+  struct Table { uint16_t count[17] = {}; uint8_t symbol[256] = {}; bool set = false; };
+  const std::vector<uint8_t>& m_f;
+  size_t m_pos = 0;
+  int m_width = 0, m_height = 0, m_restart = 0, m_hmax = 1, m_vmax = 1;
+  bool m_adobe = false;
+  int m_adobe_transform = 0;
+  std::vector<Component> m_comp;
+  uint16_t m_q[4][64] = {};
+  bool m_q_set[4] = {false, false, false, false};
+  Table m_dc[4], m_ac[4];
+  uint32_t m_bits = 0;
+  int m_nbits = 0;
+  bool m_hit_marker = false;
+
+  int next_marker()
+  {
+    while (m_pos + 1 < m_f.size()) {
+      if (m_f[m_pos] != 0xff) { ++m_pos; continue; }
+      const int m = m_f[m_pos + 1];
+      if (m == 0x00 || m == 0xff) { ++m_pos; continue; }
+      m_pos += 2;
+      return m;
+    }
+    throw std::runtime_error("jpeg: truncated");
+  }
+  size_t seg_length() const
+  {
+    if (m_pos + 2 > m_f.size()) throw std::runtime_error("jpeg: truncated");
+    const size_t len = (size_t(m_f[m_pos]) << 8) | m_f[m_pos + 1];
+    if (len < 2 || m_pos + len > m_f.size()) throw std::runtime_error("jpeg: bad segment length");
+    return len;
+  }
+  void frame(const uint8_t* d, size_t n)
+  {
+    if (n < 6 || d[0] != 8) throw std::runtime_error("jpeg: only 8-bit samples are supported");
+    m_height = (d[1] << 8) | d[2];
+    m_width = (d[3] << 8) | d[4];
+    const int nc = d[5];
+    if (m_width <= 0 || m_height <= 0) throw std::runtime_error("jpeg: bad dimensions");
+    if (nc != 1 && nc != 3) throw std::runtime_error("jpeg: only 1- and 3-component images are supported");
+    if (n < size_t(6 + 3 * nc)) throw std::runtime_error("jpeg: bad SOF");
+    m_comp.assign(size_t(nc), Component());
+    for (int i = 0; i < nc; ++i) {
+      Component& c = m_comp[size_t(i)];
+      c.id = d[6 + 3 * i]; c.h = d[7 + 3 * i] >> 4; c.v = d[7 + 3 * i] & 15; c.tq = d[8 + 3 * i];
+      if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2 || c.tq > 3) throw std::runtime_error("jpeg: unsupported sampling factors");
+      m_hmax = std::max(m_hmax, c.h); m_vmax = std::max(m_vmax, c.v);
+    }
+    if (nc == 1) { m_comp[0].h = m_comp[0].v = 1; m_hmax = m_vmax = 1; }
+    for (Component& c : m_comp)
+      if (m_hmax % c.h || m_vmax % c.v) throw std::runtime_error("jpeg: unsupported sampling factors");
+  }
+  void quant_tables(const uint8_t* d, size_t n)
+  {
+    static const uint8_t zz[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    size_t p = 0;
+    while (p < n) {
+      const int pq = d[p] >> 4, tq = d[p] & 15;
+      ++p;
+      if (tq > 3 || pq > 1 || p + size_t(64 * (pq + 1)) > n) throw std::runtime_error("jpeg: bad DQT");
+      for (int i = 0; i < 64; ++i) { m_q[tq][zz[i]] = pq ? uint16_t((d[p] << 8) | d[p + 1]) : d[p]; p += size_t(pq + 1); }
+      m_q_set[tq] = true;
+    }
+  }
+  void huffman_tables(const uint8_t* d, size_t n)
+  {
+    size_t p = 0;
+    while (p < n) {
+      if (p + 17 > n) throw std::runtime_error("jpeg: bad DHT");
+      const int tc = d[p] >> 4, th = d[p] & 15;
+      if (tc > 1 || th > 3) throw std::runtime_error("jpeg: bad DHT");
+      Table& t = tc ? m_ac[th] : m_dc[th];
+      int total = 0;
+      for (int i = 1; i <= 16; ++i) { t.count[i] = d[p + size_t(i)]; total += t.count[i]; }
+      p += 17;
+      if (total > 256 || p + size_t(total) > n) throw std::runtime_error("jpeg: bad DHT");
+      std::memcpy(t.symbol, d + p, size_t(total));
+      t.set = true;
+      p += size_t(total);
+    }
+  }
+  // entropy-coded segment: 0xff 0x00 is a stuffed 0xff; any other marker ends the data (zero bits follow)
+  int bit()
+  {
+    if (m_nbits == 0) {
+      uint8_t b = 0;
+      if (!m_hit_marker && m_pos < m_f.size()) {
+        b = m_f[m_pos];
+        if (b == 0xff) {
+          const uint8_t b2 = m_pos + 1 < m_f.size() ? m_f[m_pos + 1] : 0xd9;
+          if (b2 == 0x00) m_pos += 2;
+          else { m_hit_marker = true; b = 0; }
+        } else ++m_pos;
+      }
+      m_bits = b;
+      m_nbits = 8;
+    }
+    --m_nbits;
+    return int((m_bits >> m_nbits) & 1u);
+  }
+  int receive(int n) { int v = 0; for (int i = 0; i < n; ++i) v = (v << 1) | bit(); return v; }
+  static int extend(int v, int n) { return n == 0 ? 0 : (v < (1 << (n - 1)) ? v - (1 << n) + 1 : v); }
+  int decode(const Table& t)
+  {
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 16; ++len) {
+      code |= bit();
+      const int count = t.count[len];
+      if (code - count < first) return t.symbol[index + (code - first)];
+      index += count;
+      first = (first + count) << 1;
+      code <<= 1;
+    }
+    throw std::runtime_error("jpeg: bad Huffman code");
+  }
+  void restart()
+  {
+    m_nbits = 0;
+    m_hit_marker = false;
+    // skip to the RSTn marker
+    while (m_pos + 1 < m_f.size() && !(m_f[m_pos] == 0xff && m_f[m_pos + 1] >= 0xd0 && m_f[m_pos + 1] <= 0xd7)) ++m_pos;
+    if (m_pos + 1 < m_f.size()) m_pos += 2;
+    for (Component& c : m_comp) c.pred = 0;
+  }
+
+  static void idct(const int* in, uint8_t* out, int stride)  // in: dequantised coefficients, natural order
+  {
+    constexpr int CB = 13, P1 = 2;
+    constexpr int F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137, F1961 = 16069, F2053 = 16819,
+                  F2562 = 20995, F3072 = 25172;
+    int ws[64];
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i = 0; i < 8; ++i) {
+        const int* s = pass == 0 ? in + i : ws + 8 * i;
+        const int st = pass == 0 ? 8 : 1;
+        const long d0 = s[0], d1 = s[st], d2 = s[2 * st], d3 = s[3 * st], d4 = s[4 * st], d5 = s[5 * st], d6 = s[6 * st], d7 = s[7 * st];
+        long z1 = (d2 + d6) * F0541;
+        const long t2 = z1 + d6 * (-F1847), t3 = z1 + d2 * F0765;
+        const long t0 = (d0 + d4) << CB, t1 = (d0 - d4) << CB;
+        const long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+        long a0 = d7, a1 = d5, a2 = d3, a3 = d1;
+        z1 = a0 + a3;
+        long z2 = a1 + a2, z3 = a0 + a2, z4 = a1 + a3;
+        const long z5 = (z3 + z4) * F1175;
+        a0 *= F0298; a1 *= F2053; a2 *= F3072; a3 *= F1501;
+        z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+        z3 += z5; z4 += z5;
+        a0 += z1 + z3; a1 += z2 + z4; a2 += z2 + z3; a3 += z1 + z4;
+        const int sh = pass == 0 ? CB - P1 : CB + P1 + 3;
+        const long rnd = 1L << (sh - 1);
+        const long o[8] = {t10 + a3, t11 + a2, t12 + a1, t13 + a0, t13 - a0, t12 - a1, t11 - a2, t10 - a3};
+        for (int k = 0; k < 8; ++k) {
+          const long v = (o[k] + rnd) >> sh;
+          if (pass == 0) ws[8 * k + i] = int(v);
+          else { const long px = v + 128; out[i * stride + k] = uint8_t(px < 0 ? 0 : (px > 255 ? 255 : px)); }
+        }
+      }
+    }
+  }
+
+  void scan()
+  {
+    const size_t len = seg_length();
+    const uint8_t* d = &m_f[m_pos + 2];
+    if (m_comp.empty()) throw std::runtime_error("jpeg: scan before frame");
+    const int ns = d[0];
+    if (ns != int(m_comp.size()) || len < size_t(6 + 2 * ns)) throw std::runtime_error("jpeg: non-interleaved scans are not supported");
+    for (int i = 0; i < ns; ++i) {
+      Component* c = nullptr;
+      for (Component& cc : m_comp) if (cc.id == d[1 + 2 * i]) c = &cc;
+      if (!c) throw std::runtime_error("jpeg: bad scan component");
+      c->td = d[2 + 2 * i] >> 4; c->ta = d[2 + 2 * i] & 15;
+      if (c->td > 3 || c->ta > 3 || !m_dc[c->td].set || !m_ac[c->ta].set || !m_q_set[c->tq]) throw std::runtime_error("jpeg: missing table");
+    }
+    m_pos += len;
+    static const uint8_t zz[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    const int mcu_w = 8 * m_hmax, mcu_h = 8 * m_vmax;
+    const int mx = (m_width + mcu_w - 1) / mcu_w, my = (m_height + mcu_h - 1) / mcu_h;
+    for (Component& c : m_comp) {
+      c.bw = mx * c.h * 8; c.bh = my * c.v * 8;
+      c.plane.assign(size_t(c.bw) * size_t(c.bh), 0);
+      c.pred = 0;
+    }
+    int count = 0;
+    for (int y = 0; y < my; ++y)
+      for (int x = 0; x < mx; ++x) {
+        if (m_restart && count && count % m_restart == 0) restart();
+        ++count;
+        for (Component& c : m_comp)
+          for (int by = 0; by < c.v; ++by)
+            for (int bx = 0; bx < c.h; ++bx) {
+              int coef[64] = {0};
+              const int t = decode(m_dc[c.td]);
+              if (t > 11) throw std::runtime_error("jpeg: bad DC size");
+              c.pred += extend(receive(t), t);
+              coef[0] = c.pred * m_q[c.tq][0];
+              for (int k = 1; k < 64;) {
+                const int rs = decode(m_ac[c.ta]);
+                const int r = rs >> 4, sz = rs & 15;
+                if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                k += r;
+                if (k > 63) throw std::runtime_error("jpeg: bad AC run");
+                coef[zz[k]] = extend(receive(sz), sz) * m_q[c.tq][zz[k]];
+                ++k;
+              }
+              idct(coef, &c.plane[size_t((y * c.v + by) * 8) * size_t(c.bw) + size_t((x * c.h + bx) * 8)], c.bw);
+            }
+      }
+  }
+
+  // full-resolution plane of a component (triangle-filter upsampling)
+  std::vector<uint8_t> upsampled(const Component& c) const
+  {
+    const int fx = m_hmax / c.h, fy = m_vmax / c.v;
+    const int W = c.bw * fx, H = c.bh * fy;
+    if (fx == 1 && fy == 1) return c.plane;
+    std::vector<uint8_t> out(size_t(W) * size_t(H));
+    auto at = [&](int x, int y) { x = x < 0 ? 0 : (x >= c.bw ? c.bw - 1 : x); y = y < 0 ? 0 : (y >= c.bh ? c.bh - 1 : y); return int(c.plane[size_t(y) * size_t(c.bw) + size_t(x)]); };
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        int v;
+        if (fx == 2 && fy == 1) {
+          const int sx = x >> 1;
+          v = (x & 1) ? (3 * at(sx, y) + at(sx + 1, y) + 2) >> 2 : (3 * at(sx, y) + at(sx - 1, y) + 1) >> 2;
+        } else if (fx == 1 && fy == 2) {
+          const int sy = y >> 1;
+          v = (y & 1) ? (3 * at(x, sy) + at(x, sy + 1) + 2) >> 2 : (3 * at(x, sy) + at(x, sy - 1) + 1) >> 2;
+        } else {
+          const int sx = x >> 1, sy = y >> 1, oy = (y & 1) ? sy + 1 : sy - 1, ox = (x & 1) ? sx + 1 : sx - 1;
+          const int near_col = 3 * at(sx, sy) + at(sx, oy), far_col = 3 * at(ox, sy) + at(ox, oy);
+          v = (3 * near_col + far_col + ((x & 1) ? 7 : 8)) >> 4;
+        }
+        out[size_t(y) * size_t(W) + size_t(x)] = uint8_t(v);
+      }
+    return out;
+  }
+
+  Image8 finish() const
+  {
+    Image8 img;
+    img.width = m_width; img.height = m_height;
+    img.rgba.resize(size_t(m_width) * size_t(m_height) * 4);
+    if (m_comp.size() == 1) {
+      const Component& c = m_comp[0];
+      for (int y = 0; y < m_height; ++y)
+        for (int x = 0; x < m_width; ++x) {
+          uint8_t* o = &img.rgba[(size_t(y) * size_t(m_width) + size_t(x)) * 4];
+          o[0] = o[1] = o[2] = c.plane[size_t(y) * size_t(c.bw) + size_t(x)];
+          o[3] = 255;
+        }
+      return img;
+    }
+    const std::vector<uint8_t> p0 = upsampled(m_comp[0]), p1 = upsampled(m_comp[1]), p2 = upsampled(m_comp[2]);
+    const int W = m_comp[0].bw * (m_hmax / m_comp[0].h);
+    const bool ycc = m_adobe ? m_adobe_transform != 0 : true;
+    auto clamp8 = [](int v) { return uint8_t(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+    for (int y = 0; y < m_height; ++y)
+      for (int x = 0; x < m_width; ++x) {
+        const size_t i = size_t(y) * size_t(W) + size_t(x);
+        uint8_t* o = &img.rgba[(size_t(y) * size_t(m_width) + size_t(x)) * 4];
+        if (ycc) {
+          const int Y = p0[i], cb = int(p1[i]) - 128, cr = int(p2[i]) - 128;
+          o[0] = clamp8(Y + ((91881 * cr + 32768) >> 16));
+          o[1] = clamp8(Y + ((-22554 * cb - 46802 * cr + 32768) >> 16));
+          o[2] = clamp8(Y + ((116130 * cb + 32768) >> 16));
+        } else { o[0] = p0[i]; o[1] = p1[i]; o[2] = p2[i]; }
+        o[3] = 255;
+      }
+    return img;
+  }
+};
+
+inline Image8 decode_jpeg(const std::vector<uint8_t>& file) { return JpegDecoder(file).run(); }
+
 // stbi_load(path, ..., STBI_rgb_alpha); flip = stbi_set_flip_vertically_on_load
 inline Image8 load_rgba8(const std::filesystem::path& path, bool flip_vertically)
 {
@@ -342,7 +657,8 @@ inline Image8 load_rgba8(const std::filesystem::path& path, bool flip_vertically
   Image8 img;
   if (file.size() >= 8 && file[0] == 0x89 && file[1] == 'P') img = decode_png(file);
   else if (file.size() >= 2 && file[0] == 'P' && (file[1] == '5' || file[1] == '6')) img = decode_pnm(file);
-  else throw std::runtime_error("failed to load " + path.generic_string() + ": only PNG and binary PPM/PGM images are supported in this build");
+  else if (file.size() >= 2 && file[0] == 0xff && file[1] == 0xd8) img = decode_jpeg(file);
+  else throw std::runtime_error("failed to load " + path.generic_string() + ": only PNG, baseline JPEG and binary PPM/PGM images are supported in this build");
   if (flip_vertically) {
     const size_t rb = (size_t)img.width * 4;
     std::vector<uint8_t> tmp(rb);

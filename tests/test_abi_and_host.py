@@ -287,6 +287,41 @@ def test_png_decoders_agree_on_every_filter_and_colour_type(tmp_path, image_dump
     assert n == 20
 
 
+def test_jpeg_decoders_agree_and_reconstruct(tmp_path, image_dump):
+    """baseline JPEG: the C++ reader (include/fredholm/image_io.h) and the Python reader decode to identical bytes for every chroma
+    sampling and with restart markers, and both are within quantisation error of the source"""
+    from fredholm_amd import image_io as I
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:45, 0:70]
+    smooth = np.stack([80 + 1.5 * xx + 0.5 * yy, 200 - 2.0 * yy + 0.3 * xx, 60 + 1.2 * (xx + yy)], axis=-1)
+    smooth = np.clip(smooth + rng.normal(0, 2.0, smooth.shape), 0, 255).astype(np.uint8)
+    for sub in ((1, 1), (2, 1), (1, 2), (2, 2)):
+        for ri in (0, 2):
+            f = tmp_path / f"s{sub[0]}{sub[1]}_{ri}.jpg"
+            I.write_jpeg(f, smooth, quality=95, subsampling=sub, restart_interval=ri)
+            py, cpp = I.load_rgba8(f, False), image_dump("rgba8", f)
+            assert np.array_equal(py, cpp), (sub, ri)
+            assert py.shape == (45, 70, 4) and (py[..., 3] == 255).all()
+            err = np.abs(py[..., :3].astype(np.int32) - smooth.astype(np.int32))
+            assert err.mean() < 2.5 and err.max() <= 14, (sub, ri, err.mean(), err.max())
+            assert np.array_equal(I.load_rgba8(f), py[::-1]) and np.array_equal(image_dump("rgba8_flip", f), py[::-1])
+    g = tmp_path / "grey.jpg"
+    I.write_jpeg(g, smooth[..., 0], quality=90)
+    py, cpp = I.load_rgba8(g, False), image_dump("rgba8", g)
+    assert np.array_equal(py, cpp) and (py[..., 0] == py[..., 1]).all() and np.abs(py[..., 0].astype(int) - smooth[..., 0]).max() <= 12
+    # a flat block decodes exactly: DC only, no rounding anywhere in the integer IDCT
+    flat = np.full((16, 16, 3), (120, 120, 120), np.uint8)
+    I.write_jpeg(tmp_path / "flat.jpg", flat, quality=100)
+    assert np.abs(I.load_rgba8(tmp_path / "flat.jpg", False)[..., :3].astype(int) - 120).max() <= 1
+    # progressive frames are rejected by both, not mis-decoded
+    data = bytearray((tmp_path / "s11_0.jpg").read_bytes())
+    data[data.index(b"\xff\xc0") + 1] = 0xC2
+    (tmp_path / "prog.jpg").write_bytes(bytes(data))
+    for loader in (lambda: I.load_rgba8(tmp_path / "prog.jpg"), lambda: image_dump("rgba8", tmp_path / "prog.jpg")):
+        with pytest.raises(ValueError, match="progressive"):
+            loader()
+
+
 def test_png_writer_round_trip(tmp_path, image_dump):
     """include/fredholm/image_io.h: write_png_rgba8 (stored deflate blocks) is read back by zlib and by the C++ reader"""
     import zlib
