@@ -3,8 +3,10 @@
 // Mirrors the host duties of fredholm::Renderer (fredholm/include/fredholm/renderer.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
+#include "../../include/fredholm/image_io.h"
 #include "context.h"
 #include "fh_bsdf.h"
 #include "fh_trace.h"
@@ -591,6 +593,22 @@ int fh_copy_to_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes)
   FH_HIP(hipStreamSynchronize(ctx->stream));
   return FH_OK;
 }
+int fh_image_load_rgba8(const char* path, int flip_vertically, uint32_t* width, uint32_t* height, uint8_t** rgba8)
+{
+  if (!path || !width || !height || !rgba8) { g_create_error = "fh_image_load_rgba8: null argument"; return FH_E_INVALID; }
+  try {
+    const fredholm::image_io::Image8 img = fredholm::image_io::load_rgba8(path, flip_vertically != 0);
+    uint8_t* out = (uint8_t*)std::malloc(img.rgba.size() ? img.rgba.size() : 1);
+    if (!out) { g_create_error = "fh_image_load_rgba8: out of memory"; return FH_E_INVALID; }
+    std::memcpy(out, img.rgba.data(), img.rgba.size());
+    *width = (uint32_t)img.width; *height = (uint32_t)img.height; *rgba8 = out;
+    return FH_OK;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    return FH_E_INVALID;
+  }
+}
+void fh_image_free(uint8_t* rgba8) { std::free(rgba8); }
 int fh_copy_on_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes)
 {
   CTX_CHECK(ctx);

@@ -141,8 +141,38 @@ def decode_pnm(data):
     return img
 
 
+def load_rgba8_native(path, flip_vertically=True):
+    """the same image through the library's host-side decoder (fh_image_load_rgba8: include/fredholm/image_io.h compiled into
+    libfredholm_hip.so) -- what the scene loaders use, since a pure-Python Huffman decoder is slow on real textures"""
+    import ctypes as C
+    from . import native as N
+    L = N.lib()
+    w, h, ptr = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+    L.fh_image_load_rgba8.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8))]
+    L.fh_image_free.argtypes = [C.POINTER(C.c_uint8)]
+    L.fh_image_free.restype = None
+    rc = L.fh_image_load_rgba8(str(path).encode(), int(bool(flip_vertically)), C.byref(w), C.byref(h), C.byref(ptr))
+    if rc != 0:
+        msg = L.fh_last_error(None)
+        raise ValueError(msg.decode() if msg else f"failed to load {path}")
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(h.value, w.value, 4)).copy()
+    finally:
+        L.fh_image_free(ptr)
+
+
+def load_texture(path, flip_vertically=True):
+    """what the scene loaders call: the library's decoder when the library can be loaded, the pure-Python one otherwise (same bytes)"""
+    try:
+        from . import native as N
+        N.lib()
+    except Exception:
+        return load_rgba8(path, flip_vertically)
+    return load_rgba8_native(path, flip_vertically)
+
+
 def load_rgba8(path, flip_vertically=True):
-    """stbi_load(path, ..., STBI_rgb_alpha) with stbi_set_flip_vertically_on_load(flip) (scene.cpp:15-16)."""
+    """stbi_load(path, ..., STBI_rgb_alpha) with stbi_set_flip_vertically_on_load(flip) (scene.cpp:15-16); pure Python."""
     data = _read(path)
     if data[:2] == b"\x89P": img = decode_png(data)
     elif data[:2] in (b"P5", b"P6"): img = decode_pnm(data)

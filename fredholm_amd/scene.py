@@ -236,7 +236,7 @@ class Scene:
         self.m_materials = np.concatenate([self.m_materials, mats])
         for texture in model.get("textures", []):
             image = model["images"][texture["source"]]
-            self.m_textures.append({"rgba8": image_io.load_rgba8(os.path.join(folder, image["uri"]), flip_vertically=True), "srgb": False})
+            self.m_textures.append({"rgba8": image_io.load_texture(os.path.join(folder, image["uri"]), flip_vertically=True), "srgb": False})
 
         def load_node(node_idx):
             node = model["nodes"][node_idx]

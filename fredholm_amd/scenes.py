@@ -244,7 +244,7 @@ def load_obj(path):
                 name = t[-1]
                 if name not in tex_index:
                     tex_index[name] = len(textures)
-                    textures.append({"rgba8": image_io.load_rgba8(os.path.join(os.path.dirname(p), name), flip_vertically=True), "srgb": srgb})
+                    textures.append({"rgba8": image_io.load_texture(os.path.join(os.path.dirname(p), name), flip_vertically=True), "srgb": srgb})
                 m[field] = tex_index[name]
             elif t[0].startswith("map_"):
                 raise ValueError(f"{t[0]} is not a texture slot of the reference's .mtl mapping ({p})")

@@ -176,6 +176,12 @@ int fh_free(fh_ctx* ctx, void* ptr);
 int fh_memset(fh_ctx* ctx, void* ptr, int value, uint64_t bytes);
 int fh_copy_to_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int fh_copy_to_host(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+/* host-side image decoding for front ends without a decoder of their own (PNG, baseline JPEG, binary PPM/PGM through
+ * include/fredholm/image_io.h; stb_image's role in fredholm/src/scene.cpp:7-37).  No context and no GPU needed.  *rgba8 holds
+ * width*height*4 bytes, row 0 first (after the optional vertical flip), and is released with fh_image_free.  Returns FH_OK or
+ * FH_E_INVALID; the message is available from fh_last_error(NULL). */
+int fh_image_load_rgba8(const char* path, int flip_vertically, uint32_t* width, uint32_t* height, uint8_t** rgba8);
+void fh_image_free(uint8_t* rgba8);
 int fh_copy_on_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes); /* asynchronous, ordered on the context stream (cwl::CUDABuffer device-to-device copies) */
 void* fh_stream(fh_ctx* ctx); /* hipStream_t of the context */
 

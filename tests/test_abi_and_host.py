@@ -501,3 +501,22 @@ def test_gltf_loader_rejects_what_the_reference_rejects(tmp_path, scene_dump):
     for loader in (lambda: Scene().load_model(str(tmp_path / "c.gltf")), lambda: scene_dump(tmp_path / "x.bin", -1, tmp_path / "c.gltf")):
         with pytest.raises(ValueError, match="invalid target node"):
             loader()
+
+
+def test_native_image_loader_matches_the_python_readers(tmp_path):
+    """fh_image_load_rgba8 (host-side entry point of the C ABI, no GPU needed) against fredholm_amd/image_io.py"""
+    from fredholm_amd import image_io as I
+    rng = np.random.default_rng(31)
+    img = rng.integers(0, 256, (23, 31, 4), dtype=np.uint8)
+    I.write_png(tmp_path / "a.png", img, 4)
+    I.write_jpeg(tmp_path / "a.jpg", img[..., :3], quality=85, subsampling=(2, 2), restart_interval=1)
+    (tmp_path / "a.ppm").write_bytes(b"P6\n31 23\n255\n" + img[..., :3].tobytes())
+    for name in ("a.png", "a.jpg", "a.ppm"):
+        for flip in (False, True):
+            assert np.array_equal(I.load_rgba8_native(tmp_path / name, flip), I.load_rgba8(tmp_path / name, flip)), (name, flip)
+            assert np.array_equal(I.load_texture(tmp_path / name, flip), I.load_rgba8(tmp_path / name, flip))
+    with pytest.raises(ValueError, match="failed to load"):
+        I.load_rgba8_native(tmp_path / "missing.png")
+    (tmp_path / "bad.bin").write_bytes(b"not an image")
+    with pytest.raises(ValueError, match="only PNG"):
+        I.load_rgba8_native(tmp_path / "bad.bin")
