@@ -27,6 +27,8 @@
 // which reproduces the draw order of SURVEY.md appendix A without per-path sampler state.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1262,6 +1264,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const bool stream = coop && !(stream_env && stream_env[0] == '0');
   // 6 workgroups (24 waves) per CU: all resident at the kernels' LDS budget (26 KB each)
   uint32_t stream_grid = (uint32_t)prop.multiProcessorCount * 6u, stream_refill = 24u;
+  uint32_t env_tail_depth = 0;  // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail (developer switch)
+  if (const char* e = getenv("FH_TAIL_DEPTH")) env_tail_depth = (uint32_t)atoi(e);
   bool sort_queues = true;  // FH_SORT=0: trace the bounce queues in the order the shade kernels emit them
   if (const char* e = getenv("FH_SORT")) sort_queues = e[0] != '0';
   uint32_t stream_chunk = 64u;  // queue entries a wave takes per global atomic (64/128 equal on big launches, 64 better on small ones)
@@ -1298,12 +1302,26 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       if (!(ctx->counters_in_flight[k] && hipEventQuery(ctx->ev_counters[k]) == hipSuccess)) continue;
       ctx->counters_in_flight[k] = false;
       const uint32_t wd = ctx->counters_wave_depth[k];
-      uint32_t pick = wd + 1u;  // too many survivors at the old switch depth: go one bounce deeper
-      for (uint32_t d = 1; d <= wd; ++d)
-        if (ctx->h_counters[k][d * kCounterStride + CNT_RAD] <= kTailPaths) { pick = d; break; }
+      const uint32_t* hc = ctx->h_counters[k];
+      uint32_t pick = 0;
+      for (uint32_t d = 1; d <= wd && !pick; ++d)
+        if (hc[d * kCounterStride + CNT_RAD] <= kTailPaths) pick = d;
+      if (!pick) {
+        // too many survivors even at the old switch depth: extrapolate with the survival ratio of the last bounce.  (Snapshots only
+        // arrive when the host happens to be behind the GPU -- after a synchronisation -- so the depth has to be right in one step.)
+        const double last = (double)hc[wd * kCounterStride + CNT_RAD], prev = wd ? (double)hc[(wd - 1u) * kCounterStride + CNT_RAD] : 0.0;
+        uint32_t more = 1;
+        if (last > 0.0 && prev > last) {
+          const double steps = ceil(log((double)kTailPaths / last) / log(last / prev));
+          more = steps < 1.0 ? 1u : (steps > 16.0 ? 16u : (uint32_t)steps);
+        }
+        pick = wd + more;
+      }
       ctx->auto_wave_depth = pick;
+      if (getenv("FH_DEBUG_TAIL")) { fprintf(stderr, "[tail] slot %d wd %u pick %u survivors:", k, wd, pick); for (uint32_t d = 0; d <= wd; ++d) fprintf(stderr, " %u", ctx->h_counters[k][d * kCounterStride + CNT_RAD]); fprintf(stderr, "\n"); }
     }
     uint32_t wave_depth = ctx->tail_depth ? ctx->tail_depth : ctx->auto_wave_depth;
+    if (env_tail_depth) wave_depth = env_tail_depth;
     if (wave_depth < 1u) wave_depth = 1u;
     if (wave_depth > max_depth) wave_depth = max_depth;
     PoolDev pd = pool, ps = pool;  // per-bounce views: pd rotates the radiance queues through the sorted buffers, ps reads the sorted secondary queue
