@@ -174,19 +174,29 @@ def load_texture(path, flip_vertically=True):
 def load_rgba8(path, flip_vertically=True):
     """stbi_load(path, ..., STBI_rgb_alpha) with stbi_set_flip_vertically_on_load(flip) (scene.cpp:15-16); pure Python."""
     data = _read(path)
-    if data[:2] == b"\x89P": img = decode_png(data)
-    elif data[:2] in (b"P5", b"P6"): img = decode_pnm(data)
-    elif data[:2] == b"\xff\xd8":
-        try:
-            img = decode_jpeg(data)
-        except (IndexError, KeyError, StopIteration) as e:  # ran off the end of the file / a table or component that was never defined
-            raise ValueError(f"jpeg: truncated or inconsistent file {path}") from e
-    else: raise ValueError(f"failed to load {path}: only PNG, baseline JPEG and binary PPM/PGM images are supported in this build")
+    try:
+        if data[:2] == b"\x89P": img = decode_png(data)
+        elif data[:2] in (b"P5", b"P6"): img = decode_pnm(data)
+        elif data[:2] == b"\xff\xd8": img = decode_jpeg(data)
+        else: raise ValueError(f"failed to load {path}: only PNG, baseline JPEG and binary PPM/PGM images are supported in this build")
+    except ValueError:
+        raise
+    except Exception as e:  # ran off the end of a damaged file, undefined table, zlib error ...: one error type for callers
+        raise ValueError(f"failed to load {path}: damaged or truncated file ({type(e).__name__}: {e})") from e
     return np.ascontiguousarray(img[::-1] if flip_vertically else img)
 
 
 def load_hdr(path):
     """stbi_loadf(path, ..., STBI_rgb_alpha) without flip (scene.cpp:44-45): float32 [h, w, 4], alpha 1."""
+    try:
+        return _load_hdr(path)
+    except ValueError:
+        raise
+    except Exception as e:
+        raise ValueError(f"failed to load {path}: damaged or truncated file ({type(e).__name__}: {e})") from e
+
+
+def _load_hdr(path):
     data = _read(path)
     lines, pos = [], 0
 

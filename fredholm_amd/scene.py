@@ -181,6 +181,14 @@ class Scene:
     # ------------------------------------------------------------------ scene.cpp:445-860
     def load_gltf(self, filepath):
         try:
+            self._load_gltf(filepath)
+        except ValueError:
+            raise
+        except Exception as e:  # missing keys, indices outside their arrays, accessors outside their buffers ...
+            raise ValueError(f"failed to load {filepath}: inconsistent glTF ({type(e).__name__}: {e})") from e
+
+    def _load_gltf(self, filepath):
+        try:
             model = json.load(open(filepath, "r"))
         except (OSError, ValueError) as e:
             raise ValueError(f"failed to load {filepath}") from e

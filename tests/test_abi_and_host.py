@@ -223,9 +223,10 @@ def image_dump(tmp_path_factory):
     assert r.returncode == 0, r.stderr
 
     def run(mode, path):
-        p = subprocess.run([str(exe), mode, str(path)], capture_output=True)
-        if p.returncode != 0:
+        p = subprocess.run([str(exe), mode, str(path)], capture_output=True, timeout=120)
+        if p.returncode == 1:
             raise ValueError(p.stderr.decode())
+        assert p.returncode == 0, f"image_dump crashed on {path}: {p.returncode}"
         w, h = np.frombuffer(p.stdout[:8], dtype=np.int32)
         body = p.stdout[8:]
         return np.frombuffer(body, dtype=np.float32 if mode == "hdr" else np.uint8).reshape(h, w, 4)
@@ -394,9 +395,10 @@ def scene_dump(tmp_path_factory):
     assert r.returncode == 0, r.stderr
 
     def run(out, time, *files):
-        p = subprocess.run([str(exe), str(out), repr(float(time)), *[str(f) for f in files]], capture_output=True, text=True)
-        if p.returncode != 0:
+        p = subprocess.run([str(exe), str(out), repr(float(time)), *[str(f) for f in files]], capture_output=True, text=True, timeout=120)
+        if p.returncode == 1:
             raise ValueError(p.stderr)
+        assert p.returncode == 0, f"scene_dump crashed on {files}: {p.returncode}"
         data = open(out, "rb").read()
         chunks, pos = [], 0
         while pos < len(data):
@@ -520,3 +522,52 @@ def test_native_image_loader_matches_the_python_readers(tmp_path):
     (tmp_path / "bad.bin").write_bytes(b"not an image")
     with pytest.raises(ValueError, match="only PNG"):
         I.load_rgba8_native(tmp_path / "bad.bin")
+
+
+def test_damaged_files_raise_errors_never_crash(tmp_path, image_dump, scene_dump):
+    """truncations and byte flips of valid PNG / JPEG / HDR / glTF files: both front ends answer with an error (or a decoded image),
+    never with a crash, a hang or an exception type of their own"""
+    from fredholm_amd import image_io as I
+    from fredholm_amd.scene import Scene
+    rng = np.random.default_rng(41)
+    img = rng.integers(0, 256, (19, 27, 3), dtype=np.uint8)
+    I.write_png(tmp_path / "a.png", img, 4)
+    I.write_jpeg(tmp_path / "a.jpg", img, quality=80, subsampling=(2, 2), restart_interval=2)
+    I.write_hdr(tmp_path / "a.hdr", img.astype(np.float32) / 32.0, rle=True)
+    scenes.animated_cornell_gltf(str(tmp_path / "a.gltf"), embed=True, textured=False)
+
+    def mutations(data, n):
+        for _ in range(n):
+            d = bytearray(data)
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                d = d[: int(rng.integers(1, len(d)))]
+            else:
+                for _ in range(int(rng.integers(1, 6))):
+                    d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+            yield bytes(d)
+    outcomes = {"ok": 0, "error": 0}
+    for name, mode in (("a.png", "rgba8"), ("a.jpg", "rgba8"), ("a.hdr", "hdr")):
+        data = (tmp_path / name).read_bytes()
+        for k, d in enumerate(mutations(data, 40)):
+            f = tmp_path / f"m{k}_{name}"
+            f.write_bytes(d)
+            for loader in ((lambda: I.load_hdr(f)) if mode == "hdr" else (lambda: I.load_rgba8(f)), lambda: image_dump(mode, f)):
+                try:
+                    loader()
+                    outcomes["ok"] += 1
+                except ValueError:
+                    outcomes["error"] += 1
+            p = subprocess.run([image_dump.exe, mode, str(f)], capture_output=True, timeout=60)
+            assert p.returncode in (0, 1), (name, k, p.returncode)  # 1 = reported error; anything else = crash
+    text = (tmp_path / "a.gltf").read_bytes()
+    for k, d in enumerate(mutations(text, 40)):
+        f = tmp_path / f"m{k}.gltf"
+        f.write_bytes(d)
+        for loader in (lambda: Scene().load_model(str(f)), lambda: scene_dump(tmp_path / "x.bin", -1, f)):
+            try:
+                loader()
+                outcomes["ok"] += 1
+            except ValueError:
+                outcomes["error"] += 1
+    assert outcomes["error"] > 100 and outcomes["ok"] > 10
