@@ -132,8 +132,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
       } else {
         const f3 r = alive ? mk3(0.0f) + mk3(1.0f) * env_radiance(fr, dir) : mk3(0.0f);
         pool.rad[p] = mk4(r, 0.0f);
-        pool.flags[p] = 2u;  // finished: k_miss_primary must not touch it
-        pool.hit[p] = make_float4(1e9f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
+        pool.flags[p] = 2u;  // finished here and in no queue: only k_accumulate reads the slot again (radiance and flags)
       }
     }
     queue_push(&pool.counters[CNT_RAD], pool.q_rad[0], enter, p);
