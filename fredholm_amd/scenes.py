@@ -395,7 +395,7 @@ def gradient_ibl(w=64, h=32):
     return img
 
 
-def write_gltf(scene, path, submeshes, nodes, roots, animations=(), cameras=0, embed=False):
+def write_gltf(scene, path, submeshes, nodes, roots, animations=(), cameras=0, embed=False, image_format="png"):
     """Write a flat scene as glTF 2.0 the way the reference's loader wants it (scene.cpp:692-741: 16-bit indices, float3
     POSITION / NORMAL, float2 TEXCOORD_0, one buffer).  For tests and tools.
       submeshes: list of face-index arrays, one glTF mesh each; a mesh gets one primitive per material it uses
@@ -452,8 +452,13 @@ def write_gltf(scene, path, submeshes, nodes, roots, animations=(), cameras=0, e
     textures = scene.get("textures") or []
     images = []
     for k, tex in enumerate(textures):
-        image_io.write_png(f"{base}_img{k}.png", np.asarray(tex["rgba8"])[::-1], filter_type=(k + 1) % 5)
-        images.append({"uri": f"{os.path.basename(base)}_img{k}.png"})
+        top_first = np.asarray(tex["rgba8"])[::-1]
+        if image_format == "jpg" and k % 2 == 0:  # every other texture as baseline JPEG (lossy: the loader sees what the file decodes to)
+            image_io.write_jpeg(f"{base}_img{k}.jpg", top_first[..., :3], quality=90, subsampling=((1, 1), (2, 2), (2, 1))[k // 2 % 3], restart_interval=k % 4)
+            images.append({"uri": f"{os.path.basename(base)}_img{k}.jpg"})
+        else:
+            image_io.write_png(f"{base}_img{k}.png", top_first, filter_type=(k + 1) % 5)
+            images.append({"uri": f"{os.path.basename(base)}_img{k}.png"})
     mats = []
     for m in scene["materials"]:
         pmr = {"baseColorFactor": [float(x) for x in m["base_color"]] + [1.0], "roughnessFactor": float(m["specular_roughness"]), "metallicFactor": float(m["metalness"])}
@@ -478,7 +483,7 @@ def write_gltf(scene, path, submeshes, nodes, roots, animations=(), cameras=0, e
     json.dump(doc, open(path, "w"), indent=1)
 
 
-def animated_cornell_gltf(path, embed=False, textured=True):
+def animated_cornell_gltf(path, embed=False, textured=True, image_format="png"):
     """Test asset: the Cornell box as a glTF scene graph -- room (root), a key-framed root node carrying the short block with the
     tall block as its child (so the child inherits the animation), a static scaled/rotated node, and a camera node."""
     sc = textured_cornell_box() if textured else cornell_box()
@@ -503,5 +508,5 @@ def animated_cornell_gltf(path, embed=False, textured=True):
     animations = [[(1, "translation", [0.0, 0.5, 1.5, 2.0], [[0.1, 0.0, 0.05], [0.2, 0.05, 0.0], [0.0, 0.1, 0.1], [0.1, 0.0, 0.05]]),
                    (1, "rotation", [0.0, 1.0, 2.0], [[0, 0, 0, 1], [0, float(h), 0, float(h)], [0, 1, 0, 0]]),
                    (1, "scale", [0.0, 2.0], [[1, 1, 1], [0.8, 1.2, 0.8]])]]
-    write_gltf(sc, path, submeshes, nodes, roots, animations, cameras=1, embed=embed)
+    write_gltf(sc, path, submeshes, nodes, roots, animations, cameras=1, embed=embed, image_format=image_format)
     return sc

@@ -423,7 +423,7 @@ def _scene_chunks(S):
 def test_gltf_scene_graph_and_animation_match_between_cpp_and_python(tmp_path, scene_dump, embed):
     from fredholm_amd.scene import Scene
     gltf = tmp_path / "anim.gltf"
-    scenes.animated_cornell_gltf(str(gltf), embed=embed)
+    scenes.animated_cornell_gltf(str(gltf), embed=embed, image_format="jpg" if embed else "png")  # (JPEG and PNG textures)
     names = ["vertices", "normals", "texcoords", "indices", "material_ids", "instance_ids", "materials", "o2w", "w2o", "camera", "submesh_offsets", "submesh_n_faces", "texture headers"]
     for time in (-1.0, 0.0, 0.3, 0.75, 1.0, 1.9, 2.6, 7.25):
         S = Scene()

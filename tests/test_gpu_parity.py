@@ -700,7 +700,7 @@ def test_animated_gltf_batch_driver_matches_python_path_and_checker(tmp_path, or
            "-Wl,-rpath," + os.path.join(root, "fredholm_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", str(exe)]
     assert subprocess.run(cmd).returncode == 0
     gltf = str(tmp_path / "anim.gltf")
-    scenes.animated_cornell_gltf(gltf)
+    scenes.animated_cornell_gltf(gltf, image_format="jpg")  # half of the textures as baseline JPEG files, the rest PNG
     w, h, spp, depth, fps, n_frames = 80, 60, 3, 4, 2.0, 4
     out = tmp_path / "frames"
     run = subprocess.run([str(exe), "--scene", gltf, "--out", str(out), "--width", str(w), "--height", str(h), "--spp", str(spp), "--depth", str(depth), "--fps", str(fps),
