@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per step: one fh_render call = one presented frame of BASELINE configs[2] (1080p, 1024 spp)")
-    ap.add_argument("--pool-spp", type=int, default=0, help="samples per pixel per pass of the path pool; 0 = half a step per pass (two passes in flight overlap), at most 64 spp of the full frame (132.7 M paths, 49 GB per pool)")
+    ap.add_argument("--pool-spp", type=int, default=0, help="samples per pixel per pass of the path pool; 0 = equal passes of at most ~64 spp of the full frame, at least two per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-frame", action="store_true", help="N > 1: rank 0 re-renders the whole frame unsharded and compares it bit for bit with the gathered one")
     args = ap.parse_args()
@@ -106,10 +106,17 @@ def main():
     r.set_resolution(WIDTH, HEIGHT)
     if world > 1:
         r.set_tile_shard(rank, world, 32, 32)
-    # path-pool slots = owned pixels x samples per pass (372 B per slot, two pools): by default a step is at least two passes, so
-    # that the library's two-passes-in-flight pipelining has something to overlap inside a step
-    pool_spp = args.pool_spp if args.pool_spp > 0 else max(args.spp // 2, 1)
-    r.set_path_pool(min(r.owned_pixel_count() * pool_spp, WIDTH * HEIGHT * 64))
+    # path-pool slots = owned pixels x samples per pass (384 B per slot, two pools).  By default a step is split into equal passes of
+    # at most ~64 spp of the full frame (135 M paths, 52 GB per pool), and into at least two, so that the library's
+    # two-passes-in-flight pipelining has something to overlap inside a step
+    n_owned_now = r.owned_pixel_count()
+    if args.pool_spp > 0:
+        pool_spp = args.pool_spp
+    else:
+        cap = int(WIDTH * HEIGHT * 64 * 1.02)  # 2 % slack: tile ownership is not perfectly even across ranks
+        passes = max(2, -(-n_owned_now * args.spp // cap))
+        pool_spp = max(-(-args.spp // passes), 1)
+    r.set_path_pool(n_owned_now * pool_spp)
     cam = F.Camera(**scenes.SOUP_CAMERA)
     dev = torch.device("cuda", local_rank)
     bufs = {n: torch.zeros((HEIGHT, WIDTH) if n == "depth" else (HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev) for n in F.RenderLayer.NAMES}
