@@ -238,15 +238,16 @@ int fh_ctx_create(int device, fh_ctx** out)
   (void)hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
   (void)hipMemset(ctx->d_trace_counters, 0, 26 * sizeof(unsigned long long));
-  if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 2; ++k)
+    if (hipStreamCreateWithFlags(&ctx->aux_stream[k], hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+  for (int k = 0; k < 3; ++k) {
     (void)hipHostMalloc((void**)&ctx->h_counters[k], sizeof(uint32_t) * fh::kCounterStride * 66);
     (void)hipEventCreate(&ctx->ev_counters[k]);
     (void)hipEventCreateWithFlags(&ctx->ev_gen[k], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ctx->ev_acc[k], hipEventDisableTiming);
   }
   (void)hipEventCreateWithFlags(&ctx->ev_enter, hipEventDisableTiming);
-  if (const char* e = getenv("FH_PIPELINE")) ctx->pipeline = e[0] != '0';
+  if (const char* e = getenv("FH_PIPELINE")) ctx->n_slots = e[0] == '0' ? 1 : (e[0] == '3' ? 3 : 2);
   (void)hipEventCreate(&ctx->ev_render_begin);
   (void)hipEventCreate(&ctx->ev_render_end);
   *out = ctx;
@@ -258,7 +259,6 @@ int fh_ctx_destroy(fh_ctx* ctx)
   if (!ctx) return FH_E_INVALID;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipStreamSynchronize(ctx->stream2);
   pool_release(ctx);
   void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
                   ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl};
@@ -266,14 +266,14 @@ int fh_ctx_destroy(fh_ctx* ctx)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     if (ctx->h_counters[k]) (void)hipHostFree(ctx->h_counters[k]);
     (void)hipEventDestroy(ctx->ev_counters[k]);
     (void)hipEventDestroy(ctx->ev_gen[k]);
     (void)hipEventDestroy(ctx->ev_acc[k]);
   }
   (void)hipEventDestroy(ctx->ev_enter);
-  (void)hipStreamDestroy(ctx->stream2);
+  for (int k = 0; k < 2; ++k) (void)hipStreamDestroy(ctx->aux_stream[k]);
   (void)hipEventDestroy(ctx->ev_render_begin);
   (void)hipEventDestroy(ctx->ev_render_end);
   (void)hipStreamDestroy(ctx->stream);

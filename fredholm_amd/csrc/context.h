@@ -13,7 +13,7 @@
 struct fh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;   // main stream: everything the caller can observe is ordered on it
-  hipStream_t stream2 = nullptr;  // odd passes of fh_render run here, overlapping the latency-bound end of the pass before
+  hipStream_t aux_stream[2] = {nullptr, nullptr};  // passes j % n_slots != 0 of fh_render run here, overlapping the latency-bound ends of the passes before
   std::string err;
   uint32_t flags = 0;
 
@@ -75,20 +75,20 @@ struct fh_ctx {
   bool has_hosek = false;
   fh::HosekSky hosek{};
 
-  // path pools: two, so that two passes can be in flight (pass j uses slot j % 2 and the stream of that slot)
-  fh::PoolDev pool[2] = {};
-  std::vector<void*> pool_allocs[2];
+  // path pools: one per pass in flight (pass j uses slot j % n_slots and the stream of that slot); allocated on first use
+  fh::PoolDev pool[3] = {};
+  std::vector<void*> pool_allocs[3];
   uint32_t pool_target = 1u << 25;  // 32 Mi path slots (12.5 GB): 16 samples per pixel per pass at 1080p
   uint32_t tail_depth = 0;          // bounces run as wavefront kernels before k_tail finishes the survivors; 0 = adaptive
   uint32_t auto_wave_depth = 2;     // adaptive choice, updated from the per-bounce survivor counts of earlier passes
-  uint32_t* h_counters[2] = {nullptr, nullptr};  // pinned snapshots of the per-bounce counters of a finished pass
-  hipEvent_t ev_counters[2] = {nullptr, nullptr};
-  bool counters_in_flight[2] = {false, false};
-  uint32_t counters_wave_depth[2] = {0, 0};  // wave depth used by the pass the snapshot comes from
+  uint32_t* h_counters[3] = {nullptr, nullptr, nullptr};  // pinned snapshots of the per-bounce counters of a finished pass
+  hipEvent_t ev_counters[3] = {nullptr, nullptr, nullptr};
+  bool counters_in_flight[3] = {false, false, false};
+  uint32_t counters_wave_depth[3] = {0, 0, 0};  // wave depth used by the pass the snapshot comes from
   unsigned long long pass_seq = 0;           // passes submitted so far
-  hipEvent_t ev_gen[2] = {nullptr, nullptr}, ev_acc[2] = {nullptr, nullptr}, ev_enter = nullptr;
-  bool gen_valid[2] = {false, false}, acc_valid[2] = {false, false};
-  bool pipeline = true;  // FH_PIPELINE=0: every pass on the main stream
+  hipEvent_t ev_gen[3] = {nullptr, nullptr, nullptr}, ev_acc[3] = {nullptr, nullptr, nullptr}, ev_enter = nullptr;
+  bool gen_valid[3] = {false, false, false}, acc_valid[3] = {false, false, false};
+  int n_slots = 2;  // passes in flight (FH_PIPELINE=0: 1, every pass on the main stream; =3: three)
 
   // stats
   fh_stats stats{};

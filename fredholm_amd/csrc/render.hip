@@ -1151,7 +1151,9 @@ SceneDev scene_dev(const fh_ctx* ctx)
 
 void pool_release(fh_ctx* ctx)
 {
-  for (int k = 0; k < 2; ++k) {
+  (void)hipStreamSynchronize(ctx->stream);  // nothing may still be running out of the buffers (the counter snapshots trail the accumulate)
+  for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(ctx->aux_stream[k]);
+  for (int k = 0; k < 3; ++k) {
     for (void* p : ctx->pool_allocs[k]) (void)hipFree(p);
     ctx->pool_allocs[k].clear();
     ctx->pool[k] = PoolDev{};
@@ -1164,7 +1166,7 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
   if (ctx->pool[slot].capacity >= capacity) return FH_OK;
   if (ctx->pool[slot].capacity) {  // growing: nothing may still be running out of the old buffers
     FH_HIP(hipStreamSynchronize(ctx->stream));
-    FH_HIP(hipStreamSynchronize(ctx->stream2));
+    for (int k = 0; k < 2; ++k) FH_HIP(hipStreamSynchronize(ctx->aux_stream[k]));
     for (void* p : ctx->pool_allocs[slot]) (void)hipFree(p);
     ctx->pool_allocs[slot].clear();
     ctx->pool[slot] = PoolDev{};
@@ -1247,8 +1249,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (!ctx->render_pending) { (void)hipEventRecord(ctx->ev_render_begin, ctx->stream); ctx->render_pending = true; }
   // whatever the caller queued on the main stream before this call (clears, uploads) comes first on the second stream too
   FH_HIP(hipEventRecord(ctx->ev_enter, ctx->stream));
-  FH_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_enter, 0));
-  bool used_stream2 = false;
+  for (int k = 0; k + 1 < ctx->n_slots; ++k) FH_HIP(hipStreamWaitEvent(ctx->aux_stream[k], ctx->ev_enter, 0));
+  int last_slot = 0;
 
   if (max_depth > 64) return fail(ctx, FH_E_INVALID, "fh_render: max_depth > 64 is not supported");
   hipDeviceProp_t prop;
@@ -1276,17 +1278,17 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
     const uint32_t n_paths = ctx->n_owned * nb;
     const uint32_t grid = grid_for(n_paths);
-    // two passes in flight: pass j lives in pool j % 2 on stream j % 2.  Only two things order consecutive passes: the sample
+    // n_slots passes in flight (two by default): pass j lives in pool j % n_slots on the stream of that slot.  Only two things order consecutive passes: the sample
     // indices (k_generate reads what k_bump_issued of the pass before wrote) and the running means (k_accumulate of pass j
     // follows k_accumulate of pass j - 1, so the floating-point result is that of a serial run)
-    const int slot = ctx->pipeline ? (int)(ctx->pass_seq & 1ull) : 0;
+    const int slot = (int)(ctx->pass_seq % (unsigned long long)ctx->n_slots), prev = (slot + ctx->n_slots - 1) % ctx->n_slots;
     ctx->pass_seq++;
-    hipStream_t st = slot ? ctx->stream2 : ctx->stream;
-    used_stream2 = used_stream2 || slot == 1;
+    hipStream_t st = slot ? ctx->aux_stream[slot - 1] : ctx->stream;
+    last_slot = slot;
     { const int rc = pool_ensure(ctx, slot, ctx->n_owned * batch); if (rc) return rc; }
     const PoolDev& pool = ctx->pool[slot];
     FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
-    if (ctx->gen_valid[slot ^ 1]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_gen[slot ^ 1], 0));
+    if (prev != slot && ctx->gen_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_gen[prev], 0));
     hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, n_paths);
     hipLaunchKernelGGL(k_bump_issued, dim3((ctx->n_owned + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, nb);
     FH_HIP(hipEventRecord(ctx->ev_gen[slot], st));
@@ -1297,7 +1299,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     // the device counters: no host/device synchronisation)
     uint32_t kTailPaths = 65536;
     if (const char* e = getenv("FH_TAIL_PATHS")) { const int v = atoi(e); if (v >= 64) kTailPaths = (uint32_t)v; }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
       if (!(ctx->counters_in_flight[k] && hipEventQuery(ctx->ev_counters[k]) == hipSuccess)) continue;
       ctx->counters_in_flight[k] = false;
       const uint32_t wd = ctx->counters_wave_depth[k];
@@ -1389,7 +1391,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       Span sp(ctx, st, 3);
       hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), 0, st, sc, fr, pd, wave_depth);
     }
-    if (ctx->acc_valid[slot ^ 1]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[slot ^ 1], 0));
+    if (prev != slot && ctx->acc_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[prev], 0));
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb);
     FH_HIP(hipEventRecord(ctx->ev_acc[slot], st));
     ctx->acc_valid[slot] = true;
@@ -1401,7 +1403,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     }
   }
   // join: later work on the main stream (pack, post-process, copies, the caller's clears) sees every pass of this call
-  if (used_stream2 && ctx->acc_valid[1]) FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_acc[1], 0));
+  // (the accumulates form a chain across the streams, so the last one implies all the others)
+  if (last_slot != 0) FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_acc[last_slot], 0));
   FH_HIP(hipGetLastError());
   return FH_OK;
 }
