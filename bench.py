@@ -190,10 +190,17 @@ def main():
         full = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
         others = {n: torch.zeros((HEIGHT, WIDTH) if n == "depth" else (HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev) for n in F.RenderLayer.NAMES}
         others["beauty"] = full
-        r2.render(cam, (0.0, 0.0, 0.0), F.RenderLayer(r2, WIDTH, HEIGHT, pointers={n: t.data_ptr() for n, t in others.items()}), total_spp, MAX_DEPTH)
+        layers2 = F.RenderLayer(r2, WIDTH, HEIGHT, pointers={n: t.data_ptr() for n, t in others.items()})
+        # 1. the frame assembled from every rank's tiles after the last timed step against an unsharded render of as many samples
+        r2.render(cam, (0.0, 0.0, 0.0), layers2, total_spp - args.spp, MAX_DEPTH)
         r2.wait_for_completion()
-        # gather once more so that `frame` holds the state after the counting replay as well
-        step_spp0 = None
+        whole = bool((full.reshape(-1, 4).view(torch.int32) == frame.view(torch.int32)).all().item())
+        print(f"check-frame: frame gathered from {world} ranks bit-identical to the unsharded render: {whole}", file=sys.stderr, flush=True)
+        if not whole:
+            raise SystemExit("gathered frame differs from the unsharded one")
+        # 2. this rank's tiles after the counting replay (one more step that only the local layers saw)
+        r2.render(cam, (0.0, 0.0, 0.0), layers2, args.spp, MAX_DEPTH)
+        r2.wait_for_completion()
         a = full.reshape(-1, 4).view(torch.int32)
         r.pack_owned(bufs["beauty"].data_ptr(), 4, packed.data_ptr())
         r.wait_for_completion()
