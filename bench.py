@@ -244,7 +244,7 @@ def main():
             "config": {"workload": "configs[2]: 1M random-triangle soup (PCG32 seed 0x853c49e6748fea9b), Hosek sky turbidity 3 albedo 0.3, 1920x1080, max_depth 8, seed 1",
                        "spp_per_step": args.spp, "triangles": N_TRIS, "parallelism": f"pixel-tile x{world}" if world > 1 else "single GPU",
                        "gather": "RCCL all_gather of packed float4 beauty tiles, inside the timed region" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": dom + "_stream", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "per_ray": {"nodes": round(nodes / max(rays, 1), 2), "triangles": round(tris / max(rays, 1), 2), "bytes": round(bytes_per_step / max(rays, 1), 1)},
                          "note": "rank 0 shard" if world > 1 else "whole frame"},
