@@ -342,6 +342,7 @@ int fh_scene_upload(fh_ctx* ctx, const fh_scene_desc* s)
   const int rc = rebuild_device_scene(ctx);
   if (rc) return rc;
   ctx->scene_loaded = true;
+  ctx->builder_choice = 0;  // new geometry: let the next build choose its builder again
   return FH_OK;
 }
 

@@ -56,6 +56,7 @@ struct fh_ctx {
   float4* d_bvh8_tris = nullptr;
   uint32_t bvh8_n_nodes = 0, bvh8_n_tris = 0;
   bool use_bvh8 = false;
+  int builder_choice = 0;  // 0 = not decided for this scene, 1 = radix tree (LBVH), 2 = PLOC; decided at the first build after an upload
   double bvh_build_ms = 0.0;
   float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};  // padded world bounds of the geometry
 

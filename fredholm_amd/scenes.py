@@ -510,3 +510,44 @@ def animated_cornell_gltf(path, embed=False, textured=True, image_format="png"):
                    (1, "scale", [0.0, 2.0], [[1, 1, 1], [0.8, 1.2, 0.8]])]]
     write_gltf(sc, path, submeshes, nodes, roots, animations, cameras=1, embed=embed, image_format=image_format)
     return sc
+
+
+def city(n_blocks=40000, seed=11):
+    """A non-uniform scene for builder comparisons: a ground plane of two huge triangles, `n_blocks` boxes of widely varying size on a
+    jittered grid (towers next to kerb stones), and a few hundred long thin triangles spanning the whole extent (cables).  Vectorised:
+    12 triangles per box."""
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(np.sqrt(n_blocks)))
+    gx, gz = np.meshgrid(np.arange(side), np.arange(side))
+    gx, gz = gx.reshape(-1)[:n_blocks].astype(np.float64), gz.reshape(-1)[:n_blocks].astype(np.float64)
+    cell = 2.0 / side
+    cx = -1.0 + (gx + 0.5 + rng.uniform(-0.3, 0.3, n_blocks)) * cell
+    cz = -1.0 + (gz + 0.5 + rng.uniform(-0.3, 0.3, n_blocks)) * cell
+    hx = cell * rng.uniform(0.05, 0.45, n_blocks)
+    hz = cell * rng.uniform(0.05, 0.45, n_blocks)
+    hy = cell * np.exp(rng.uniform(np.log(0.05), np.log(12.0), n_blocks))
+    ang = rng.uniform(0, np.pi, n_blocks)
+    c, s = np.cos(ang), np.sin(ang)
+    corners = np.array([[-1, -1, -1], [1, -1, -1], [1, -1, 1], [-1, -1, 1], [-1, 1, -1], [1, 1, -1], [1, 1, 1], [-1, 1, 1]], dtype=np.float64)
+    lx, ly, lz = corners[:, 0][None] * hx[:, None], (corners[:, 1][None] + 1.0) * hy[:, None], corners[:, 2][None] * hz[:, None]
+    P = np.stack([cx[:, None] + c[:, None] * lx + s[:, None] * lz, ly, cz[:, None] - s[:, None] * lx + c[:, None] * lz], axis=-1)  # [n, 8, 3]
+    quads = [(7, 6, 5, 4), (0, 1, 2, 3), (3, 2, 6, 7), (1, 0, 4, 5), (2, 1, 5, 6), (0, 3, 7, 4)]
+    tri_idx = np.array([[q[0], q[1], q[2], q[0], q[2], q[3]] for q in quads]).reshape(-1)
+    boxes = P[:, tri_idx].reshape(-1, 3)
+    ground = np.array(_quad((-1.2, 0, 1.2), (1.2, 0, 1.2), (1.2, 0, -1.2), (-1.2, 0, -1.2)))
+    n_cables = 300
+    a = np.stack([rng.uniform(-1, 1, n_cables), rng.uniform(0.2, 1.5, n_cables), rng.uniform(-1, 1, n_cables)], axis=1)
+    b = np.stack([rng.uniform(-1, 1, n_cables), rng.uniform(0.2, 1.5, n_cables), rng.uniform(-1, 1, n_cables)], axis=1)
+    cables = np.stack([a, b, b + np.array([0.0, 0.004, 0.0])], axis=1).reshape(-1, 3)
+    tris = np.concatenate([ground, boxes, cables])
+    nf = tris.shape[0] // 3
+    m = default_materials(6)
+    for k, col in enumerate([(0.5, 0.5, 0.5), (0.7, 0.3, 0.2), (0.2, 0.4, 0.7), (0.8, 0.8, 0.75), (0.3, 0.6, 0.3), (0.9, 0.85, 0.6)]):
+        m["base_color"][k] = col
+    m["metalness"][5] = 1.0
+    mats = np.concatenate([[0, 0], 1 + (np.arange(12 * n_blocks) // 12) % 4, np.full(n_cables, 5)]).astype(np.uint32)
+    assert mats.shape[0] == nf
+    return _finish(tris, mats, m)
+
+
+CITY_CAMERA = dict(origin=(0.0, 0.9, 2.4), fov=np.radians(50.0), F=100.0, focus=10000.0, forward=(0.0, -0.35, -1.0))
