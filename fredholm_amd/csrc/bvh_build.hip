@@ -69,6 +69,124 @@ __global__ void k_face_bounds(const float4* face_rec, uint32_t n, float4* lo, fl
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Early split clipping (Ernst & Greiner, "Early Split Clipping for Bounding Volume Hierarchies", RT 2007).  A triangle that is
+// large against the scene (a floor, a wall, a cable) has a bounding box that most rays enter without coming near the triangle.
+// Such a triangle enters the build as several REFERENCES instead: its box is cut into a grid along its two longest axes, the
+// triangle is clipped to every cell and each non-empty cell becomes a leaf with the tight box of the clipped polygon.  All
+// references of a face store the same triangle; a ray that meets two of them computes the identical (t, face) pair, which the
+// closest-hit order treats as one hit.  Faces below the size threshold keep their single box, so a scene without large triangles
+// (the bench soup) builds exactly as before.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxSplitCells = 64;  // references per face at most
+
+struct SplitGrid { int a, b, ka, kb; };  // axes (a = longest) and cells per axis
+
+__device__ __forceinline__ float axis_of(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+__device__ inline SplitGrid split_grid(const float4& lo, const float4& hi, float thr)
+{
+  const float e[3] = {hi.x - lo.x, hi.y - lo.y, hi.z - lo.z};
+  int a = 0;
+  if (e[1] > e[a]) a = 1;
+  if (e[2] > e[a]) a = 2;
+  int b = (a + 1) % 3;
+  const int c = (a + 2) % 3;
+  if (e[c] > e[b]) b = c;
+  SplitGrid g{a, b, 1, 1};
+  if (!(e[a] > thr)) return g;
+  float fa = ceilf(e[a] / thr), fb = e[b] > thr ? ceilf(e[b] / thr) : 1.0f;
+  while (fa * fb > (float)kMaxSplitCells) { if (fa >= fb) fa = ceilf(fa * 0.5f); else fb = ceilf(fb * 0.5f); }
+  g.ka = (int)fa; g.kb = (int)fb;
+  return g;
+}
+
+// clip the polygon (<= 8 vertices) against the half-space  sign * (p[axis] - plane) >= 0
+__device__ inline int clip_poly(float (*p)[3], int n, int axis, float plane, float sign)
+{
+  float out[9][3];
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const float* cur = p[i];
+    const float* nxt = p[(i + 1) % n];
+    const float dc = sign * (cur[axis] - plane), dn = sign * (nxt[axis] - plane);
+    if (dc >= 0.0f) { out[m][0] = cur[0]; out[m][1] = cur[1]; out[m][2] = cur[2]; ++m; }
+    if ((dc >= 0.0f) != (dn >= 0.0f)) {
+      const float t = dc / (dc - dn);
+      out[m][0] = cur[0] + t * (nxt[0] - cur[0]); out[m][1] = cur[1] + t * (nxt[1] - cur[1]); out[m][2] = cur[2] + t * (nxt[2] - cur[2]);
+      out[m][axis] = plane;
+      ++m;
+    }
+  }
+  for (int i = 0; i < m; ++i) { p[i][0] = out[i][0]; p[i][1] = out[i][1]; p[i][2] = out[i][2]; }
+  return m;
+}
+
+// box of the part of triangle (v0, v1, v2) inside cell (i, j) of the grid; false if the cell is empty
+__device__ inline bool split_cell_box(const float4& v0, const float4& v1, const float4& v2, const float4& lo, const float4& hi, const SplitGrid& g, int i, int j, float eps,
+                                      float4& clo, float4& chi)
+{
+  float poly[9][3] = {{v0.x, v0.y, v0.z}, {v1.x, v1.y, v1.z}, {v2.x, v2.y, v2.z}};
+  int n = 3;
+  const float la = axis_of(lo, g.a), ha = axis_of(hi, g.a), lb = axis_of(lo, g.b), hb = axis_of(hi, g.b);
+  const float a0 = la + (ha - la) * ((float)i / (float)g.ka), a1 = i + 1 == g.ka ? ha : la + (ha - la) * ((float)(i + 1) / (float)g.ka);
+  const float b0 = lb + (hb - lb) * ((float)j / (float)g.kb), b1 = j + 1 == g.kb ? hb : lb + (hb - lb) * ((float)(j + 1) / (float)g.kb);
+  n = clip_poly(poly, n, g.a, a0, 1.0f); if (n < 3) return false;
+  n = clip_poly(poly, n, g.a, a1, -1.0f); if (n < 3) return false;
+  if (g.kb > 1) {
+    n = clip_poly(poly, n, g.b, b0, 1.0f); if (n < 3) return false;
+    n = clip_poly(poly, n, g.b, b1, -1.0f); if (n < 3) return false;
+  }
+  float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+  for (int k = 0; k < n; ++k)
+    for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], poly[k][c]); mx[c] = fmaxf(mx[c], poly[k][c]); }
+  // a little slack for the rounding of the clip points, but never beyond the triangle's own box
+  clo = make_float4(fmaxf(mn[0] - eps, lo.x), fmaxf(mn[1] - eps, lo.y), fmaxf(mn[2] - eps, lo.z), 0.0f);
+  chi = make_float4(fminf(mx[0] + eps, hi.x), fminf(mx[1] + eps, hi.y), fminf(mx[2] + eps, hi.z), 0.0f);
+  return true;
+}
+
+// pass 1: references per face (1 = unsplit)
+__global__ void k_split_count(const float4* face_rec, const float4* face_lo, const float4* face_hi, uint32_t n, float thr, float eps, uint32_t* count)
+{
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const float4 lo = face_lo[f], hi = face_hi[f];
+  const SplitGrid g = split_grid(lo, hi, thr);
+  uint32_t c = 1;
+  if (g.ka * g.kb > 1) {
+    const float4 v0 = face_rec[7 * (size_t)f], v1 = face_rec[7 * (size_t)f + 1], v2 = face_rec[7 * (size_t)f + 2];
+    c = 0;
+    float4 a, b;
+    for (int i = 0; i < g.ka; ++i)
+      for (int j = 0; j < g.kb; ++j)
+        if (split_cell_box(v0, v1, v2, lo, hi, g, i, j, eps, a, b)) ++c;
+    if (c == 0) c = 1;  // degenerate triangle: keep its box
+  }
+  count[f] = c;
+}
+
+// pass 2: write the references
+__global__ void k_split_emit(const float4* face_rec, const float4* face_lo, const float4* face_hi, uint32_t n, float thr, float eps, const uint32_t* count, const uint32_t* offset,
+                             uint32_t* ref_face, float4* ref_lo, float4* ref_hi)
+{
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const float4 lo = face_lo[f], hi = face_hi[f];
+  uint32_t o = offset[f];
+  const SplitGrid g = split_grid(lo, hi, thr);
+  if (g.ka * g.kb > 1 && count[f] > 0) {
+    const float4 v0 = face_rec[7 * (size_t)f], v1 = face_rec[7 * (size_t)f + 1], v2 = face_rec[7 * (size_t)f + 2];
+    uint32_t written = 0;
+    float4 a, b;
+    for (int i = 0; i < g.ka; ++i)
+      for (int j = 0; j < g.kb; ++j)
+        if (split_cell_box(v0, v1, v2, lo, hi, g, i, j, eps, a, b)) { ref_face[o] = f; ref_lo[o] = a; ref_hi[o] = b; ++o; ++written; }
+    if (written) return;
+  }
+  ref_face[o] = f; ref_lo[o] = lo; ref_hi[o] = hi;
+}
+
 __device__ __forceinline__ unsigned long long expand21(unsigned long long v)
 {
   v &= 0x1fffffull;
@@ -211,11 +329,12 @@ __global__ void k_emit2_tiny(int n, const float4* face_lo, const float4* face_hi
   out[3] = make_float4(__int_as_float(ra), __int_as_float(ra), 0.0f, 0.0f);
 }
 
-__global__ void k_emit_tris(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, uint32_t n, float4* tris)
+__global__ void k_emit_tris(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, uint32_t n, float4* tris, const uint32_t* ref_face)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t f = sorted_face[i];
+  uint32_t f = sorted_face[i];
+  if (ref_face) f = ref_face[f];  // split faces: the leaf is a reference
   const float4 a = face_rec[7 * f], b = face_rec[7 * f + 1], c = face_rec[7 * f + 2];
   tris[3 * i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
   tris[3 * i + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);  // .w != 0: candidate hits need the alpha test
@@ -409,11 +528,12 @@ __global__ void k_collapse8_tiny(int n, const float4* face_lo, const float4* fac
   nodes[4] = make_uint4(0xffu, 0u, 0xffu, 0u);
 }
 
-__global__ void k_emit_tris8(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, const uint32_t* tri_map, uint32_t n, float4* tris)
+__global__ void k_emit_tris8(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, const uint32_t* tri_map, uint32_t n, float4* tris, const uint32_t* ref_face)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t f = sorted_face[tri_map[i]];
+  uint32_t f = sorted_face[tri_map[i]];
+  if (ref_face) f = ref_face[f];
   const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
   tris[3 * (size_t)i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
   tris[3 * (size_t)i + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);
@@ -549,17 +669,16 @@ int bvh_build_device(fh_ctx* ctx)
   const float pad = fmaxf(maxabs, 1e-3f) * (1.0f / 65536.0f);
   for (int k = 0; k < 3; ++k) { ctx->scene_lo[k] = order_float(hb[k]) - 2.0f * pad; ctx->scene_hi[k] = order_float(hb[3 + k]) + 2.0f * pad; }
 
-  FH_HIP(hipMalloc((void**)&ctx->d_bvh2_tris, sizeof(float4) * 3ull * n));
-  ctx->bvh2_n_tris = n;
-
   if (n <= kLeafMax2) {
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh2_tris, sizeof(float4) * 3ull * n));
+    ctx->bvh2_n_tris = n;
     FH_HIP(hipMalloc((void**)&ctx->d_bvh2_nodes, sizeof(float4) * 4));
     FH_HIP(vals_a.alloc(n));
     std::vector<uint32_t> ident(n);
     for (uint32_t i = 0; i < n; ++i) ident[i] = i;
     FH_HIP(hipMemcpyAsync(vals_a.p, ident.data(), 4ull * n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_emit2_tiny, dim3(1), dim3(1), 0, st, (int)n, face_lo.p, face_hi.p, pad, ctx->d_bvh2_nodes);
-    hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, n, ctx->d_bvh2_tris);
+    hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, n, ctx->d_bvh2_tris, (const uint32_t*)nullptr);
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh2_n_nodes = 1;
     if (n <= kLeafMax8) {
@@ -568,32 +687,73 @@ int bvh_build_device(fh_ctx* ctx)
       FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * 5));
       FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n));
       hipLaunchKernelGGL(k_collapse8_tiny, dim3(1), dim3(1), 0, st, (int)n, face_lo.p, face_hi.p, pad, ctx->d_bvh8_nodes, tri_map.p);
-      hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, tri_map.p, n, ctx->d_bvh8_tris);
+      hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, tri_map.p, n, ctx->d_bvh8_tris, (const uint32_t*)nullptr);
       FH_HIP(hipStreamSynchronize(st));
       ctx->bvh8_n_nodes = 1;
       ctx->bvh8_n_tris = n;
       ctx->use_bvh8 = true;
     }
   } else {
-    FH_HIP(keys_a.alloc(n)); FH_HIP(keys_b.alloc(n)); FH_HIP(vals_a.alloc(n)); FH_HIP(vals_b.alloc(n));
-    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, st, face_lo.p, face_hi.p, n, bounds.p, keys_a.p, vals_a.p);
+    // ---- references: large triangles enter the build as several clipped boxes (early split clipping, kernels above)
+    uint32_t nr = n;
+    DevBuf<uint32_t> ref_face_buf, split_count, split_offset;
+    DevBuf<float4> ref_lo, ref_hi;
+    const float4* box_lo = face_lo.p;
+    const float4* box_hi = face_hi.p;
+    const uint32_t* ref_face = nullptr;
+    bool splitting = n >= 256;
+    if (const char* e = getenv("FH_SPLIT")) splitting = splitting && e[0] != '0';
+    if (splitting) {
+      const float extent = fmaxf(fmaxf(ctx->scene_hi[0] - ctx->scene_lo[0], ctx->scene_hi[1] - ctx->scene_lo[1]), ctx->scene_hi[2] - ctx->scene_lo[2]);
+      float thr = extent / 32.0f;
+      const float eps = extent * 1e-6f;
+      FH_HIP(split_count.alloc(n)); FH_HIP(split_offset.alloc(n));
+      size_t scan_bytes = 0;
+      FH_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, split_count.p, split_offset.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+      DevBuf<char> scan_tmp;
+      FH_HIP(scan_tmp.alloc(scan_bytes));
+      uint32_t total = n;
+      for (int attempt = 0; attempt < 6; ++attempt, thr *= 2.0f) {  // a scene made of large triangles only: coarser cells until the references fit
+        hipLaunchKernelGGL(k_split_count, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, face_lo.p, face_hi.p, n, thr, eps, split_count.p);
+        FH_HIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, split_count.p, split_offset.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+        uint32_t tail[2];
+        FH_HIP(hipMemcpyAsync(&tail[0], split_offset.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+        FH_HIP(hipMemcpyAsync(&tail[1], split_count.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+        FH_HIP(hipStreamSynchronize(st));
+        total = tail[0] + tail[1];
+        if ((unsigned long long)total <= (unsigned long long)n + n / 2 + 4096ull) break;
+        total = n;
+      }
+      if (total > n) {
+        nr = total;
+        FH_HIP(ref_face_buf.alloc(nr)); FH_HIP(ref_lo.alloc(nr)); FH_HIP(ref_hi.alloc(nr));
+        hipLaunchKernelGGL(k_split_emit, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, face_lo.p, face_hi.p, n, thr, eps, split_count.p, split_offset.p, ref_face_buf.p, ref_lo.p,
+                           ref_hi.p);
+        box_lo = ref_lo.p; box_hi = ref_hi.p; ref_face = ref_face_buf.p;
+      }
+    }
+    const uint32_t rblocks = (nr + 255) / 256;
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh2_tris, sizeof(float4) * 3ull * nr));
+    ctx->bvh2_n_tris = nr;
+    FH_HIP(keys_a.alloc(nr)); FH_HIP(keys_b.alloc(nr)); FH_HIP(vals_a.alloc(nr)); FH_HIP(vals_b.alloc(nr));
+    hipLaunchKernelGGL(k_morton, dim3(rblocks), dim3(256), 0, st, box_lo, box_hi, nr, bounds.p, keys_a.p, vals_a.p);
     size_t temp_bytes = 0;
-    FH_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)n, 0u, 63u, st));
+    FH_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)nr, 0u, 63u, st));
     DevBuf<char> temp;
     FH_HIP(temp.alloc(temp_bytes));
-    FH_HIP(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)n, 0u, 63u, st));
-    const uint32_t n_inner = n - 1;
-    FH_HIP(children.alloc(n_inner)); FH_HIP(ranges.alloc(n_inner)); FH_HIP(node_parent.alloc(n_inner)); FH_HIP(leaf_parent.alloc(n));
-    FH_HIP(node_lo.alloc(n_inner)); FH_HIP(node_hi.alloc(n_inner)); FH_HIP(leaf_lo.alloc(n)); FH_HIP(leaf_hi.alloc(n));
+    FH_HIP(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)nr, 0u, 63u, st));
+    const uint32_t n_inner = nr - 1;
+    FH_HIP(children.alloc(n_inner)); FH_HIP(ranges.alloc(n_inner)); FH_HIP(node_parent.alloc(n_inner)); FH_HIP(leaf_parent.alloc(nr));
+    FH_HIP(node_lo.alloc(n_inner)); FH_HIP(node_hi.alloc(n_inner)); FH_HIP(leaf_lo.alloc(nr)); FH_HIP(leaf_hi.alloc(nr));
     FH_HIP(arrive.alloc(n_inner));
     FH_HIP(hipMemsetAsync(arrive.p, 0, 4ull * n_inner, st));
     const uint32_t iblocks = (n_inner + 255) / 256;
-    hipLaunchKernelGGL(k_hierarchy, dim3(iblocks), dim3(256), 0, st, keys_b.p, (int)n, children.p, ranges.p, node_parent.p, leaf_parent.p);
-    hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, st, vals_b.p, face_lo.p, face_hi.p, (int)n, children.p, node_parent.p, leaf_parent.p, node_lo.p, node_hi.p, leaf_lo.p,
+    hipLaunchKernelGGL(k_hierarchy, dim3(iblocks), dim3(256), 0, st, keys_b.p, (int)nr, children.p, ranges.p, node_parent.p, leaf_parent.p);
+    hipLaunchKernelGGL(k_refit, dim3(rblocks), dim3(256), 0, st, vals_b.p, box_lo, box_hi, (int)nr, children.p, node_parent.p, leaf_parent.p, node_lo.p, node_hi.p, leaf_lo.p,
                        leaf_hi.p, arrive.p);
     FH_HIP(hipMalloc((void**)&ctx->d_bvh2_nodes, sizeof(float4) * 4ull * n_inner));
     hipLaunchKernelGGL(k_emit2, dim3(iblocks), dim3(256), 0, st, (int)n_inner, children.p, ranges.p, node_lo.p, node_hi.p, leaf_lo.p, leaf_hi.p, pad, ctx->d_bvh2_nodes);
-    hipLaunchKernelGGL(k_emit_tris, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, n, ctx->d_bvh2_tris);
+    hipLaunchKernelGGL(k_emit_tris, dim3(rblocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, nr, ctx->d_bvh2_tris, ref_face);
     FH_HIP(hipGetLastError());
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh2_n_nodes = n_inner;
@@ -614,18 +774,18 @@ int bvh_build_device(fh_ctx* ctx)
       DevBuf<int> cid_a, cid_b, nn;
       DevBuf<float4> clo_a, chi_a, clo_b, chi_b;
       DevBuf<uint32_t> valid, offset, node_counter;
-      FH_HIP(cid_a.alloc(n)); FH_HIP(cid_b.alloc(n)); FH_HIP(nn.alloc(n)); FH_HIP(clo_a.alloc(n)); FH_HIP(chi_a.alloc(n)); FH_HIP(clo_b.alloc(n)); FH_HIP(chi_b.alloc(n));
-      FH_HIP(valid.alloc(n)); FH_HIP(offset.alloc(n)); FH_HIP(node_counter.alloc(1));
+      FH_HIP(cid_a.alloc(nr)); FH_HIP(cid_b.alloc(nr)); FH_HIP(nn.alloc(nr)); FH_HIP(clo_a.alloc(nr)); FH_HIP(chi_a.alloc(nr)); FH_HIP(clo_b.alloc(nr)); FH_HIP(chi_b.alloc(nr));
+      FH_HIP(valid.alloc(nr)); FH_HIP(offset.alloc(nr)); FH_HIP(node_counter.alloc(1));
       FH_HIP(p_children.alloc(n_inner)); FH_HIP(p_ranges.alloc(n_inner)); FH_HIP(p_node_lo.alloc(n_inner)); FH_HIP(p_node_hi.alloc(n_inner));
       FH_HIP(hipMemsetAsync(node_counter.p, 0, 4, st));
-      hipLaunchKernelGGL(k_ploc_init, dim3(blocks), dim3(256), 0, st, (int)n, leaf_lo.p, leaf_hi.p, cid_a.p, clo_a.p, chi_a.p);
+      hipLaunchKernelGGL(k_ploc_init, dim3(rblocks), dim3(256), 0, st, (int)nr, leaf_lo.p, leaf_hi.p, cid_a.p, clo_a.p, chi_a.p);
       size_t scan_bytes = 0;
-      FH_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, valid.p, offset.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+      FH_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, valid.p, offset.p, 0u, (size_t)nr, rocprim::plus<uint32_t>(), st));
       DevBuf<char> scan_tmp;
       FH_HIP(scan_tmp.alloc(scan_bytes));
       int* cid = cid_a.p; int* cid_o = cid_b.p;
       float4 *clo = clo_a.p, *chi = chi_a.p, *clo_o = clo_b.p, *chi_o = chi_b.p;
-      uint32_t count = n;
+      uint32_t count = nr;
       for (int round = 0; count > 1 && round < 4096; ++round) {
         const uint32_t b = (count + 255) / 256;
         hipLaunchKernelGGL(k_ploc_nearest, dim3(b), dim3(256), 0, st, (int)count, clo, chi, nn.p);
@@ -671,9 +831,9 @@ int bvh_build_device(fh_ctx* ctx)
     // ---- collapse to BVH8, breadth first
     DevBuf<Work8> work_a, work_b;
     DevBuf<uint32_t> counters, tri_map;  // [0] node counter, [1] triangle counter, [2] next-level item count
-    FH_HIP(work_a.alloc(n_inner)); FH_HIP(work_b.alloc(n_inner)); FH_HIP(counters.alloc(3)); FH_HIP(tri_map.alloc(n));
+    FH_HIP(work_a.alloc(n_inner)); FH_HIP(work_b.alloc(n_inner)); FH_HIP(counters.alloc(3)); FH_HIP(tri_map.alloc(nr));
     FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * 5ull * n_inner));
-    FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n));
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * nr));
     uint32_t leaf_max8 = 1;  // one triangle per leaf child: box tests are ~4x cheaper than triangle tests (profiles/README.md)
     uint32_t absorb8 = 1u;  // FH_ABSORB=0: plain largest-child-first collapse
     if (const char* e = getenv("FH_ABSORB")) absorb8 = e[0] != '0' ? 1u : 0u;
@@ -697,12 +857,12 @@ int bvh_build_device(fh_ctx* ctx)
     uint32_t final_counters[2] = {0, 0};
     FH_HIP(hipMemcpyAsync(final_counters, counters.p, 8, hipMemcpyDeviceToHost, st));
     FH_HIP(hipStreamSynchronize(st));
-    if (final_counters[1] != n) return fail(ctx, FH_E_INVALID, "BVH8 collapse lost triangles");
-    hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_map.p, n, ctx->d_bvh8_tris);
+    if (final_counters[1] != nr) return fail(ctx, FH_E_INVALID, "BVH8 collapse lost triangles");
+    hipLaunchKernelGGL(k_emit_tris8, dim3(rblocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_map.p, nr, ctx->d_bvh8_tris, ref_face);
     FH_HIP(hipGetLastError());
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh8_n_nodes = final_counters[0];
-    ctx->bvh8_n_tris = n;
+    ctx->bvh8_n_tris = nr;
     ctx->use_bvh8 = true;
   }
   ctx->bvh_valid = true;
@@ -711,7 +871,7 @@ int bvh_build_device(fh_ctx* ctx)
   if (getenv("FH_BVH2")) ctx->use_bvh8 = false;  // developer switch: traverse the binary layout instead of the wide one
   ctx->stats.bvh_nodes = ctx->use_bvh8 ? ctx->bvh8_n_nodes : ctx->bvh2_n_nodes;
   ctx->stats.bvh_node_bytes = ctx->use_bvh8 ? 80ull * ctx->bvh8_n_nodes : 64ull * ctx->bvh2_n_nodes;
-  ctx->stats.bvh_tri_bytes = 48ull * n;
+  ctx->stats.bvh_tri_bytes = 48ull * (ctx->use_bvh8 ? ctx->bvh8_n_tris : ctx->bvh2_n_tris);
   return FH_OK;
 }
 
