@@ -8,7 +8,7 @@ if len(sys.argv) > 1:
     import fredholm_amd as F
     from fredholm_amd import native as N, scenes
     name = sys.argv[1]
-    sc, camkw = (scenes.triangle_soup(1_000_000), scenes.SOUP_CAMERA) if name == "soup" else (scenes.city(80000), scenes.CITY_CAMERA)
+    sc, camkw = (scenes.triangle_soup(1_000_000), scenes.SOUP_CAMERA) if name == "soup" else (scenes.city(int(os.environ.get("CITY_BLOCKS", "80000"))), scenes.CITY_CAMERA)
     r = F.Renderer(0); r.load_scene(sc); r.build_ias()
     r.set_directional_light((0, 0, 0), scenes.SOUP_SUN, 0.0); r.clear_directional_light(); r.load_arhosek_sky(3.0, 0.3)
     W, H = 1920, 1080
