@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle as O  # noqa: E402
 
@@ -22,5 +22,5 @@ for t, a, e in grid:
     cfg, rad = O.ref_hosek_state(t, a, e)
     cases.append({"turbidity": t, "albedo": a, "elevation": e, "configs_bits": [int(x) for x in cfg.reshape(-1).view(np.uint32)], "radiances_bits": [int(x) for x in rad.view(np.uint32)]})
 out = os.path.join(ROOT, "tests", "golden", "hosek_reference_states.json")
-json.dump({"source": "reference arhosek.h cook run through oracle/_ref/libref_hosek.so (tools/gen_hosek_golden.py)", "cases": cases}, open(out, "w"), indent=0)
+json.dump({"source": "reference arhosek.h cook run through oracle/_ref/libref_hosek.so (tests/golden/gen_hosek_golden.py)", "cases": cases}, open(out, "w"), indent=0)
 print(len(cases), "cases ->", out)

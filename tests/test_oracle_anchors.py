@@ -361,7 +361,7 @@ def test_alpha_cutout_lets_rays_through(oracle):
 # ---------------------------------------------------------------- pinned against the reference's OWN code (the one part of it that builds here)
 def test_hosek_cook_matches_outputs_of_the_reference_source(oracle):
     """tests/golden/hosek_reference_states.json holds outputs of the reference's arhosek_rgb_skymodelstate_alloc_init
-    (arhosek.h:298-322), produced by tools/gen_hosek_golden.py from oracle/_ref/libref_hosek.so = the reference's sources built by
+    (arhosek.h:298-322), produced by tests/golden/gen_hosek_golden.py from oracle/_ref/libref_hosek.so = the reference's sources built by
     oracle/Makefile.  The restatement agrees to 2 ulp (it evaluates pow through include/fh_elementary.h, the reference through
     glibc's powf); most states are bit-identical."""
     import json
