@@ -206,7 +206,7 @@ int fh_trace_rays(fh_ctx* ctx, uint32_t n, const float* rays7, int any_hit, floa
   Tmp<uint32_t> p;
   FH_HIP(r.up(rays7, 7ull * n)); FH_HIP(t.up(nullptr, 3ull * n)); FH_HIP(p.up(nullptr, n));
   const SceneDev sd = scene_dev(ctx);
-  uint32_t flush = 8u;
+  uint32_t flush = 32u;
   if (const char* e = getenv("FH_COOP_T")) { const int v = atoi(e); if (v >= 1 && v <= 64) flush = (uint32_t)v; }
   const char* coop_env = getenv("FH_COOP");
   if (sd.use_bvh8 && sd.bvh8.n_tris < kCoopMaxTris && !(coop_env && coop_env[0] == '0')) {

@@ -1256,7 +1256,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   hipDeviceProp_t prop;
   FH_HIP(hipGetDeviceProperties(&prop, ctx->device));
   // wave-cooperative triangle tests (default for the wide BVH); FH_COOP=0 selects the per-lane loop, FH_COOP_T the flush threshold
-  uint32_t coop_flush = 8u;
+  uint32_t coop_flush = 32u;
   if (const char* e = getenv("FH_COOP_T")) { const int v = atoi(e); if (v >= 1 && v <= 64) coop_flush = (uint32_t)v; }
   const char* coop_env = getenv("FH_COOP");
   const bool coop = sc.use_bvh8 != 0 && sc.bvh8.n_tris < kCoopMaxTris && !(coop_env && coop_env[0] == '0');
