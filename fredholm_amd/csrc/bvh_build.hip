@@ -565,15 +565,15 @@ __global__ void k_ploc_nearest(int n, const float4* clo, const float4* chi, int*
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 lo = clo[i], hi = chi[i];
-  float best = 3e38f;
-  int bj = -1;
+  float best = __builtin_inff();
+  int bj = -1;  // the first neighbour is taken unconditionally, so a cluster whose merged areas are all inf / NaN still gets a partner
   const int j0 = i - kPlocRadius < 0 ? 0 : i - kPlocRadius, j1 = i + kPlocRadius > n - 1 ? n - 1 : i + kPlocRadius;
   for (int j = j0; j <= j1; ++j) {
     if (j == i) continue;
     const float4 l2 = clo[j], h2 = chi[j];
     const float ex = fmaxf(hi.x, h2.x) - fminf(lo.x, l2.x), ey = fmaxf(hi.y, h2.y) - fminf(lo.y, l2.y), ez = fmaxf(hi.z, h2.z) - fminf(lo.z, l2.z);
     const float a = ex * ey + ey * ez + ez * ex;
-    if (a < best) { best = a; bj = j; }  // ties: the lower index (the loop ascends)
+    if (bj < 0 || a < best) { best = a; bj = j; }  // ties: the lower index (the loop ascends)
   }
   nn[i] = bj;
 }
@@ -768,6 +768,7 @@ int bvh_build_device(fh_ctx* ctx)
     if (const char* e = getenv("FH_BVH_BUILDER")) { if (std::strcmp(e, "ploc") == 0) mode = 2; else if (std::strcmp(e, "lbvh") == 0) mode = 1; }
     const bool deciding = mode == 0;
     bool ploc = mode == 2 || deciding;
+    bool ploc_failed = false;
     DevBuf<int2> p_children, p_ranges;
     DevBuf<float4> p_node_lo, p_node_hi;
     if (ploc) {
@@ -797,15 +798,25 @@ int bvh_build_device(fh_ctx* ctx)
         FH_HIP(hipMemcpyAsync(&tail[1], valid.p + (count - 1), 4, hipMemcpyDeviceToHost, st));
         FH_HIP(hipStreamSynchronize(st));
         const uint32_t next = tail[0] + tail[1];
-        if (next >= count) return fail(ctx, FH_E_INVALID, "PLOC made no progress");
+        if (next >= count) {  // no mutual pair found (non-finite boxes): in auto mode the radix tree built above is still valid
+          if (!deciding) return fail(ctx, FH_E_INVALID, "PLOC made no progress");
+          ploc_failed = true;
+          break;
+        }
         count = next;
         int* t = cid; cid = cid_o; cid_o = t;
         float4* tl = clo; clo = clo_o; clo_o = tl;
         float4* th = chi; chi = chi_o; chi_o = th;
       }
-      FH_HIP(hipMemcpyAsync(&root_node, cid, 4, hipMemcpyDeviceToHost, st));
-      FH_HIP(hipStreamSynchronize(st));
-      if (root_node < 0 || (uint32_t)root_node >= n_inner) return fail(ctx, FH_E_INVALID, "PLOC did not end in one inner node");
+      if (!ploc_failed) {
+        FH_HIP(hipMemcpyAsync(&root_node, cid, 4, hipMemcpyDeviceToHost, st));
+        FH_HIP(hipStreamSynchronize(st));
+        if (root_node < 0 || (uint32_t)root_node >= n_inner) {
+          if (!deciding) return fail(ctx, FH_E_INVALID, "PLOC did not end in one inner node");
+          ploc_failed = true;
+        }
+      }
+      if (ploc_failed) { ploc = false; ctx->builder_choice = 1; }  // auto mode falls back to the radix tree; an explicit FH_BVH_BUILDER=ploc reported the error above
     }
     if (deciding || getenv("FH_DEBUG_BVH")) {
       DevBuf<double> sums;
@@ -816,7 +827,7 @@ int bvh_build_device(fh_ctx* ctx)
       double h[2];
       FH_HIP(hipMemcpyAsync(h, sums.p, 16, hipMemcpyDeviceToHost, st));
       FH_HIP(hipStreamSynchronize(st));
-      if (deciding) {
+      if (deciding && !ploc_failed) {
         ploc = h[1] < 0.85 * h[0];
         ctx->builder_choice = ploc ? 2 : 1;
       }

@@ -16,16 +16,18 @@
 
 namespace fh {
 
+// errors of calls that have no context (fh_ctx_create, fh_image_load_rgba8) are kept per thread: a failing call on one thread
+// (e.g. a texture loader thread) never reallocates a string another thread is reading through fh_last_error(NULL)
+static thread_local std::string g_create_error;
+
 int fail(fh_ctx* ctx, int code, const std::string& msg)
 {
-  static thread_local std::string g_last;
-  g_last = msg;
+  g_create_error = msg;
   if (ctx) ctx->err = msg;
   return code;
 }
 
 namespace {
-std::string g_create_error;
 
 m34 load_m34(const float* m)
 {
@@ -43,8 +45,10 @@ bool material_textured(const fh_material& m)
          m.normalmap_texture_id != -1 || m.alpha_texture_id != -1;
 }
 
-// lobes a material can ever enable (see fh_bsdf.h).  metalness == 1 zeroes the weight and the
-// layering multiplier of every lobe after the metal one, so those lobes are dropped exactly.
+// lobes a material can ever enable (see fh_bsdf.h).  Seen from the FRONT, metalness == 1 zeroes the weight and the layering
+// multiplier of every lobe after the metal one.  Seen from BEHIND the reference resets metalness, specular, sheen and diffuse to 0
+// (bsdf.cu:56-62), so transmission and diffuse transmission get their full weight back (weights[3], weights[5], bsdf.cu:74-84): those
+// two stay whenever their own parameters enable them.  specular / sheen / diffuse are zero on both sides of a full metal and are dropped.
 uint32_t material_lobes(const fh_material& m)
 {
   // a texture on a parameter that switches lobes on or off makes the mask unknowable on the host: take every lobe
@@ -54,11 +58,11 @@ uint32_t material_lobes(const fh_material& m)
   if (coat > 0.0f) l |= L_COAT;
   if (m.metalness > 0.0f) l |= L_METAL;
   const bool metal_full = m.metalness == 1.0f;
+  if (m.transmission > 0.0f) l |= L_TRANS;
+  if (m.subsurface * m.thin_walled > 0.0f) l |= L_DT;
   if (!metal_full) {
     if (m.specular * lum(mk3(m.specular_color[0], m.specular_color[1], m.specular_color[2])) > 0.0f) l |= L_SPEC;
-    if (m.transmission > 0.0f) l |= L_TRANS;
     if (m.sheen * lum(mk3(m.sheen_color[0], m.sheen_color[1], m.sheen_color[2])) != 0.0f) l |= L_SHEEN;
-    if (m.subsurface * m.thin_walled > 0.0f) l |= L_DT;
     if (m.diffuse > 0.0f) l |= L_DIFF;
   }
   return l;
@@ -248,6 +252,25 @@ int fh_ctx_create(int device, fh_ctx** out)
   }
   (void)hipEventCreateWithFlags(&ctx->ev_enter, hipEventDisableTiming);
   if (const char* e = getenv("FH_PIPELINE")) ctx->n_slots = e[0] == '0' ? 1 : (e[0] == '3' ? 3 : 2);
+  {
+    fh_ctx::Tunables& t = ctx->tun;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) t.n_cus = (uint32_t)prop.multiProcessorCount;
+    auto env_uint = [](const char* name, int lo, int hi, uint32_t& dst) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) dst = (uint32_t)v; } };
+    auto env_off = [](const char* name, bool& dst) { if (const char* e = getenv(name)) dst = e[0] != '0'; };
+    env_uint("FH_COOP_T", 1, 64, t.coop_flush);
+    env_off("FH_COOP", t.coop);
+    env_off("FH_STREAM", t.stream);
+    env_uint("FH_STREAM_WGS", 1, 8, t.stream_wgs_per_cu);
+    env_uint("FH_STREAM_GRID", 8, 8192, t.stream_grid);
+    t.stream_grid &= ~7u;
+    env_uint("FH_STREAM_REFILL", 1, 64, t.stream_refill);
+    env_uint("FH_STREAM_CHUNK", 16, 65536, t.stream_chunk);
+    env_uint("FH_TAIL_DEPTH", 0, 64, t.tail_depth);
+    env_uint("FH_TAIL_PATHS", 64, 1 << 30, t.tail_paths);
+    env_off("FH_SORT", t.sort_queues);
+    t.debug_tail = getenv("FH_DEBUG_TAIL") != nullptr;
+  }
   (void)hipEventCreate(&ctx->ev_render_begin);
   (void)hipEventCreate(&ctx->ev_render_end);
   *out = ctx;
@@ -261,7 +284,8 @@ int fh_ctx_destroy(fh_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   pool_release(ctx);
   void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
-                  ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl};
+                  ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl,
+                  ctx->d_bloom_weights};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }

@@ -91,6 +91,26 @@ struct fh_ctx {
   bool gen_valid[3] = {false, false, false}, acc_valid[3] = {false, false, false};
   int n_slots = 2;  // passes in flight (FH_PIPELINE=0: 1, every pass on the main stream; =3: three)
 
+  // device facts and developer switches, read ONCE at fh_ctx_create (fh_render does no getenv / hipGetDeviceProperties)
+  struct Tunables {
+    uint32_t n_cus = 256;
+    uint32_t coop_flush = 32;       // FH_COOP_T: queued candidate triangles that trigger a cooperative test round
+    bool coop = true;               // FH_COOP=0: per-lane triangle loop
+    bool stream = true;             // FH_STREAM=0: one fixed batch per wave
+    uint32_t stream_wgs_per_cu = 0; // FH_STREAM_WGS: workgroups per CU of the streaming kernels (0 = the kernels' LDS budget decides)
+    uint32_t stream_grid = 0;       // FH_STREAM_GRID: blocks (0 = n_cus * workgroups per CU)
+    uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill
+    uint32_t stream_chunk = 64;     // FH_STREAM_CHUNK: queue entries a wave takes per global atomic
+    uint32_t tail_depth = 0;        // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail
+    uint32_t tail_paths = 65536;    // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail
+    bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
+    bool debug_tail = false;        // FH_DEBUG_TAIL
+  } tun;
+
+  // bloom weights of the last sigma used (post.hip): no allocation, upload or host synchronisation per frame
+  float* d_bloom_weights = nullptr;
+  float bloom_sigma_cached = -1.0f, bloom_wsum = 0.0f;
+
   // stats
   fh_stats stats{};
   unsigned long long* d_trace_counters = nullptr;  // nodes, tris, rays of the closest-hit kernel, then of the secondary kernel

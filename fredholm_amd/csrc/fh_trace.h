@@ -248,7 +248,10 @@ FH_D bool first_active_lane() { return __lane_id() == (uint32_t)__ffsll((long lo
 // Traversal stack of node groups: the first kLdsStack entries of every lane live in LDS (column layout
 // [entry][thread], conflict-free), deeper entries in the lane's private (scratch) array.  A wide tree of a
 // million triangles is ~8 levels deep and each level leaves at most one pending group, so the spill part is cold.
-constexpr int kLdsStack = 6;  // 6 entries x 256 lanes x 8 B + the cooperative-test records = 26 KB per workgroup: six workgroups per CU
+#ifndef FH_LDS_STACK
+#define FH_LDS_STACK 6
+#endif
+constexpr int kLdsStack = FH_LDS_STACK;  // 6 entries x 256 lanes x 8 B + the cooperative-test records = 26 KB per workgroup: six workgroups per CU
 template <bool LDS>
 struct GroupStack;
 template <>
@@ -355,6 +358,9 @@ struct CoopLds {            // per-wave slices of the block's LDS
   uint32_t* queue;          // [kCoopQueue]
 };
 constexpr uint32_t kCoopLdsBytesPerWave = 64 * 32 + 64 * 8 + 64 * 8 + kCoopQueue * 4;
+// LDS of one 256-thread workgroup of a streaming traversal kernel, and how many of them a CU (160 KiB of LDS, 32 waves) holds
+constexpr uint32_t kStreamLdsBytes = (uint32_t)kLdsStack * 256u * 8u + 4u * kCoopLdsBytesPerWave;
+constexpr uint32_t kStreamWgsPerCu = 163840u / kStreamLdsBytes < 8u ? 163840u / kStreamLdsBytes : 8u;
 FH_D CoopLds coop_lds(unsigned char* block_lds, uint32_t wave_in_block)
 {
   unsigned char* b = block_lds + (size_t)wave_in_block * kCoopLdsBytesPerWave;

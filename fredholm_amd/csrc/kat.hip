@@ -9,6 +9,7 @@
 
 #include "context.h"
 #include "fh_bsdf.h"
+#include "fh_tonemap.h"
 #include "fh_trace.h"
 
 namespace fh {
@@ -112,6 +113,40 @@ __global__ void k_bsdf(MaterialDev mat, int entering, BsdfTables lut, uint32_t n
   for (int k = 0; k < 7; ++k) r[11 + k] = b.pmf(k);
 }
 
+// small math building blocks that have a reference-built counterpart (oracle/_ref/libref_lut_math_post.so): albedo LUT fetches
+// (lut.cu:957-1081), shading-frame helpers (math.cu:7-35, :90-118) and the tone-map helper chain (post-process.h:13-124)
+__global__ void k_math(int kind, BsdfTables lut, uint32_t n, const float* in, uint32_t si, float* out, uint32_t so)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* a = in + (size_t)si * i;
+  float* o = out + (size_t)so * i;
+  switch (kind) {
+    case FH_MATH_ALBEDO_REFLECTION: o[0] = lut_reflection_albedo(lut.reflection, mk3(0.0f, a[0], 0.0f), a[1], a[2]); break;
+    case FH_MATH_ALBEDO_SHEEN: o[0] = lut_sheen_albedo(lut.sheen, mk3(0.0f, a[0], 0.0f), a[1]); break;
+    case FH_MATH_ONB: { f3 t, b; onb(mk3(a[0], a[1], a[2]), t, b); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = b.x; o[4] = b.y; o[5] = b.z; break; }
+    case FH_MATH_TO_LOCAL: { const f3 r = to_local(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(a[6], a[7], a[8]), mk3(a[9], a[10], a[11])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+    case FH_MATH_TO_WORLD: { const f3 r = to_world(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(a[6], a[7], a[8]), mk3(a[9], a[10], a[11])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+    case FH_MATH_SPHERICAL: {  // cartesian_to_spherical as env_radiance evaluates it for the IBL lookup
+      o[0] = fhe_acos(clampf(a[1], -1.0f, 1.0f));
+      float phi = fhe_atan2(a[2], a[0]);
+      if (phi < 0) phi += 2.0f * kPi;
+      o[1] = phi;
+      break;
+    }
+    case FH_MATH_LUMINANCE: o[0] = lum(mk3(a[0], a[1], a[2])); break;
+    case FH_MATH_UCHIMURA: o[0] = uchimura1(a[0]); o[1] = uchimura1(a[1]); o[2] = uchimura1(a[2]); break;
+    case FH_MATH_LINEAR_TO_SRGB: o[0] = srgb1(a[0]); o[1] = srgb1(a[1]); o[2] = srgb1(a[2]); break;
+    case FH_MATH_EXPOSURE: o[0] = ev100_of(a[0], a[1], a[2]); o[1] = exposure_from_ev100(o[0]); break;
+    case FH_MATH_TONE_MAP_TAIL: {
+      const float e = exposure_from_ev100(ev100_of(1.0f, 1.0f, a[3]));
+      o[0] = srgb1(uchimura1(a[0] * e)); o[1] = srgb1(uchimura1(a[1] * e)); o[2] = srgb1(uchimura1(a[2] * e));
+      break;
+    }
+    case FH_MATH_POST_LUMINANCE: o[0] = luminance_rgb(a[0], a[1], a[2]); break;
+  }
+}
+
 __global__ void k_sky(HosekSky st, f3 sun, float intensity, uint32_t n, const float* d, float* out)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,9 +242,8 @@ int fh_trace_rays(fh_ctx* ctx, uint32_t n, const float* rays7, int any_hit, floa
   FH_HIP(r.up(rays7, 7ull * n)); FH_HIP(t.up(nullptr, 3ull * n)); FH_HIP(p.up(nullptr, n));
   const SceneDev sd = scene_dev(ctx);
   uint32_t flush = 32u;
-  if (const char* e = getenv("FH_COOP_T")) { const int v = atoi(e); if (v >= 1 && v <= 64) flush = (uint32_t)v; }
-  const char* coop_env = getenv("FH_COOP");
-  if (sd.use_bvh8 && sd.bvh8.n_tris < kCoopMaxTris && !(coop_env && coop_env[0] == '0')) {
+  flush = ctx->tun.coop_flush;
+  if (sd.use_bvh8 && sd.bvh8.n_tris < kCoopMaxTris && ctx->tun.coop) {
     const dim3 g(blocks(n)), b(256);
     if (any_hit && sd.has_alpha) hipLaunchKernelGGL((k_trace_batch_coop<true, true>), g, b, 0, ctx->stream, sd, n, r.p, t.p, p.p, flush);
     else if (any_hit) hipLaunchKernelGGL((k_trace_batch_coop<true, false>), g, b, 0, ctx->stream, sd, n, r.p, t.p, p.p, flush);
@@ -334,6 +368,22 @@ int fh_kat_offset_origin(fh_ctx* ctx, uint32_t n, const float* p3, const float* 
   hipLaunchKernelGGL(k_offset, dim3(blocks(n)), dim3(256), 0, ctx->stream, n, a.p, b.p, o.p);
   FH_HIP(hipStreamSynchronize(ctx->stream));
   FH_HIP(o.down(out3));
+  return FH_OK;
+}
+int fh_kat_math(fh_ctx* ctx, int kind, uint32_t n, const float* in, float* out)
+{
+  KCTX(ctx);
+  static const uint32_t widths[FH_MATH_COUNT][2] = {{3, 1}, {2, 1}, {3, 6}, {12, 3}, {12, 3}, {3, 2}, {3, 1}, {3, 3}, {3, 3}, {3, 2}, {4, 3}, {3, 1}};
+  if (kind < 0 || kind >= FH_MATH_COUNT) return fail(ctx, FH_E_INVALID, "fh_kat_math: unknown kind");
+  const uint32_t si = widths[kind][0], so = widths[kind][1];
+  Tmp<float> a, o;
+  FH_HIP(a.up(in, (size_t)si * n)); FH_HIP(o.up(nullptr, (size_t)so * n));
+  BsdfTables lut;
+  lut.reflection = ctx->d_lut_refl;
+  lut.sheen = ctx->d_lut_sheen;
+  hipLaunchKernelGGL(k_math, dim3(blocks(n)), dim3(256), 0, ctx->stream, kind, lut, n, a.p, si, o.p, so);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out));
   return FH_OK;
 }
 

@@ -14,7 +14,7 @@
 #include <vector>
 
 #include "context.h"
-#include "../../include/fh_elementary.h"
+#include "fh_tonemap.h"
 
 namespace fh {
 namespace {
@@ -66,32 +66,6 @@ __global__ void __launch_bounds__(256) k_copy(const float4* in, int w, int gw, i
   out[i + w * j] = in[i + w * j];
 }
 
-__device__ __forceinline__ float smoothstep_f(float e0, float e1, float x)
-{
-  if (x < e0) return 0.0f;
-  if (x > e1) return 1.0f;
-  x = (x - e0) / (e1 - e0);
-  return x * x * (3.0f - 2.0f * x);
-}
-__device__ __forceinline__ float uchimura1(float x)
-{
-  const float P = 1.0f, a = 1.0f, m = 0.22f, l = 0.4f, c = 1.33f, b = 0.0f;
-  const float l0 = ((P - m) * l) / a;
-  const float S0 = m + l0;
-  const float S1 = m + a * l0;
-  const float C2 = (a * P) / (P - S1);
-  const float CP = -C2 / P;
-  const float w0 = 1.0f - smoothstep_f(0.0f, m, x);
-  const float w2 = (x < m + l0) ? 0.0f : 1.0f;
-  const float w1 = 1.0f - w0 - w2;
-  const float T = m * fhe_pow(x / m, c) + b;
-  const float S = P - (P - S1) * fhe_exp(CP * (x - S0));
-  const float Lc = m + a * (x - m);
-  return T * w0 + Lc * w1 + S * w2;
-}
-__device__ __forceinline__ float srgb1(float x) { return x < 0.0031308 ? (float)(12.92 * x) : (float)(1.055 * fhe_pow(x, 1.0f / 2.4f) - 0.055); }
-__device__ __forceinline__ float clamp01f(float v) { return fmaxf(0.0f, fminf(v, 1.0f)); }
-
 __global__ void __launch_bounds__(256) k_tone_map(const float4* in, int w, int h, int gw, int gh, float exposure, float ca, float4* out)
 {
   const int i = blockIdx.x * kT + threadIdx.x, j = blockIdx.y * kT + threadIdx.y;
@@ -119,28 +93,30 @@ int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int
   const dim3 grid(bx, by), block(kT, kT);
   if (pp->use_bloom) {
     if (w < kT || h < kT) return fail(ctx, FH_E_UNSUPPORTED, "bloom needs an image of at least 16x16 pixels");
-    std::vector<float> wt(33 * 33);
-    float wsum = 0.0f;
-    for (int v = -kR; v <= kR; ++v)
-      for (int u = -kR; u <= kR; ++u) {
-        const float dist2 = (float)(u * u + v * v);
-        const float hh = fhe_exp(-dist2 / (2.0f * pp->bloom_sigma));
-        wt[(v + kR) * 33 + (u + kR)] = hh;
-        wsum += hh;
-      }
-    float* d_wt = nullptr;
-    FH_HIP(hipMalloc((void**)&d_wt, wt.size() * 4));
-    FH_HIP(hipMemcpyAsync(d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, st));
+    // the 1089 weights depend on bloom_sigma only: computed and uploaded when sigma changes, kept in the context otherwise
+    // (no allocation, copy or host synchronisation per frame)
+    if (!ctx->d_bloom_weights) FH_HIP(hipMalloc((void**)&ctx->d_bloom_weights, 33 * 33 * sizeof(float)));
+    if (ctx->bloom_sigma_cached != pp->bloom_sigma) {
+      std::vector<float> wt(33 * 33);
+      float wsum = 0.0f;
+      for (int v = -kR; v <= kR; ++v)
+        for (int u = -kR; u <= kR; ++u) {
+          const float dist2 = (float)(u * u + v * v);
+          const float hh = fhe_exp(-dist2 / (2.0f * pp->bloom_sigma));
+          wt[(v + kR) * 33 + (u + kR)] = hh;
+          wsum += hh;
+        }
+      FH_HIP(hipStreamSynchronize(st));  // an earlier frame may still read the old weights
+      FH_HIP(hipMemcpy(ctx->d_bloom_weights, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+      ctx->bloom_sigma_cached = pp->bloom_sigma;
+      ctx->bloom_wsum = wsum;
+    }
     hipLaunchKernelGGL(k_bloom_threshold, grid, block, 0, st, (const float4*)in, w, gw, gh, pp->bloom_threshold, (float4*)hi);
-    hipLaunchKernelGGL(k_bloom_blur, grid, block, 0, st, (const float4*)in, (const float4*)hi, w, h, d_wt, wsum, (float4*)tmp);
-    FH_HIP(hipStreamSynchronize(st));
-    (void)hipFree(d_wt);
+    hipLaunchKernelGGL(k_bloom_blur, grid, block, 0, st, (const float4*)in, (const float4*)hi, w, h, ctx->d_bloom_weights, ctx->bloom_wsum, (float4*)tmp);
   } else {
     hipLaunchKernelGGL(k_copy, grid, block, 0, st, (const float4*)in, w, gw, gh, (float4*)tmp);
   }
-  const float EV100 = fhe_log2((float)(1.0f * 1.0f / 1.0f * 100.0 / pp->ISO));
-  const float maxLum = (float)(1.2 * fhe_pow(2.0f, EV100));
-  const float exposure = 1.0f / maxLum;
+  const float exposure = exposure_from_ev100(ev100_of(1.0f, 1.0f, pp->ISO));
   hipLaunchKernelGGL(k_tone_map, grid, block, 0, st, (const float4*)tmp, w, h, gw, gh, exposure, pp->chromatic_aberration, (float4*)out);
   FH_HIP(hipGetLastError());
   return FH_OK;

@@ -1180,16 +1180,28 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
     return e;
   };
   const size_t n = capacity;
-  FH_HIP(alloc(P.ray_o, n)); FH_HIP(alloc(P.ray_d, n)); FH_HIP(alloc(P.thr, n)); FH_HIP(alloc(P.rad, n)); FH_HIP(alloc(P.hit, n));
-  FH_HIP(alloc(P.pixel, n)); FH_HIP(alloc(P.nspp, n)); FH_HIP(alloc(P.flags, n));
-  FH_HIP(alloc(P.aov_position, n)); FH_HIP(alloc(P.aov_normal, n)); FH_HIP(alloc(P.aov_albedo, n)); FH_HIP(alloc(P.aov_texdepth, n));
-  FH_HIP(alloc(P.sec_o, n * SEC_COUNT)); FH_HIP(alloc(P.sec_d, n * SEC_COUNT)); FH_HIP(alloc(P.sec_c, n * SEC_COUNT));
-  FH_HIP(alloc(P.lp_a, n)); FH_HIP(alloc(P.lp_b, n));
-  FH_HIP(alloc(P.q_rad[0], n)); FH_HIP(alloc(P.q_rad[1], n)); FH_HIP(alloc(P.q_cls, n * kNumQueues)); FH_HIP(alloc(P.q_sec, n));
-  FH_HIP(alloc(P.counters, (size_t)kCounterStride * 66));  // up to 65 bounces per pass
-  FH_HIP(alloc(P.key_sec, n)); FH_HIP(alloc(P.key_rad, n)); FH_HIP(alloc(P.q_tmp, n)); FH_HIP(alloc(P.q_sec_sorted, n));
-  FH_HIP(alloc(P.bins, (size_t)2 * kCells));
-  FH_HIP(hipMemset(P.bins, 0, sizeof(uint32_t) * 2 * kCells));
+  auto all = [&]() -> hipError_t {
+    hipError_t e;
+#define FH_POOL(ptr, count) if ((e = alloc(ptr, count)) != hipSuccess) return e
+    FH_POOL(P.ray_o, n); FH_POOL(P.ray_d, n); FH_POOL(P.thr, n); FH_POOL(P.rad, n); FH_POOL(P.hit, n);
+    FH_POOL(P.pixel, n); FH_POOL(P.nspp, n); FH_POOL(P.flags, n);
+    FH_POOL(P.aov_position, n); FH_POOL(P.aov_normal, n); FH_POOL(P.aov_albedo, n); FH_POOL(P.aov_texdepth, n);
+    FH_POOL(P.sec_o, n * SEC_COUNT); FH_POOL(P.sec_d, n * SEC_COUNT); FH_POOL(P.sec_c, n * SEC_COUNT);
+    FH_POOL(P.lp_a, n); FH_POOL(P.lp_b, n);
+    FH_POOL(P.q_rad[0], n); FH_POOL(P.q_rad[1], n); FH_POOL(P.q_cls, n * kNumQueues); FH_POOL(P.q_sec, n);
+    FH_POOL(P.counters, (size_t)kCounterStride * 66);  // up to 65 bounces per pass
+    FH_POOL(P.key_sec, n); FH_POOL(P.key_rad, n); FH_POOL(P.q_tmp, n); FH_POOL(P.q_sec_sorted, n);
+    FH_POOL(P.bins, (size_t)2 * kCells);
+#undef FH_POOL
+    return hipMemset(P.bins, 0, sizeof(uint32_t) * 2 * kCells);
+  };
+  const hipError_t e = all();
+  if (e != hipSuccess) {  // leave the slot empty rather than half allocated: the next call starts from scratch
+    for (void* p : ctx->pool_allocs[slot]) (void)hipFree(p);
+    ctx->pool_allocs[slot].clear();
+    P = PoolDev{};
+    return fail(ctx, FH_E_HIP, std::string("path pool allocation: ") + hipGetErrorString(e));
+  }
   P.capacity = capacity;
   return FH_OK;
 }
@@ -1198,6 +1210,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
 {
   if (!ctx->scene_loaded || !ctx->bvh_valid) return fail(ctx, FH_E_INVALID, "fh_render: scene not uploaded or BVH not built");
   if (ctx->width == 0 || ctx->height == 0 || !ctx->d_sample_count) return fail(ctx, FH_E_INVALID, "fh_render: resolution not set");
+  if (max_depth > 64) return fail(ctx, FH_E_INVALID, "fh_render: max_depth > 64 is not supported");
   if (ctx->n_owned == 0 || n_samples == 0) return FH_OK;
   uint32_t target = ctx->pool_target > ctx->n_owned ? ctx->pool_target : ctx->n_owned;
   uint32_t batch = target / ctx->n_owned;
@@ -1252,27 +1265,16 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   for (int k = 0; k + 1 < ctx->n_slots; ++k) FH_HIP(hipStreamWaitEvent(ctx->aux_stream[k], ctx->ev_enter, 0));
   int last_slot = 0;
 
-  if (max_depth > 64) return fail(ctx, FH_E_INVALID, "fh_render: max_depth > 64 is not supported");
-  hipDeviceProp_t prop;
-  FH_HIP(hipGetDeviceProperties(&prop, ctx->device));
-  // wave-cooperative triangle tests (default for the wide BVH); FH_COOP=0 selects the per-lane loop, FH_COOP_T the flush threshold
-  uint32_t coop_flush = 32u;
-  if (const char* e = getenv("FH_COOP_T")) { const int v = atoi(e); if (v >= 1 && v <= 64) coop_flush = (uint32_t)v; }
-  const char* coop_env = getenv("FH_COOP");
-  const bool coop = sc.use_bvh8 != 0 && sc.bvh8.n_tris < kCoopMaxTris && !(coop_env && coop_env[0] == '0');
-  // streaming form: FH_STREAM=0 falls back to one fixed batch per wave; FH_STREAM_GRID blocks, FH_STREAM_REFILL idle lanes
-  const char* stream_env = getenv("FH_STREAM");
-  const bool stream = coop && !(stream_env && stream_env[0] == '0');
-  // 6 workgroups (24 waves) per CU: all resident at the kernels' LDS budget (26 KB each)
-  uint32_t stream_grid = (uint32_t)prop.multiProcessorCount * 6u, stream_refill = 24u;
-  uint32_t env_tail_depth = 0;  // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail (developer switch)
-  if (const char* e = getenv("FH_TAIL_DEPTH")) env_tail_depth = (uint32_t)atoi(e);
-  bool sort_queues = true;  // FH_SORT=0: trace the bounce queues in the order the shade kernels emit them
-  if (const char* e = getenv("FH_SORT")) sort_queues = e[0] != '0';
-  uint32_t stream_chunk = 64u;  // queue entries a wave takes per global atomic (64/128 equal on big launches, 64 better on small ones)
-  if (const char* e = getenv("FH_STREAM_CHUNK")) { const int v = atoi(e); if (v >= 16 && v <= 65536) stream_chunk = (uint32_t)v; }
-  if (const char* e = getenv("FH_STREAM_GRID")) { const int v = atoi(e); if (v >= 8 && v <= 8192) stream_grid = (uint32_t)v & ~7u; }
-  if (const char* e = getenv("FH_STREAM_REFILL")) { const int v = atoi(e); if (v >= 1 && v <= 64) stream_refill = (uint32_t)v; }
+  // device facts and developer switches were read once at fh_ctx_create (context.h: Tunables)
+  const fh_ctx::Tunables& tun = ctx->tun;
+  const uint32_t coop_flush = tun.coop_flush;  // wave-cooperative triangle tests (default for the wide BVH): queued candidates that trigger a round
+  const bool coop = sc.use_bvh8 != 0 && sc.bvh8.n_tris < kCoopMaxTris && tun.coop;
+  const bool stream = coop && tun.stream;      // streaming form; FH_STREAM=0 falls back to one fixed batch per wave
+  // all workgroups of a streaming launch are resident: kStreamWgsPerCu of them fit a CU's LDS (fh_trace.h)
+  const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * (tun.stream_wgs_per_cu ? tun.stream_wgs_per_cu : kStreamWgsPerCu);
+  const uint32_t stream_refill = tun.stream_refill, stream_chunk = tun.stream_chunk;
+  const uint32_t env_tail_depth = tun.tail_depth;
+  const bool sort_queues = tun.sort_queues;
 
   for (uint32_t done = 0; done < n_samples; done += batch) {
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
@@ -1297,8 +1299,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     // bounces run as bounce-synchronous wavefront kernels; the survivors are finished by k_tail.  Adaptive mode picks the
     // first depth at which an earlier pass had at most kTailPaths survivors (counts come from an asynchronous snapshot of
     // the device counters: no host/device synchronisation)
-    uint32_t kTailPaths = 65536;
-    if (const char* e = getenv("FH_TAIL_PATHS")) { const int v = atoi(e); if (v >= 64) kTailPaths = (uint32_t)v; }
+    const uint32_t kTailPaths = tun.tail_paths;
     for (int k = 0; k < 3; ++k) {
       if (!(ctx->counters_in_flight[k] && hipEventQuery(ctx->ev_counters[k]) == hipSuccess)) continue;
       ctx->counters_in_flight[k] = false;
@@ -1319,7 +1320,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         pick = wd + more;
       }
       ctx->auto_wave_depth = pick;
-      if (getenv("FH_DEBUG_TAIL")) { fprintf(stderr, "[tail] slot %d wd %u pick %u survivors:", k, wd, pick); for (uint32_t d = 0; d <= wd; ++d) fprintf(stderr, " %u", ctx->h_counters[k][d * kCounterStride + CNT_RAD]); fprintf(stderr, "\n"); }
+      if (tun.debug_tail) { fprintf(stderr, "[tail] slot %d wd %u pick %u survivors:", k, wd, pick); for (uint32_t d = 0; d <= wd; ++d) fprintf(stderr, " %u", ctx->h_counters[k][d * kCounterStride + CNT_RAD]); fprintf(stderr, "\n"); }
     }
     uint32_t wave_depth = ctx->tail_depth ? ctx->tail_depth : ctx->auto_wave_depth;
     if (env_tail_depth) wave_depth = env_tail_depth;

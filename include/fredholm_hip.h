@@ -204,6 +204,16 @@ int fh_kat_sky(fh_ctx* ctx, uint32_t n, const float* dirs3, float* out3);       
 int fh_kat_hosek_state(fh_ctx* ctx, float* out30);                                  /* cooked cfg[3][9] + rad[3] */
 int fh_kat_camera(fh_ctx* ctx, const fh_camera* cam, uint32_t width, uint32_t height, uint32_t seed, uint32_t n, const uint32_t* pixel_idx, const uint32_t* n_spp, float* out6);
 int fh_kat_offset_origin(fh_ctx* ctx, uint32_t n, const float* p3, const float* n3, float* out3);
+/* small math blocks that have a reference-built counterpart (oracle/_ref/libref_lut_math_post.so); floats in / out per item:
+   ALBEDO_REFLECTION (w.y, roughness, F0) -> 1  lut.cu:985-992     ALBEDO_SHEEN (w.y, roughness) -> 1  lut.cu:1075-1081
+   ONB n.xyz -> tangent.xyz bitangent.xyz  math.cu:7-17            TO_LOCAL / TO_WORLD (v, t, n, b) -> 3  math.cu:19-35
+   SPHERICAL w.xyz -> (theta, phi)  math.cu:111-118                LUMINANCE rgb -> 1  math.cu:90-93
+   UCHIMURA rgb -> 3  post-process.h:78-111                        LINEAR_TO_SRGB rgb -> 3  post-process.h:19-29
+   EXPOSURE (aperture, shutter, ISO) -> (EV100, exposure)  post-process.h:114-125
+   TONE_MAP_TAIL (r, g, b, ISO) -> 3  post-process.cu:139-152      POST_LUMINANCE rgb -> 1  post-process.h:13-16 */
+enum { FH_MATH_ALBEDO_REFLECTION = 0, FH_MATH_ALBEDO_SHEEN, FH_MATH_ONB, FH_MATH_TO_LOCAL, FH_MATH_TO_WORLD, FH_MATH_SPHERICAL, FH_MATH_LUMINANCE,
+       FH_MATH_UCHIMURA, FH_MATH_LINEAR_TO_SRGB, FH_MATH_EXPOSURE, FH_MATH_TONE_MAP_TAIL, FH_MATH_POST_LUMINANCE, FH_MATH_COUNT };
+int fh_kat_math(fh_ctx* ctx, int kind, uint32_t n, const float* in, float* out);
 
 #ifdef __cplusplus
 }

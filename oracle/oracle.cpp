@@ -1062,6 +1062,47 @@ void orc_post_process(const float* in, float* hi, float* tmp, int w, int h, int 
   const PostParams pp{use_bloom, threshold, sigma, iso, ca};
   post_process(in, hi, tmp, w, h, pp, out);
 }
+// small math blocks with a reference-built counterpart (oracle/_ref/libref_lut_math_post.so); kinds and widths as fh_kat_math (include/fredholm_hip.h)
+void orc_math(int kind, int n, const float* in, float* out)
+{
+  static const int widths[12][2] = {{3, 1}, {2, 1}, {3, 6}, {12, 3}, {12, 3}, {3, 2}, {3, 1}, {3, 3}, {3, 3}, {3, 2}, {4, 3}, {3, 1}};
+  if (kind < 0 || kind >= 12) return;
+  const int si = widths[kind][0], so = widths[kind][1];
+  for (int i = 0; i < n; ++i) {
+    const float* a = in + (size_t)si * i;
+    float* o = out + (size_t)so * i;
+    switch (kind) {
+      case 0: o[0] = lut_reflection_albedo(v3(0.0f, a[0], 0.0f), a[1], a[2]); break;   // lut.cu:985-992
+      case 1: o[0] = lut_sheen_albedo(v3(0.0f, a[0], 0.0f), a[1]); break;             // lut.cu:1075-1081
+      case 2: { V3 t, b; onb(v3(a[0], a[1], a[2]), t, b); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = b.x; o[4] = b.y; o[5] = b.z; break; }  // math.cu:7-17
+      case 3: { const V3 r = to_local(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+      case 4: { const V3 r = to_world(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+      case 5: {  // math.cu:111-118, as env_radiance evaluates it
+        o[0] = fhe_acos(clampf(a[1], -1.0f, 1.0f));
+        float phi = fhe_atan2(a[2], a[0]);
+        if (phi < 0) phi += 2.0f * kPi;
+        o[1] = phi;
+        break;
+      }
+      case 6: o[0] = luminance(v3(a[0], a[1], a[2])); break;                            // math.cu:90-93
+      case 7: o[0] = uchimura1(a[0]); o[1] = uchimura1(a[1]); o[2] = uchimura1(a[2]); break;  // post-process.h:78-111
+      case 8: o[0] = srgb1(a[0]); o[1] = srgb1(a[1]); o[2] = srgb1(a[2]); break;        // post-process.h:19-29
+      case 9: {                                                                        // post-process.h:114-125
+        o[0] = fhe_log2((float)(a[0] * a[0] / a[1] * 100.0 / a[2]));
+        const float max_lum = (float)(1.2 * fhe_pow(2.0f, o[0]));
+        o[1] = 1.0f / max_lum;
+        break;
+      }
+      case 10: {                                                                       // post-process.cu:139-152
+        const float ev = fhe_log2((float)(1.0f * 1.0f / 1.0f * 100.0 / a[3]));
+        const float e = 1.0f / (float)(1.2 * fhe_pow(2.0f, ev));
+        o[0] = srgb1(uchimura1(a[0] * e)); o[1] = srgb1(uchimura1(a[1] * e)); o[2] = srgb1(uchimura1(a[2] * e));
+        break;
+      }
+      case 11: o[0] = luminance(v3(a[0], a[1], a[2])); break;                           // post-process.h:13-16
+    }
+  }
+}
 void orc_tex2d(const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb, int n, const float* uv, float* out)
 {
   float lut[256];

@@ -152,6 +152,85 @@ def ref_hosek_radiance(turbidity, albedo, elevation, theta, gamma):
     return out
 
 
+MATH_KINDS = {"albedo_reflection": (0, 3, 1), "albedo_sheen": (1, 2, 1), "onb": (2, 3, 6), "to_local": (3, 12, 3), "to_world": (4, 12, 3), "spherical": (5, 3, 2),
+              "luminance": (6, 3, 1), "uchimura": (7, 3, 3), "linear_to_srgb": (8, 3, 3), "exposure": (9, 3, 2), "tone_map_tail": (10, 4, 3), "post_luminance": (11, 3, 1)}
+
+
+def math(kind, x):
+    """the checker's restatement of the small math blocks (kinds and widths as fh_kat_math)"""
+    k, si, so = MATH_KINDS[kind]
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, si)
+    out = np.zeros((x.shape[0], so), dtype=np.float32)
+    lib().orc_math(k, int(x.shape[0]), _p(x), _p(out))
+    return out
+
+
+_REF_LMP = None
+
+
+def ref_lut_math_post():
+    """oracle/_ref/libref_lut_math_post.so: the reference's own lut.cu, math.cu and kernels/post-process.h built for the host by oracle/Makefile;
+    None when it was not built (no /root/reference at build time)"""
+    global _REF_LMP
+    if _REF_LMP is None:
+        path = os.path.join(_HERE, "_ref", "libref_lut_math_post.so")
+        if not os.path.exists(path):
+            return None
+        _REF_LMP = C.CDLL(path)
+    return _REF_LMP
+
+
+def ref_math(kind, x):
+    """the REFERENCE's own functions for the same kinds, run on the host (glibc libm where they call powf / expf / acosf ...)"""
+    R = ref_lut_math_post()
+    k, si, so = MATH_KINDS[kind]
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, si)
+    n = int(x.shape[0])
+    out = np.zeros((n, so), dtype=np.float32)
+    col = lambda j: np.ascontiguousarray(x[:, j])
+    blk = lambda j: np.ascontiguousarray(x[:, 3 * j:3 * j + 3])
+    if kind == "albedo_reflection":
+        a, b, c = col(0), col(1), col(2); R.ref_albedo_reflection(n, _p(a), _p(b), _p(c), _p(out))
+    elif kind == "albedo_sheen":
+        a, b = col(0), col(1); R.ref_albedo_sheen(n, _p(a), _p(b), _p(out))
+    elif kind == "onb":
+        t, b = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        R.ref_orthonormal_basis(n, _p(x), _p(t), _p(b)); out = np.concatenate([t, b], axis=1)
+    elif kind in ("to_local", "to_world"):
+        v, t, nn, b = blk(0), blk(1), blk(2), blk(3)
+        getattr(R, "ref_world_to_local" if kind == "to_local" else "ref_local_to_world")(n, _p(v), _p(t), _p(nn), _p(b), _p(out))
+    elif kind == "spherical":
+        R.ref_cartesian_to_spherical(n, _p(x), _p(out))
+    elif kind == "luminance":
+        R.ref_rgb_to_luminance(n, _p(x), _p(out))
+    elif kind == "post_luminance":
+        R.ref_post_luminance(n, _p(x), _p(out))
+    elif kind == "uchimura":
+        R.ref_uchimura(n, _p(x), _p(out))
+    elif kind == "linear_to_srgb":
+        R.ref_linear_to_srgb(n, _p(x), _p(out))
+    elif kind == "exposure":
+        a, b, c = col(0), col(1), col(2)
+        ev, ex = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        R.ref_exposure(n, _p(a), _p(b), _p(c), _p(ev), _p(ex)); out = np.stack([ev, ex], axis=1)
+    elif kind == "tone_map_tail":
+        iso = np.unique(x[:, 3])
+        for v in iso:  # the reference's kernel takes one ISO per launch
+            m = x[:, 3] == v
+            rgb = np.ascontiguousarray(x[m, :3]); o = np.zeros_like(rgb)
+            R.ref_tone_map_tail(int(rgb.shape[0]), C.c_float(float(v)), _p(rgb), _p(o)); out[m] = o
+    else:
+        raise KeyError(kind)
+    return out
+
+
+def ref_lut_tables():
+    R = ref_lut_math_post()
+    a, b = np.zeros(512, np.float32), np.zeros(256, np.float32)
+    R.ref_lut_entries(_p(a), _p(b))
+    return a, b
+
+
 def hosek_radiance(state30, sun_dir, intensity, dirs):
     d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
     out = np.zeros_like(d)

@@ -371,6 +371,41 @@ def test_exotic_lobes_render_matches_checker(oracle):
     _assert_image_parity(gpu["beauty"], ref["beauty"])
 
 
+def test_full_metal_seen_from_behind_still_transmits(oracle):
+    """bsdf.cu:56-62 zeroes metalness / specular / sheen / diffuse on a back-face hit, so an open metalness = 1 surface with transmission
+    (or thin-walled subsurface) refracts when seen from behind: the host-side lobe mask must keep those two lobes (capi.hip: material_lobes)"""
+    base = scenes.cornell_box()
+    nm = base["materials"].shape[0]
+    mats = default_materials(nm + 2)
+    mats[:nm] = base["materials"]
+    mats["metalness"][nm] = 1.0
+    mats["transmission"][nm] = 0.5
+    mats["metalness"][nm + 1] = 1.0
+    mats["subsurface"][nm + 1] = 0.6
+    mats["thin_walled"][nm + 1] = 1.0
+    mats["subsurface_color"][nm + 1] = (0.8, 0.5, 0.3)
+    # two open quads in mid-room whose geometric normal points away from the camera (camera at z = +1 looking down -z)
+    quads = np.array([[-0.9, 0.2, 0.2], [-0.9, 1.6, 0.2], [-0.1, 1.6, 0.2], [-0.9, 0.2, 0.2], [-0.1, 1.6, 0.2], [-0.1, 0.2, 0.2],
+                      [0.1, 0.2, 0.1], [0.1, 1.6, 0.1], [0.9, 1.6, 0.1], [0.1, 0.2, 0.1], [0.9, 1.6, 0.1], [0.9, 0.2, 0.1]], np.float32)
+    nrm = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (12, 1))
+    assert np.allclose(np.cross(quads[1] - quads[0], quads[2] - quads[0]) / 1.12, [0, 0, -1])
+    nv = base["vertices"].shape[0]
+    sc = dict(base)
+    sc["vertices"] = np.concatenate([base["vertices"], quads])
+    sc["normals"] = np.concatenate([base["normals"], nrm])
+    sc["texcoords"] = np.concatenate([base["texcoords"], np.tile(np.array([[0, 0], [1, 0], [0, 1]], np.float32), (4, 1))])
+    sc["indices"] = np.concatenate([base["indices"], (nv + np.arange(12, dtype=np.uint32)).reshape(4, 3)])
+    sc["material_ids"] = np.concatenate([base["material_ids"], np.array([nm, nm, nm + 1, nm + 1], np.uint32)])
+    sc["materials"] = mats
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    gpu, ref = _render_pair(oracle, sc, cam, 64, 48, launches=3, spp_per_launch=1, depth=5)
+    for name in ("beauty", "normal", "albedo"):
+        _assert_image_parity(gpu[name], ref[name])
+    # paths do continue through the quads: with the two lobes dropped every path died there (f = 0) and the region behind stayed darker
+    S = oracle.Scene(sc)
+    assert np.isfinite(ref["beauty"][..., :3]).all() and S.n_lights() == 2
+
+
 def test_small_path_pool_and_batching_do_not_change_results(oracle):
     sc = scenes.cornell_box()
     cam = F.Camera(**scenes.CORNELL_CAMERA)
