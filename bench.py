@@ -250,7 +250,7 @@ def main():
                          "note": "rank 0 shard" if world > 1 else "whole frame"},
             "kernel_ms_per_step": {"trace_closest": round(timed["trace_closest_ms"] / args.steps, 3), "trace_secondary": round(timed["trace_shadow_ms"] / args.steps, 3),
                                    "shade": round(timed["shade_ms"] / args.steps, 3), "tail": round(timed["tail_ms"] / args.steps, 3), "render_total": round(timed["render_ms"] / args.steps, 3)},
-            "bvh": {"build_ms": round(timed["bvh_build_ms"], 2), "nodes": timed["bvh_nodes"], "node_bytes": timed["bvh_node_bytes"], "tri_bytes": timed["bvh_tri_bytes"]},
+            "bvh": {"build_ms": round(timed["bvh_build_ms"], 2), "nodes": timed["bvh_nodes"], "node_bytes": timed["bvh_node_bytes"], "tri_bytes": timed["bvh_tri_bytes"], "depth": timed["bvh_depth"]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc)

@@ -857,7 +857,9 @@ int bvh_build_device(fh_ctx* ctx)
     uint32_t level_count = 1;
     Work8* cur = work_a.p;
     Work8* nxt = work_b.p;
+    uint32_t levels = 0;
     for (int level = 0; level < 64 && level_count > 0; ++level) {
+      ++levels;
       FH_HIP(hipMemsetAsync(counters.p + 2, 0, 4, st));
       hipLaunchKernelGGL(k_collapse8, dim3((level_count + 63) / 64), dim3(64), 0, st, cur, level_count, c_children, c_ranges, c_node_lo, c_node_hi, leaf_lo.p, leaf_hi.p, pad,
                          leaf_max8, absorb8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2);
@@ -869,6 +871,8 @@ int bvh_build_device(fh_ctx* ctx)
     FH_HIP(hipMemcpyAsync(final_counters, counters.p, 8, hipMemcpyDeviceToHost, st));
     FH_HIP(hipStreamSynchronize(st));
     if (final_counters[1] != nr) return fail(ctx, FH_E_INVALID, "BVH8 collapse lost triangles");
+    if (levels > (uint32_t)kBvh8Stack) return fail(ctx, FH_E_UNSUPPORTED, "BVH8 deeper than the traversal stack (48 levels)");
+    ctx->bvh8_depth = levels;
     hipLaunchKernelGGL(k_emit_tris8, dim3(rblocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_map.p, nr, ctx->d_bvh8_tris, ref_face);
     FH_HIP(hipGetLastError());
     FH_HIP(hipStreamSynchronize(st));
@@ -883,6 +887,7 @@ int bvh_build_device(fh_ctx* ctx)
   ctx->stats.bvh_nodes = ctx->use_bvh8 ? ctx->bvh8_n_nodes : ctx->bvh2_n_nodes;
   ctx->stats.bvh_node_bytes = ctx->use_bvh8 ? 80ull * ctx->bvh8_n_nodes : 64ull * ctx->bvh2_n_nodes;
   ctx->stats.bvh_tri_bytes = 48ull * (ctx->use_bvh8 ? ctx->bvh8_n_tris : ctx->bvh2_n_tris);
+  ctx->stats.bvh_depth = ctx->use_bvh8 ? ctx->bvh8_depth : 0;
   return FH_OK;
 }
 

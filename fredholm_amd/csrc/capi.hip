@@ -237,11 +237,11 @@ int fh_ctx_create(int device, fh_ctx** out)
   if (hipMalloc((void**)&ctx->d_sobol, kSobolMatricesBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_refl, kLutReflectionBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_sheen, kLutSheenBytes) != hipSuccess) return bail("hipMalloc failed");
-  if (hipMalloc((void**)&ctx->d_trace_counters, 26 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
+  if (hipMalloc((void**)&ctx->d_trace_counters, 32 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
   if (hipMemcpy(ctx->d_sobol, kSobolMatrices, kSobolMatricesBytes, hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
   (void)hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
-  (void)hipMemset(ctx->d_trace_counters, 0, 26 * sizeof(unsigned long long));
+  (void)hipMemset(ctx->d_trace_counters, 0, 32 * sizeof(unsigned long long));
   for (int k = 0; k < 2; ++k)
     if (hipStreamCreateWithFlags(&ctx->aux_stream[k], hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
   for (int k = 0; k < 3; ++k) {
@@ -550,6 +550,9 @@ int fh_sync(fh_ctx* ctx)
       if (s.kind == 0) ctx->stats.trace_closest_ms += ms;
       else if (s.kind == 1) ctx->stats.trace_shadow_ms += ms;
       else if (s.kind == 3) ctx->stats.tail_ms += ms;
+      else if (s.kind == 4) ctx->stats.generate_ms += ms;
+      else if (s.kind == 5) ctx->stats.accumulate_ms += ms;
+      else if (s.kind == 6) ctx->stats.queue_ms += ms;
       else ctx->stats.shade_ms += ms;
     }
     ctx->event_pool.push_back(s.a);
@@ -557,12 +560,13 @@ int fh_sync(fh_ctx* ctx)
   }
   ctx->spans.clear();
   if (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) {
-    unsigned long long c[26];
+    unsigned long long c[32];
     FH_HIP(hipMemcpy(c, ctx->d_trace_counters, sizeof c, hipMemcpyDeviceToHost));
     ctx->stats.wave_node_steps_closest = c[6]; ctx->stats.wave_tri_steps_closest = c[7]; ctx->stats.wave_node_steps_shadow = c[8]; ctx->stats.wave_tri_steps_shadow = c[9];
     for (int k = 0; k < 8; ++k) { ctx->stats.hist_nodes_closest[k] = c[10 + k]; ctx->stats.hist_nodes_shadow[k] = c[18 + k]; }
     ctx->stats.nodes_closest = c[0]; ctx->stats.tris_closest = c[1]; ctx->stats.rays_closest = c[2];
     ctx->stats.nodes_shadow = c[3]; ctx->stats.tris_shadow = c[4]; ctx->stats.rays_shadow = c[5];
+    ctx->stats.shaded_hits = c[26];
   }
   return FH_OK;
 }
@@ -578,10 +582,10 @@ int fh_reset_stats(fh_ctx* ctx)
 {
   CTX_CHECK(ctx);
   const double build_ms = ctx->stats.bvh_build_ms;
-  const uint64_t nodes = ctx->stats.bvh_nodes, nb = ctx->stats.bvh_node_bytes, tb = ctx->stats.bvh_tri_bytes;
+  const uint64_t nodes = ctx->stats.bvh_nodes, nb = ctx->stats.bvh_node_bytes, tb = ctx->stats.bvh_tri_bytes, depth = ctx->stats.bvh_depth;
   ctx->stats = fh_stats{};
-  ctx->stats.bvh_build_ms = build_ms; ctx->stats.bvh_nodes = nodes; ctx->stats.bvh_node_bytes = nb; ctx->stats.bvh_tri_bytes = tb;
-  FH_HIP(hipMemsetAsync(ctx->d_trace_counters, 0, 26 * sizeof(unsigned long long), ctx->stream));
+  ctx->stats.bvh_build_ms = build_ms; ctx->stats.bvh_nodes = nodes; ctx->stats.bvh_node_bytes = nb; ctx->stats.bvh_tri_bytes = tb; ctx->stats.bvh_depth = depth;
+  FH_HIP(hipMemsetAsync(ctx->d_trace_counters, 0, 32 * sizeof(unsigned long long), ctx->stream));
   return FH_OK;
 }
 

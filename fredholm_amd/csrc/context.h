@@ -55,6 +55,8 @@ struct fh_ctx {
   uint4* d_bvh8_nodes = nullptr;
   float4* d_bvh8_tris = nullptr;
   uint32_t bvh8_n_nodes = 0, bvh8_n_tris = 0;
+  uint32_t bvh8_depth = 0;            // levels of the wide tree = most entries a traversal stack can hold
+  uint32_t lds_configured_bytes = 0;  // dynamic-LDS size the traversal kernels were last configured for (render.hip)
   bool use_bvh8 = false;
   int builder_choice = 0;  // 0 = not decided for this scene, 1 = radix tree (LBVH), 2 = PLOC; decided at the first build after an upload
   double bvh_build_ms = 0.0;

@@ -245,17 +245,17 @@ FH_D Ray8 ray8_prepare(const RayPre& rp, f3 d)
 struct WaveSteps { uint32_t node = 0, tri = 0; };
 FH_D bool first_active_lane() { return __lane_id() == (uint32_t)__ffsll((long long)__ballot(true)) - 1u; }
 
-// Traversal stack of node groups: the first kLdsStack entries of every lane live in LDS (column layout
-// [entry][thread], conflict-free), deeper entries in the lane's private (scratch) array.  A wide tree of a
-// million triangles is ~8 levels deep and each level leaves at most one pending group, so the spill part is cold.
-#ifndef FH_LDS_STACK
-#define FH_LDS_STACK 6
-#endif
-constexpr int kLdsStack = FH_LDS_STACK;  // 6 entries x 256 lanes x 8 B + the cooperative-test records = 26 KB per workgroup: six workgroups per CU
+// Traversal stack of node groups.  A group is pushed only while descending into one of its children, so the stack never holds
+// more entries than the tree has levels; the builder records that number (fh_ctx::bvh8_depth) and refuses trees deeper than kBvh8Stack.
+//   GroupStack<true>   every entry in LDS, column layout [entry][thread] (conflict-free); the launcher sizes the dynamic LDS for the
+//                      tree's depth, so there is no overflow path and no private array: `sp` lives in a register.  (The first build kept
+//                      6 entries in LDS and the rest in a private array; the compiler then kept the whole object, `sp` included, in scratch:
+//                      every push and pop started with a scratch load on the dependent path -- 408 B of scratch, ~1 GB of writes per launch.)
+//   GroupStack<false>  a private array, for the per-lane loops of k_tail and the batch queries.
 template <bool LDS>
 struct GroupStack;
 template <>
-struct GroupStack<false> {  // all entries in the lane's private (scratch) array
+struct GroupStack<false> {
   int sp = 0;
   uint2 spill[kBvh8Stack];
   FH_D GroupStack(uint2*, int) {}
@@ -263,24 +263,16 @@ struct GroupStack<false> {  // all entries in the lane's private (scratch) array
   FH_D uint2 pop() { return spill[--sp]; }
 };
 template <>
-struct GroupStack<true> {  // first kLdsStack entries in LDS (column [entry][thread]), the rest in scratch
+struct GroupStack<true> {
   uint2* lds;
   int stride;
   int sp = 0;
-  uint2 spill[kBvh8Stack];
   FH_D GroupStack(uint2* lds_column, int lds_stride) : lds(lds_column), stride(lds_stride) {}
-  FH_D void push(uint2 g)
-  {
-    if (sp < kLdsStack) lds[sp * stride] = g;
-    else if (sp < kBvh8Stack + kLdsStack) spill[sp - kLdsStack] = g;
-    ++sp;
-  }
-  FH_D uint2 pop()
-  {
-    --sp;
-    return sp < kLdsStack ? lds[sp * stride] : spill[sp - kLdsStack];
-  }
+  FH_D void push(uint2 g) { lds[sp * stride] = g; ++sp; }
+  FH_D uint2 pop() { --sp; return lds[sp * stride]; }
 };
+// dynamic LDS of one 256-thread workgroup whose lanes keep `depth` stack entries there
+FH_HD uint32_t lds_stack_bytes(uint32_t depth) { return depth * 256u * (uint32_t)sizeof(uint2); }
 
 template <bool ANY_HIT, bool COUNT, bool LDS = false, bool ALPHA = false>
 FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr, uint2* lds_column = nullptr,
@@ -358,9 +350,8 @@ struct CoopLds {            // per-wave slices of the block's LDS
   uint32_t* queue;          // [kCoopQueue]
 };
 constexpr uint32_t kCoopLdsBytesPerWave = 64 * 32 + 64 * 8 + 64 * 8 + kCoopQueue * 4;
-// LDS of one 256-thread workgroup of a streaming traversal kernel, and how many of them a CU (160 KiB of LDS, 32 waves) holds
-constexpr uint32_t kStreamLdsBytes = (uint32_t)kLdsStack * 256u * 8u + 4u * kCoopLdsBytesPerWave;
-constexpr uint32_t kStreamWgsPerCu = 163840u / kStreamLdsBytes < 8u ? 163840u / kStreamLdsBytes : 8u;
+// static LDS of one 256-thread workgroup of a cooperative / streaming traversal kernel (the stack comes on top, dynamically)
+constexpr uint32_t kCoopLdsBytesPerBlock = 4u * kCoopLdsBytesPerWave;
 FH_D CoopLds coop_lds(unsigned char* block_lds, uint32_t wave_in_block)
 {
   unsigned char* b = block_lds + (size_t)wave_in_block * kCoopLdsBytesPerWave;

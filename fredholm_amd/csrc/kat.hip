@@ -147,6 +147,29 @@ __global__ void k_math(int kind, BsdfTables lut, uint32_t n, const float* in, ui
   }
 }
 
+// measured HBM bandwidth of this GPU: the denominator SURVEY.md 8(d) asks the roofline fraction to be quoted against.  A streaming
+// float4 read (every lane 16 B per load, grid-stride, four loads in flight) and a float4 copy over buffers far larger than the 256 MiB
+// Infinity Cache.
+__global__ void __launch_bounds__(256) k_bw_read(const float4* src, size_t n, float* sink)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float4 a = make_float4(0, 0, 0, 0), b = a, c = a, d = a;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const float4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+    a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w; b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+    c.x += v2.x; c.y += v2.y; c.z += v2.z; c.w += v2.w; d.x += v3.x; d.y += v3.y; d.z += v3.z; d.w += v3.w;
+  }
+  for (; i < n; i += stride) { const float4 v = src[i]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  const float r = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
+  if (r == 123.456f) sink[0] = r;  // never true for the zero-filled source; keeps the loads alive
+}
+__global__ void __launch_bounds__(256) k_bw_copy(const float4* src, float4* dst, size_t n)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 __global__ void k_sky(HosekSky st, f3 sun, float intensity, uint32_t n, const float* d, float* out)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -384,6 +407,35 @@ int fh_kat_math(fh_ctx* ctx, int kind, uint32_t n, const float* in, float* out)
   hipLaunchKernelGGL(k_math, dim3(blocks(n)), dim3(256), 0, ctx->stream, kind, lut, n, a.p, si, o.p, so);
   FH_HIP(hipStreamSynchronize(ctx->stream));
   FH_HIP(o.down(out));
+  return FH_OK;
+}
+int fh_measure_bandwidth(fh_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gbs, double* copy_gbs)
+{
+  KCTX(ctx);
+  if (!read_gbs || !copy_gbs || bytes < (1ull << 20) || iters == 0) return fail(ctx, FH_E_INVALID, "fh_measure_bandwidth: bad argument");
+  const size_t n = (size_t)(bytes / 16);
+  Tmp<float4> a, b;
+  Tmp<float> sink;
+  FH_HIP(a.up(nullptr, n)); FH_HIP(b.up(nullptr, n)); FH_HIP(sink.up(nullptr, 1));
+  FH_HIP(hipMemsetAsync(a.p, 0, n * 16, ctx->stream));
+  FH_HIP(hipMemsetAsync(b.p, 0, n * 16, ctx->stream));
+  const dim3 grid(ctx->tun.n_cus * 8u), block(256);
+  hipEvent_t e0, e1, e2;
+  FH_HIP(hipEventCreate(&e0)); FH_HIP(hipEventCreate(&e1)); FH_HIP(hipEventCreate(&e2));
+  hipLaunchKernelGGL(k_bw_read, grid, block, 0, ctx->stream, (const float4*)a.p, n, sink.p);  // warm-up (page tables, clocks)
+  hipLaunchKernelGGL(k_bw_copy, grid, block, 0, ctx->stream, (const float4*)a.p, b.p, n);
+  FH_HIP(hipEventRecord(e0, ctx->stream));
+  for (uint32_t k = 0; k < iters; ++k) hipLaunchKernelGGL(k_bw_read, grid, block, 0, ctx->stream, (const float4*)((k & 1u) ? b.p : a.p), n, sink.p);
+  FH_HIP(hipEventRecord(e1, ctx->stream));
+  for (uint32_t k = 0; k < iters; ++k) hipLaunchKernelGGL(k_bw_copy, grid, block, 0, ctx->stream, (const float4*)((k & 1u) ? b.p : a.p), (k & 1u) ? a.p : b.p, n);
+  FH_HIP(hipEventRecord(e2, ctx->stream));
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  float ms_r = 0.0f, ms_c = 0.0f;
+  FH_HIP(hipEventElapsedTime(&ms_r, e0, e1));
+  FH_HIP(hipEventElapsedTime(&ms_c, e1, e2));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  *read_gbs = (double)n * 16.0 * iters / (ms_r * 1e-3) / 1e9;
+  *copy_gbs = 2.0 * (double)n * 16.0 * iters / (ms_c * 1e-3) / 1e9;  // bytes read + bytes written
   return FH_OK;
 }
 

@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, Po
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, chunk), tc.hist);
-  __shared__ uint2 lds_stack[kLdsStack * kBlock];  // first stack entries of every lane in LDS: 39.0 -> 33.4 ms per 256 spp against a scratch-only stack
+  extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // the traversal stack of every lane: [entry][thread], as many entries as the BVH has levels
   traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, Po
 // ------------------------------------------------------------------------------------------------
 // Sort the hits of this bounce into per-class queues.  Appends are aggregated per block: wave
 // ballot + popcount, a prefix over the block's waves in LDS, one atomic per block and class.
-__global__ void __launch_bounds__(kBlock) k_route(SceneDev sc, PoolDev pool, uint32_t depth, uint32_t n_classes)
+__global__ void __launch_bounds__(kBlock) k_route(SceneDev sc, PoolDev pool, uint32_t depth, uint32_t n_classes, unsigned long long* hit_counter)
 {
   __shared__ uint32_t wave_cnt[kMaxClasses][kBlock / 64];
   __shared__ uint32_t block_base[kMaxClasses];
@@ -304,6 +304,7 @@ __global__ void __launch_bounds__(kBlock) k_route(SceneDev sc, PoolDev pool, uin
       uint32_t total = 0;
       for (uint32_t w = 0; w < kBlock / 64; ++w) { const uint32_t v = wave_cnt[threadIdx.x][w]; wave_cnt[threadIdx.x][w] = total; total += v; }
       block_base[threadIdx.x] = total ? atomicAdd(&cnt[CNT_CLS + threadIdx.x], total) : 0u;
+      if (hit_counter && total) atomicAdd(hit_counter, (unsigned long long)total);  // instrumented runs: surface hits that get shaded
     }
     __syncthreads();
     if (cls < n_classes) pool.q_cls[(size_t)cls * pool.capacity + block_base[cls] + wave_cnt[cls][wave] + my_rank] = p;
@@ -760,7 +761,7 @@ FH_D f3 resolve_light_ray(const SceneDev& sc, const FrameDev& fr, f3 T, float co
 template <bool COUNT, bool WIDE, bool LIGHTS, bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc)
 {
-  __shared__ uint2 lds_stack[kLdsStack * kBlock];
+  extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
   constexpr bool has_lights = LIGHTS;
   uint32_t nn = 0, nt = 0, nr = 0;
@@ -807,7 +808,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_secondary_coop(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush)
 {
-  __shared__ uint2 lds_stack[kLdsStack * kBlock];
+  extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
   const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
@@ -924,7 +925,7 @@ struct SecondaryStream {
 template <bool COUNT, bool LIGHTS, bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk)
 {
-  __shared__ uint2 lds_stack[kLdsStack * kBlock];
+  extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
   const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
@@ -1206,6 +1207,31 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
   return FH_OK;
 }
 
+// Dynamic LDS beyond the default limit has to be announced per kernel (hipFuncAttributeMaxDynamicSharedMemorySize).  Only trees
+// deeper than 24 levels get there (24 x 2 KB + 14 KB static = 62 KB); done once per BVH depth, for every kernel that keeps its stack in LDS.
+int configure_traversal_lds(fh_ctx* ctx, uint32_t stack_bytes)
+{
+  if (stack_bytes + kCoopLdsBytesPerBlock > 64u * 1024u) {
+    hipError_t err = hipSuccess;
+    auto set = [&](const void* fn) { const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stack_bytes); if (e != hipSuccess) err = e; };
+    for (int c = 0; c < 2; ++c)
+      for (int a = 0; a < 2; ++a)
+        with_bool(c != 0, [&](auto C) { with_bool(a != 0, [&](auto A) {
+          set((const void*)k_trace_closest_stream<decltype(C)::value, decltype(A)::value>);
+          for (int l = 0; l < 2; ++l)
+            with_bool(l != 0, [&](auto Li) {
+              set((const void*)k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
+              set((const void*)k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
+              set((const void*)k_trace_secondary_static<decltype(C)::value, true, decltype(Li)::value, decltype(A)::value>);
+              set((const void*)k_trace_secondary_static<decltype(C)::value, false, decltype(Li)::value, decltype(A)::value>);
+            });
+        }); });
+    if (err != hipSuccess) return fail(ctx, FH_E_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(err));
+  }
+  ctx->lds_configured_bytes = stack_bytes;
+  return FH_OK;
+}
+
 int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_render_layers* layers, uint32_t n_samples, uint32_t max_depth, uint32_t seed)
 {
   if (!ctx->scene_loaded || !ctx->bvh_valid) return fail(ctx, FH_E_INVALID, "fh_render: scene not uploaded or BVH not built");
@@ -1270,8 +1296,18 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const uint32_t coop_flush = tun.coop_flush;  // wave-cooperative triangle tests (default for the wide BVH): queued candidates that trigger a round
   const bool coop = sc.use_bvh8 != 0 && sc.bvh8.n_tris < kCoopMaxTris && tun.coop;
   const bool stream = coop && tun.stream;      // streaming form; FH_STREAM=0 falls back to one fixed batch per wave
-  // all workgroups of a streaming launch are resident: kStreamWgsPerCu of them fit a CU's LDS (fh_trace.h)
-  const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * (tun.stream_wgs_per_cu ? tun.stream_wgs_per_cu : kStreamWgsPerCu);
+  // the traversal stack of every lane lives in LDS, one entry per level of the BVH (bvh_build.hip records the depth): no overflow path
+  const uint32_t stack_bytes = lds_stack_bytes(ctx->bvh8_depth < 2u ? 2u : ctx->bvh8_depth);
+  if (sc.use_bvh8 && stack_bytes + kCoopLdsBytesPerBlock > 160u * 1024u) return fail(ctx, FH_E_UNSUPPORTED, "fh_render: BVH too deep for the LDS traversal stack");
+  if (sc.use_bvh8 && ctx->lds_configured_bytes != stack_bytes) {  // kernels that may need more than the default 64 KB of LDS are told so once per BVH depth
+    const int rc = configure_traversal_lds(ctx, stack_bytes);
+    if (rc) return rc;
+  }
+  // all workgroups of a streaming launch are resident: as many per CU as its 160 KB of LDS hold (at most 6: the kernels' register budget)
+  uint32_t wgs_per_cu = (160u * 1024u) / (stack_bytes + kCoopLdsBytesPerBlock);
+  wgs_per_cu = wgs_per_cu > 6u ? 6u : (wgs_per_cu < 1u ? 1u : wgs_per_cu);
+  if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < wgs_per_cu) wgs_per_cu = tun.stream_wgs_per_cu;
+  const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_per_cu;
   const uint32_t stream_refill = tun.stream_refill, stream_chunk = tun.stream_chunk;
   const uint32_t env_tail_depth = tun.tail_depth;
   const bool sort_queues = tun.sort_queues;
@@ -1291,8 +1327,12 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     const PoolDev& pool = ctx->pool[slot];
     FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
     if (prev != slot && ctx->gen_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_gen[prev], 0));
-    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, n_paths);
-    hipLaunchKernelGGL(k_bump_issued, dim3((ctx->n_owned + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, nb);
+    {
+      Span sp(ctx, st, 4);
+      hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, n_paths);
+      hipLaunchKernelGGL(k_bump_issued, dim3((ctx->n_owned + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, nb);
+      ctx->stats.n_generate_launches++;
+    }
     FH_HIP(hipEventRecord(ctx->ev_gen[slot], st));
     ctx->gen_valid[slot] = true;
     ctx->stats.paths += n_paths;
@@ -1334,7 +1374,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         Span sp(ctx, st, 0);
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), 0, st, sc, pd, depth, tc_closest,
+            hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), stack_bytes, st, sc, pd, depth, tc_closest,
                                coop_flush, stream_refill, stream_chunk);
           }); });
         } else if (coop) {
@@ -1349,10 +1389,17 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         ctx->stats.n_closest_launches++;
       }
       {
+        Span sp(ctx, st, 6);
+        hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pd, depth, ctx->n_classes, count ? ctx->d_trace_counters + 26 : nullptr);
+      }
+      {
         Span sp(ctx, st, 2);
-        hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pd, depth, ctx->n_classes);
         for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pd, c, depth);
         if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pd);
+        ctx->stats.n_shade_launches += ctx->n_classes;
+      }
+      {
+        Span sp(ctx, st, 6);
         if (sort_queues) {
           // secondary rays of this bounce and the radiance rays of the next one, each into cell order
           sort_queue_by_cell(st, sort_blocks, pool.counters + depth * kCounterStride + CNT_SEC, pool.q_sec, pool.key_sec, pool.bins, pool.q_sec_sorted);
@@ -1371,17 +1418,17 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         Span sp(ctx, st, 1);
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), 0, st, sc,
+            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), stack_bytes, st, sc,
                                fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk);
           }); }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, fr, ps, depth, tc_shadow,
+            hipLaunchKernelGGL((k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), stack_bytes, st, sc, fr, ps, depth, tc_shadow,
                                coop_flush);
           }); }); });
         } else {
           with_bool(count, [&](auto C) { with_bool(sc.use_bvh8 != 0, [&](auto W) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_static<decltype(C)::value, decltype(W)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, fr, ps,
+            hipLaunchKernelGGL((k_trace_secondary_static<decltype(C)::value, decltype(W)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), stack_bytes, st, sc, fr, ps,
                                depth, tc_shadow);
           }); }); }); });
         }
@@ -1391,9 +1438,14 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     if (wave_depth < max_depth) {
       Span sp(ctx, st, 3);
       hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), 0, st, sc, fr, pd, wave_depth);
+      ctx->stats.n_tail_launches++;
     }
     if (prev != slot && ctx->acc_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[prev], 0));
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb);
+    {
+      Span sp(ctx, st, 5);
+      hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb);
+      ctx->stats.n_accumulate_launches++;
+    }
     FH_HIP(hipEventRecord(ctx->ev_acc[slot], st));
     ctx->acc_valid[slot] = true;
     if (!ctx->counters_in_flight[slot] && ctx->h_counters[slot]) {

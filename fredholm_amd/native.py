@@ -81,7 +81,10 @@ class StatsC(C.Structure):
                 ("paths", C.c_uint64), ("bvh_build_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_node_bytes", C.c_uint64),
                 ("bvh_tri_bytes", C.c_uint64),
                 ("wave_node_steps_closest", C.c_uint64), ("wave_tri_steps_closest", C.c_uint64), ("wave_node_steps_shadow", C.c_uint64),
-                ("wave_tri_steps_shadow", C.c_uint64), ("hist_nodes_closest", C.c_uint64 * 8), ("hist_nodes_shadow", C.c_uint64 * 8), ("tail_ms", C.c_double)]
+                ("wave_tri_steps_shadow", C.c_uint64), ("hist_nodes_closest", C.c_uint64 * 8), ("hist_nodes_shadow", C.c_uint64 * 8), ("tail_ms", C.c_double),
+                ("generate_ms", C.c_double), ("accumulate_ms", C.c_double), ("queue_ms", C.c_double),
+                ("n_generate_launches", C.c_uint64), ("n_accumulate_launches", C.c_uint64), ("n_shade_launches", C.c_uint64), ("n_tail_launches", C.c_uint64),
+                ("shaded_hits", C.c_uint64), ("bvh_depth", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}
@@ -99,7 +102,7 @@ EXPORTS = [
     "fh_pack_owned", "fh_unpack_shard", "fh_render", "fh_sync", "fh_get_stats", "fh_reset_stats", "fh_post_process", "fh_malloc",
     "fh_free", "fh_memset", "fh_copy_to_device", "fh_copy_to_host", "fh_copy_on_device", "fh_image_load_rgba8", "fh_image_free", "fh_stream", "fh_trace_rays", "fh_kat_hash", "fh_kat_cmj",
     "fh_kat_sobol", "fh_kat_elementary", "fh_kat_warp", "fh_kat_bsdf", "fh_kat_sky", "fh_kat_hosek_state", "fh_kat_camera",
-    "fh_kat_offset_origin", "fh_kat_math",
+    "fh_kat_offset_origin", "fh_kat_math", "fh_measure_bandwidth",
 ]
 
 _lib = None

@@ -359,6 +359,12 @@ class Renderer:
                  "fh_post_process")
 
     # -- parity-test hooks
+    def measure_bandwidth(self, nbytes=1 << 30, iters=8):
+        """(read GB/s, copy GB/s) of this GPU's HBM, measured with streaming kernels (fh_measure_bandwidth)"""
+        r, c = C.c_double(0.0), C.c_double(0.0)
+        self._ck(N.lib().fh_measure_bandwidth(self._ctx, C.c_uint64(nbytes), C.c_uint32(iters), C.byref(r), C.byref(c)), "fh_measure_bandwidth")
+        return r.value, c.value
+
     def trace_rays(self, rays7, any_hit=False):
         r = np.ascontiguousarray(rays7, dtype=np.float32).reshape(-1, 7)
         tuv = np.zeros((r.shape[0], 3), dtype=np.float32)

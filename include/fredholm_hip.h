@@ -113,6 +113,10 @@ typedef struct fh_stats {
   /* instrumented build only: rays by number of node visits: <= 8, 16, 32, 64, 128, 256, 512, more */
   uint64_t hist_nodes_closest[8], hist_nodes_shadow[8];
   double tail_ms; /* summed HIP-event time of the k_tail launches */
+  double generate_ms, accumulate_ms, queue_ms; /* k_generate + k_bump_issued ; k_accumulate ; k_route + the cell sorts of the bounce queues */
+  uint64_t n_generate_launches, n_accumulate_launches, n_shade_launches, n_tail_launches;
+  uint64_t shaded_hits; /* surface hits shaded by the k_shade kernels (only when FH_FLAG_COUNT_TRAVERSAL) */
+  uint64_t bvh_depth;   /* levels of the wide BVH = entries of the LDS traversal stack */
 } fh_stats;
 
 #define FH_FLAG_TIME_KERNELS 1u    /* bracket traversal/shade launches with HIP events (fh_stats *_ms) */
@@ -214,6 +218,9 @@ int fh_kat_offset_origin(fh_ctx* ctx, uint32_t n, const float* p3, const float* 
 enum { FH_MATH_ALBEDO_REFLECTION = 0, FH_MATH_ALBEDO_SHEEN, FH_MATH_ONB, FH_MATH_TO_LOCAL, FH_MATH_TO_WORLD, FH_MATH_SPHERICAL, FH_MATH_LUMINANCE,
        FH_MATH_UCHIMURA, FH_MATH_LINEAR_TO_SRGB, FH_MATH_EXPOSURE, FH_MATH_TONE_MAP_TAIL, FH_MATH_POST_LUMINANCE, FH_MATH_COUNT };
 int fh_kat_math(fh_ctx* ctx, int kind, uint32_t n, const float* in, float* out);
+/* measured HBM bandwidth of this GPU (GB/s): a streaming float4 read and a float4 copy (read + written bytes) over `bytes`-sized buffers,
+   `iters` launches each.  The "measured HBM roofline" SURVEY.md 8(d) asks for; use buffers well beyond the 256 MiB Infinity Cache. */
+int fh_measure_bandwidth(fh_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gbs, double* copy_gbs);
 
 #ifdef __cplusplus
 }
