@@ -15,6 +15,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -626,6 +627,84 @@ __global__ void k_sah_sum(int n_inner, const float4* node_lo, const float4* node
   if ((threadIdx.x & 63) == 0 && a != 0.0) atomicAdd(sum, a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Refit of the wide tree.  When only the instance transforms change (Renderer::set_time: the reference rebuilds its IAS and leaves
+// the GAS alone, renderer.h:614-640) the topology of the flattened tree is kept: the triangle copies are refreshed from the moved
+// face records and the boxes are recomputed bottom up, level by level (levels are contiguous node ranges because the collapse is
+// breadth first), with the build's own padding and quantisation rules.  Hits do not depend on the shape of the tree (fh_trace.h), so a
+// refitted tree returns the same bits as a rebuilt one; what degrades is its quality, which bvh_build_device watches.
+__global__ void k_refresh_tris8(const float4* face_rec, uint32_t n, float4* tris)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = __float_as_uint(tris[3 * (size_t)i].w);
+  const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
+  tris[3 * (size_t)i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
+  tris[3 * (size_t)i + 1].x = b.x; tris[3 * (size_t)i + 1].y = b.y; tris[3 * (size_t)i + 1].z = b.z;  // .w keeps the alpha flag
+  tris[3 * (size_t)i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
+// full-precision box of every node of a freshly built tree, bottom up (the refit's starting state and its quality reference)
+__global__ void k_refit8_level(uint4* nodes, const float4* tris, float4* box, uint32_t begin, uint32_t end, float pad, int requantise)
+{
+  const uint32_t ni = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (ni >= end) return;
+  uint4* nd = nodes + 5 * (size_t)ni;
+  const uint4 n0 = nd[0], n1 = nd[1];
+  const uint32_t imask = n0.w >> 24, child_base = n1.x, tri_base = n1.y;
+  float lo[8][3], hi[8][3];
+  bool used[8];
+  float nlo[3] = {3e38f, 3e38f, 3e38f}, nhi[3] = {-3e38f, -3e38f, -3e38f};
+  for (int sl = 0; sl < 8; ++sl) {
+    const uint32_t m = ((sl < 4 ? n1.z : n1.w) >> (8 * (sl & 3))) & 0xffu;
+    used[sl] = m != 0u;
+    if (!used[sl]) continue;
+    if ((m >> 5) == 1u && (m & 0x1fu) >= 24u) {  // inner child: its own box, computed when its level was done (one padding already in it)
+      const uint32_t c = child_base + (uint32_t)__popc(imask & ((1u << sl) - 1u));
+      const float4 l = box[2 * (size_t)c], h = box[2 * (size_t)c + 1];
+      lo[sl][0] = l.x; lo[sl][1] = l.y; lo[sl][2] = l.z; hi[sl][0] = h.x; hi[sl][1] = h.y; hi[sl][2] = h.z;
+    } else {  // leaf child: bounds of its triangles, padded like the builder pads leaf boxes
+      const uint32_t cnt = (uint32_t)__popc(m >> 5), off = m & 0x1fu;
+      float l[3] = {3e38f, 3e38f, 3e38f}, h[3] = {-3e38f, -3e38f, -3e38f};
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const size_t t = 3 * (size_t)(tri_base + off + k);
+        const float4 a = tris[t], b = tris[t + 1], c = tris[t + 2];
+        l[0] = fminf(l[0], fminf(a.x, fminf(b.x, c.x))); l[1] = fminf(l[1], fminf(a.y, fminf(b.y, c.y))); l[2] = fminf(l[2], fminf(a.z, fminf(b.z, c.z)));
+        h[0] = fmaxf(h[0], fmaxf(a.x, fmaxf(b.x, c.x))); h[1] = fmaxf(h[1], fmaxf(a.y, fmaxf(b.y, c.y))); h[2] = fmaxf(h[2], fmaxf(a.z, fmaxf(b.z, c.z)));
+      }
+      for (int k = 0; k < 3; ++k) { lo[sl][k] = l[k] - pad; hi[sl][k] = h[k] + pad; }
+    }
+    for (int k = 0; k < 3; ++k) { nlo[k] = fminf(nlo[k], lo[sl][k]); nhi[k] = fmaxf(nhi[k], hi[sl][k]); }
+  }
+  box[2 * (size_t)ni] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);
+  box[2 * (size_t)ni + 1] = make_float4(nhi[0], nhi[1], nhi[2], 0.0f);
+  if (!requantise) return;
+  const uint32_t ex = quant_exponent(nhi[0] - nlo[0]), ey = quant_exponent(nhi[1] - nlo[1]), ez = quant_exponent(nhi[2] - nlo[2]);
+  const float is[3] = {1.0f / __uint_as_float(ex << 23), 1.0f / __uint_as_float(ey << 23), 1.0f / __uint_as_float(ez << 23)};
+  uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  for (int sl = 0; sl < 8; ++sl) {
+    if (!used[sl]) continue;
+    for (int k = 0; k < 3; ++k) {
+      const float vl = fminf(fmaxf(floorf((lo[sl][k] - nlo[k]) * is[k]), 0.0f), 255.0f), vh = fminf(fmaxf(ceilf((hi[sl][k] - nlo[k]) * is[k]), 0.0f), 255.0f);
+      q[k][sl >> 2] |= ((uint32_t)vl) << (8 * (sl & 3));
+      q[3 + k][sl >> 2] |= ((uint32_t)vh) << (8 * (sl & 3));
+    }
+  }
+  nd[0] = make_uint4(__float_as_uint(nlo[0]), __float_as_uint(nlo[1]), __float_as_uint(nlo[2]), ex | (ey << 8) | (ez << 16) | (imask << 24));
+  nd[2] = make_uint4(q[0][0], q[0][1], q[1][0], q[1][1]);
+  nd[3] = make_uint4(q[2][0], q[2][1], q[3][0], q[3][1]);
+  nd[4] = make_uint4(q[4][0], q[4][1], q[5][0], q[5][1]);
+}
+
+__global__ void k_box_area_sum(uint32_t n, const float4* box, double* sum)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  double a = 0.0;
+  if (i < n) a = (double)box_area(box[2 * (size_t)i], box[2 * (size_t)i + 1]);
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+  if ((threadIdx.x & 63) == 0 && a != 0.0) atomicAdd(sum, a);
+}
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -635,11 +714,62 @@ struct DevBuf {
 
 }  // namespace
 
+// boxes of all levels bottom up (requantise = 0: only the full-precision boxes of a freshly built tree), then the sum of the node areas
+static int refit_levels(fh_ctx* ctx, float pad, int requantise, double* area)
+{
+  hipStream_t st = ctx->stream;
+  const std::vector<uint32_t>& ls = ctx->bvh8_level_start;
+  for (size_t l = ls.size() - 1; l-- > 0;) {
+    const uint32_t begin = ls[l], end = ls[l + 1];
+    if (end > begin) hipLaunchKernelGGL(k_refit8_level, dim3((end - begin + 127) / 128), dim3(128), 0, st, ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_bvh8_box, begin, end, pad, requantise);
+  }
+  DevBuf<double> sum;
+  FH_HIP(sum.alloc(1));
+  FH_HIP(hipMemsetAsync(sum.p, 0, 8, st));
+  hipLaunchKernelGGL(k_box_area_sum, dim3((ctx->bvh8_n_nodes + 255) / 256), dim3(256), 0, st, ctx->bvh8_n_nodes, ctx->d_bvh8_box, sum.p);
+  FH_HIP(hipMemcpyAsync(area, sum.p, 8, hipMemcpyDeviceToHost, st));
+  FH_HIP(hipGetLastError());
+  FH_HIP(hipStreamSynchronize(st));
+  return FH_OK;
+}
+
 int bvh_build_device(fh_ctx* ctx)
 {
   const auto t_begin = std::chrono::steady_clock::now();
   hipStream_t st = ctx->stream;
   const uint32_t n = ctx->n_faces;
+  // ---- instance transforms changed, topology did not: refit (FH_REFIT=0 forces the full rebuild).  A refit whose boxes have grown to
+  // more than 1.5x the area the tree had when it was built is discarded for a rebuild: the instances have moved too far for the old topology.
+  if (ctx->refit_ok && ctx->use_bvh8 && ctx->d_bvh8_box && n && ctx->bvh8_n_tris == n && !(getenv("FH_REFIT") && getenv("FH_REFIT")[0] == '0')) {
+    DevBuf<float4> face_lo, face_hi;
+    DevBuf<int> bounds;
+    FH_HIP(face_lo.alloc(n)); FH_HIP(face_hi.alloc(n)); FH_HIP(bounds.alloc(6));
+    const int init_bounds[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    FH_HIP(hipMemcpyAsync(bounds.p, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_face_bounds, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_face_rec, n, face_lo.p, face_hi.p, bounds.p);
+    hipLaunchKernelGGL(k_refresh_tris8, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_face_rec, n, ctx->d_bvh8_tris);
+    int hb[6];
+    FH_HIP(hipMemcpyAsync(hb, bounds.p, sizeof hb, hipMemcpyDeviceToHost, st));
+    FH_HIP(hipStreamSynchronize(st));
+    float maxabs = 0.0f;
+    for (int k = 0; k < 6; ++k) maxabs = fmaxf(maxabs, fabsf(order_float(hb[k])));
+    const float pad = fmaxf(maxabs, 1e-3f) * (1.0f / 65536.0f);
+    double area = 0.0;
+    { const int rc = refit_levels(ctx, pad, 1, &area); if (rc) return rc; }
+    if (area <= 1.5 * ctx->bvh8_area_built) {
+      for (int k = 0; k < 3; ++k) { ctx->scene_lo[k] = order_float(hb[k]) - 2.0f * pad; ctx->scene_hi[k] = order_float(hb[3 + k]) + 2.0f * pad; }
+      ctx->bvh_valid = true;
+      ctx->n_refits++;
+      ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+      ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
+      if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[bvh] refit %u: node area %.4f (built %.4f), %.3f ms\n", ctx->n_refits, area, ctx->bvh8_area_built, ctx->bvh_build_ms);
+      return FH_OK;
+    }
+    if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[bvh] refit discarded: node area %.4f > 1.5 x %.4f, rebuilding\n", area, ctx->bvh8_area_built);
+  }
+  ctx->refit_ok = false;
+  if (ctx->d_bvh8_box) { (void)hipFree(ctx->d_bvh8_box); ctx->d_bvh8_box = nullptr; }
+  ctx->bvh8_level_start.clear();
   if (ctx->d_bvh2_nodes) { (void)hipFree(ctx->d_bvh2_nodes); ctx->d_bvh2_nodes = nullptr; }
   if (ctx->d_bvh2_tris) { (void)hipFree(ctx->d_bvh2_tris); ctx->d_bvh2_tris = nullptr; }
   if (ctx->d_bvh8_nodes) { (void)hipFree(ctx->d_bvh8_nodes); ctx->d_bvh8_nodes = nullptr; }
@@ -858,8 +988,10 @@ int bvh_build_device(fh_ctx* ctx)
     Work8* cur = work_a.p;
     Work8* nxt = work_b.p;
     uint32_t levels = 0;
+    std::vector<uint32_t> level_start{0u};
     for (int level = 0; level < 64 && level_count > 0; ++level) {
       ++levels;
+      level_start.push_back(level_start.back() + level_count);
       FH_HIP(hipMemsetAsync(counters.p + 2, 0, 4, st));
       hipLaunchKernelGGL(k_collapse8, dim3((level_count + 63) / 64), dim3(64), 0, st, cur, level_count, c_children, c_ranges, c_node_lo, c_node_hi, leaf_lo.p, leaf_hi.p, pad,
                          leaf_max8, absorb8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2);
@@ -879,6 +1011,16 @@ int bvh_build_device(fh_ctx* ctx)
     ctx->bvh8_n_nodes = final_counters[0];
     ctx->bvh8_n_tris = nr;
     ctx->use_bvh8 = true;
+    // what a later refit needs: the level ranges, the full-precision node boxes and the area the tree has now.  Split references carry
+    // clipped boxes that a moved triangle no longer has, so scenes that use them are rebuilt instead.
+    if (nr == n && level_start.back() == final_counters[0]) {
+      ctx->bvh8_level_start = level_start;
+      FH_HIP(hipMalloc((void**)&ctx->d_bvh8_box, sizeof(float4) * 2ull * final_counters[0]));
+      const int rc = refit_levels(ctx, pad, 0, &ctx->bvh8_area_built);
+      if (rc) return rc;
+      ctx->refit_ok = true;
+      ctx->n_refits = 0;
+    }
   }
   ctx->bvh_valid = true;
   ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

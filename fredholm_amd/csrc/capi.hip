@@ -51,21 +51,73 @@ bool material_textured(const fh_material& m)
 // two stay whenever their own parameters enable them.  specular / sheen / diffuse are zero on both sides of a full metal and are dropped.
 uint32_t material_lobes(const fh_material& m)
 {
-  // a texture on a parameter that switches lobes on or off makes the mask unknowable on the host: take every lobe
-  if (m.metalness_texture_id >= 0 || m.metallic_roughness_texture_id >= 0 || m.coat_texture_id >= 0 || m.specular_color_texture_id >= 0) return L_ALL;
+  // A texture on metalness (or the glTF metallic-roughness texture) makes metalness unknowable on the host: the metal lobe AND the lobes
+  // a non-metal needs are kept.  Lobes whose OWN switch is a constant zero stay dropped whatever the textures say: transmission, sheen and
+  // subsurface have no texture slot (shared.h:100-142), so a glTF material (scene.cpp:487-549 sets none of them) shades with
+  // coat? + metal + specular + diffuse instead of the generic seven-lobe kernel.
+  const bool metal_unknown = m.metalness_texture_id >= 0 || m.metallic_roughness_texture_id >= 0;
   uint32_t l = 0;
   const float coat = clampf(m.coat, 0.0f, 1.0f);
-  if (coat > 0.0f) l |= L_COAT;
-  if (m.metalness > 0.0f) l |= L_METAL;
-  const bool metal_full = m.metalness == 1.0f;
+  if (coat > 0.0f || m.coat_texture_id >= 0) l |= L_COAT;
+  if (m.metalness > 0.0f || metal_unknown) l |= L_METAL;
+  const bool metal_full = m.metalness == 1.0f && !metal_unknown;
   if (m.transmission > 0.0f) l |= L_TRANS;
   if (m.subsurface * m.thin_walled > 0.0f) l |= L_DT;
   if (!metal_full) {
-    if (m.specular * lum(mk3(m.specular_color[0], m.specular_color[1], m.specular_color[2])) > 0.0f) l |= L_SPEC;
+    if (m.specular_color_texture_id >= 0 || m.specular * lum(mk3(m.specular_color[0], m.specular_color[1], m.specular_color[2])) > 0.0f) l |= L_SPEC;
     if (m.sheen * lum(mk3(m.sheen_color[0], m.sheen_color[1], m.sheen_color[2])) != 0.0f) l |= L_SHEEN;
     if (m.diffuse > 0.0f) l |= L_DIFF;
   }
   return l;
+}
+
+// world-space face record of every face (layout: fh_device.h) from the object-space arrays and the instance transforms:
+// positions by object_to_world, normals by the transpose of world_to_object (shared.h:42-50), as pt.cu:141-179 does per hit
+__global__ void __launch_bounds__(256) k_face_records(uint32_t nf, const float* vertices, const float* normals, const float* texcoords, const uint32_t* indices, const uint2* meta,
+                                                      const float4* o2w, const float4* w2o, float4* rec)
+{
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const uint2 mi = meta[f];
+  m34 a, b;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { a.r[k] = o2w[3 * (size_t)mi.y + k]; b.r[k] = w2o[3 * (size_t)mi.y + k]; }
+  f3 p[3], n[3];
+  float uv[3][2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const size_t v = indices[3 * (size_t)f + k];
+    p[k] = xform_point(a, mk3(vertices[3 * v], vertices[3 * v + 1], vertices[3 * v + 2]));
+    n[k] = xform_normal(b, mk3(normals[3 * v], normals[3 * v + 1], normals[3 * v + 2]));
+    uv[k][0] = texcoords[2 * v];
+    uv[k][1] = texcoords[2 * v + 1];
+  }
+  float4* r = rec + 7 * (size_t)f;
+  r[0] = mk4(p[0], uv[0][0]); r[1] = mk4(p[1], uv[0][1]); r[2] = mk4(p[2], uv[1][0]);
+  r[3] = mk4(n[0], uv[1][1]); r[4] = mk4(n[1], uv[2][0]); r[5] = mk4(n[2], uv[2][1]);
+  r[6] = make_float4(__uint_as_float(mi.x), __uint_as_float(mi.y), 0.0f, 0.0f);
+}
+
+int transform_faces(fh_ctx* ctx)
+{
+  const uint32_t ni = (uint32_t)ctx->h_o2w.size() / 12;
+  if (ctx->n_xf_alloc < ni) {
+    if (ctx->d_o2w) (void)hipFree(ctx->d_o2w);
+    if (ctx->d_w2o) (void)hipFree(ctx->d_w2o);
+    ctx->d_o2w = ctx->d_w2o = nullptr; ctx->n_xf_alloc = 0;
+    FH_HIP(hipMalloc((void**)&ctx->d_o2w, 48ull * ni));
+    FH_HIP(hipMalloc((void**)&ctx->d_w2o, 48ull * ni));
+    ctx->n_xf_alloc = ni;
+  }
+  FH_HIP(hipMemcpyAsync(ctx->d_o2w, ctx->h_o2w.data(), 48ull * ni, hipMemcpyHostToDevice, ctx->stream));
+  FH_HIP(hipMemcpyAsync(ctx->d_w2o, ctx->h_w2o.data(), 48ull * ni, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->n_faces)
+    hipLaunchKernelGGL(k_face_records, dim3((ctx->n_faces + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_faces, ctx->d_obj_vertices, ctx->d_obj_normals, ctx->d_obj_texcoords, ctx->d_obj_indices,
+                       ctx->d_face_meta, ctx->d_o2w, ctx->d_w2o, ctx->d_face_rec);
+  FH_HIP(hipGetLastError());
+  FH_HIP(hipStreamSynchronize(ctx->stream));  // the host copies of the transforms may change right after this call
+  ctx->bvh_valid = false;
+  return FH_OK;
 }
 
 // Rebuild everything derived from the flat scene + transforms: face records, classes, lights.
@@ -98,34 +150,21 @@ int rebuild_device_scene(fh_ctx* ctx)
     for (uint32_t i = 0; i < nm; ++i)
       if (mats[i].cls == kMaxClasses - 1) ctx->class_lobes[kMaxClasses - 1] |= mats[i].lobes;
 
-  std::vector<float4> rec(7ull * nf);
+  // per-face class bytes, the light list and index validation on the host (cheap integer work); the world-space face records -- the
+  // transform of 3 positions and 3 normals per face -- on the device from the object-space arrays resident there, so that a frame of an
+  // animation (fh_set_transforms) uploads 96 bytes per instance instead of recomputing and re-uploading 112 bytes per face
   std::vector<uint8_t> cls(nf);
+  std::vector<uint2> meta(nf);
   std::vector<AreaLightDev> lights;
   bool any_alpha = false;
   for (uint32_t f = 0; f < nf; ++f) {
     const uint32_t inst = ctx->h_instance_ids.empty() ? 0u : ctx->h_instance_ids[f];
     if (inst >= ni) return fail(ctx, FH_E_INVALID, "instance id out of range");
-    const m34 o2w = load_m34(&ctx->h_o2w[12ull * inst]), w2o = load_m34(&ctx->h_w2o[12ull * inst]);
     const uint32_t mid = ctx->h_material_ids[f];
     if (mid >= nm) return fail(ctx, FH_E_INVALID, "material id out of range");
-    f3 p[3], n[3];
-    float uv[3][2];
-    for (int k = 0; k < 3; ++k) {
-      const uint32_t v = ctx->h_indices[3ull * f + k];
-      if (v >= nv) return fail(ctx, FH_E_INVALID, "vertex index out of range");
-      p[k] = xform_point(o2w, mk3(ctx->h_vertices[3ull * v], ctx->h_vertices[3ull * v + 1], ctx->h_vertices[3ull * v + 2]));
-      n[k] = xform_normal(w2o, mk3(ctx->h_normals[3ull * v], ctx->h_normals[3ull * v + 1], ctx->h_normals[3ull * v + 2]));
-      uv[k][0] = ctx->h_texcoords[2ull * v];
-      uv[k][1] = ctx->h_texcoords[2ull * v + 1];
-    }
-    float4* r = &rec[7ull * f];
-    r[0] = mk4(p[0], uv[0][0]); r[1] = mk4(p[1], uv[0][1]); r[2] = mk4(p[2], uv[1][0]);
-    r[3] = mk4(n[0], uv[1][1]); r[4] = mk4(n[1], uv[2][0]); r[5] = mk4(n[2], uv[2][1]);
-    uint32_t midbits = mid, instbits = inst;
-    float a, b;
-    std::memcpy(&a, &midbits, 4);
-    std::memcpy(&b, &instbits, 4);
-    r[6] = make_float4(a, b, 0.0f, 0.0f);
+    for (int k = 0; k < 3; ++k)
+      if (ctx->h_indices[3ull * f + k] >= nv) return fail(ctx, FH_E_INVALID, "vertex index out of range");
+    meta[f] = make_uint2(mid, inst);
     cls[f] = (uint8_t)(mats[mid].cls | (mats[mid].emissive ? 0x80u : 0u) | (mats[mid].alpha ? 0x40u : 0u));
     if (mats[mid].alpha) any_alpha = true;
     if (mats[mid].emissive) lights.push_back({f, mid});  // renderer.h:388-402, face order
@@ -134,20 +173,29 @@ int rebuild_device_scene(fh_ctx* ctx)
     if (ptr) { (void)hipFree(ptr); ptr = nullptr; }
     return hipMalloc((void**)&ptr, bytes ? bytes : 16);
   };
-  FH_HIP(re_alloc(ctx->d_face_rec, rec.size() * sizeof(float4)));
+  FH_HIP(re_alloc(ctx->d_face_rec, 7ull * nf * sizeof(float4)));
   FH_HIP(re_alloc(ctx->d_face_cls, cls.size()));
   FH_HIP(re_alloc(ctx->d_materials, mats.size() * sizeof(MaterialDev)));
   FH_HIP(re_alloc(ctx->d_lights, lights.size() * sizeof(AreaLightDev)));
-  FH_HIP(hipMemcpy(ctx->d_face_rec, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+  FH_HIP(re_alloc(ctx->d_obj_vertices, ctx->h_vertices.size() * sizeof(float)));
+  FH_HIP(re_alloc(ctx->d_obj_normals, ctx->h_normals.size() * sizeof(float)));
+  FH_HIP(re_alloc(ctx->d_obj_texcoords, ctx->h_texcoords.size() * sizeof(float)));
+  FH_HIP(re_alloc(ctx->d_obj_indices, ctx->h_indices.size() * sizeof(uint32_t)));
+  FH_HIP(re_alloc(ctx->d_face_meta, meta.size() * sizeof(uint2)));
   FH_HIP(hipMemcpy(ctx->d_face_cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
   FH_HIP(hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
   if (!lights.empty()) FH_HIP(hipMemcpy(ctx->d_lights, lights.data(), lights.size() * sizeof(AreaLightDev), hipMemcpyHostToDevice));
+  FH_HIP(hipMemcpy(ctx->d_obj_vertices, ctx->h_vertices.data(), ctx->h_vertices.size() * sizeof(float), hipMemcpyHostToDevice));
+  FH_HIP(hipMemcpy(ctx->d_obj_normals, ctx->h_normals.data(), ctx->h_normals.size() * sizeof(float), hipMemcpyHostToDevice));
+  FH_HIP(hipMemcpy(ctx->d_obj_texcoords, ctx->h_texcoords.data(), ctx->h_texcoords.size() * sizeof(float), hipMemcpyHostToDevice));
+  FH_HIP(hipMemcpy(ctx->d_obj_indices, ctx->h_indices.data(), ctx->h_indices.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  FH_HIP(hipMemcpy(ctx->d_face_meta, meta.data(), meta.size() * sizeof(uint2), hipMemcpyHostToDevice));
   ctx->n_faces = nf;
   ctx->n_lights = (uint32_t)lights.size();
   ctx->n_materials = nm;
   ctx->has_alpha = any_alpha;
-  ctx->bvh_valid = false;
-  return FH_OK;
+  ctx->refit_ok = false;  // new topology: the next build is a full one
+  return transform_faces(ctx);
 }
 
 // texels of all textures in one device blob + descriptors + the 256-entry sRGB table (cwl/texture.h:13-75 per texture)
@@ -285,7 +333,8 @@ int fh_ctx_destroy(fh_ctx* ctx)
   pool_release(ctx);
   void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
                   ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl,
-                  ctx->d_bloom_weights};
+                  ctx->d_bloom_weights, ctx->d_quirk_seen, ctx->d_quirk_aov, ctx->d_obj_vertices, ctx->d_obj_normals, ctx->d_obj_texcoords, ctx->d_obj_indices, ctx->d_face_meta, ctx->d_o2w, ctx->d_w2o,
+                  ctx->d_bvh8_box};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -380,9 +429,13 @@ int fh_set_transforms(fh_ctx* ctx, uint32_t n, const float* o2w, const float* w2
       std::memcmp(ctx->h_w2o.data(), w2o, 48ull * n) == 0)
     return FH_OK;
   (void)hipStreamSynchronize(ctx->stream);
+  for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(ctx->aux_stream[k]);  // no pass may still be reading the face records
+  uint32_t max_inst = 0;
+  for (uint32_t i : ctx->h_instance_ids) max_inst = i > max_inst ? i : max_inst;
+  if (max_inst >= n) return fail(ctx, FH_E_INVALID, "fh_set_transforms: fewer transforms than the scene has instances");
   ctx->h_o2w.assign(o2w, o2w + 12ull * n);
   ctx->h_w2o.assign(w2o, w2o + 12ull * n);
-  return rebuild_device_scene(ctx);
+  return transform_faces(ctx);  // topology, classes and lights are unchanged: only the world-space records move (and the BVH is refitted)
 }
 
 int fh_bvh_build(fh_ctx* ctx)

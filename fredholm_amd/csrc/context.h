@@ -34,6 +34,15 @@ struct fh_ctx {
   uint8_t* d_face_cls = nullptr;
   fh::MaterialDev* d_materials = nullptr;
   fh::AreaLightDev* d_lights = nullptr;
+  // object-space geometry resident on the device: the face records above are recomputed from it when the instance transforms change
+  float* d_obj_vertices = nullptr;
+  float* d_obj_normals = nullptr;
+  float* d_obj_texcoords = nullptr;
+  uint32_t* d_obj_indices = nullptr;
+  uint2* d_face_meta = nullptr;  // (material id, instance id) per face
+  float4* d_o2w = nullptr;       // 3 rows per instance
+  float4* d_w2o = nullptr;
+  uint32_t n_xf_alloc = 0;
   // textures (renderer.h:372-386): one device blob of texels + descriptors + the sRGB table
   std::vector<std::vector<uint8_t>> h_textures;
   std::vector<uint32_t> h_tex_w, h_tex_h, h_tex_srgb;
@@ -55,6 +64,12 @@ struct fh_ctx {
   uint4* d_bvh8_nodes = nullptr;
   float4* d_bvh8_tris = nullptr;
   uint32_t bvh8_n_nodes = 0, bvh8_n_tris = 0;
+  // kept after a full build so that a change of instance transforms refits the wide tree instead of rebuilding it (bvh_build.hip)
+  float4* d_bvh8_box = nullptr;             // full-precision (lo, hi) of every wide node
+  std::vector<uint32_t> bvh8_level_start;   // node index range of every level (levels are contiguous: the collapse is breadth first)
+  bool refit_ok = false;                    // topology unchanged since the last full build, no split references
+  double bvh8_area_built = 0.0;             // sum of the node areas right after the full build (quality reference for refits)
+  uint32_t n_refits = 0;
   uint32_t bvh8_depth = 0;            // levels of the wide tree = most entries a traversal stack can hold
   uint32_t lds_configured_bytes = 0;  // dynamic-LDS size the traversal kernels were last configured for (render.hip)
   bool use_bvh8 = false;
@@ -92,6 +107,11 @@ struct fh_ctx {
   hipEvent_t ev_gen[3] = {nullptr, nullptr, nullptr}, ev_acc[3] = {nullptr, nullptr, nullptr}, ev_enter = nullptr;
   bool gen_valid[3] = {false, false, false}, acc_valid[3] = {false, false, false};
   int n_slots = 2;  // passes in flight (FH_PIPELINE=0: 1, every pass on the main stream; =3: three)
+  int last_slot_used = 0;  // slot of the pass submitted last (what the next pass orders itself after)
+  // FH_FLAG_REFERENCE_FIRSTHIT (render.hip: k_firsthit_scan): per-pixel "a sample of this launch has hit something" + the AOVs of that hit
+  uint32_t* d_quirk_seen = nullptr;
+  float4* d_quirk_aov = nullptr;
+  size_t quirk_pixels = 0;
 
   // device facts and developer switches, read ONCE at fh_ctx_create (fh_render does no getenv / hipGetDeviceProperties)
   struct Tunables {

@@ -321,6 +321,7 @@ __global__ void __launch_bounds__(kBlock) k_miss_primary(FrameDev fr, PoolDev po
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const uint32_t p = q[i];
     if (__float_as_uint(pool.hit[p].w) != 0xffffffffu) continue;
+    if (pool.flags[p] & 4u) continue;  // bug-compat mode: an earlier sample of this launch already hit something (k_firsthit_scan)
     const f3 T = mk3(pool.thr[p]);
     const f3 d = mk3(pool.ray_d[p]);
     const f3 r = mk3(pool.rad[p]) + T * env_radiance(fr, d);
@@ -421,7 +422,7 @@ struct ShadeOut {
 
 template <uint32_t LOBES>
 FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& rows, const BounceSlots& bs, uint32_t depth, float4 hit, f3 rd, f3 T, f3 L, uint32_t image_idx, uint32_t n_spp,
-                    ShadeOut& out)
+                    ShadeOut& out, bool first = true)
 {
   const uint32_t has_lights = bs.has_lights;
   const uint32_t prim = __float_as_uint(hit.w);
@@ -468,7 +469,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
     onb(ns, tangent, bitangent);
   }
 
-  if (depth == 0) {  // first hit: AOVs and directly visible emitters (pt.cu:745-760)
+  if (depth == 0 && first) {  // first hit: AOVs and directly visible emitters (pt.cu:745-760); `first` is false only in the bug-compat mode (k_firsthit_scan)
     out.aov_position = x; out.aov_normal = ns; out.aov_albedo = sp.base_color; out.aov_u = tu; out.aov_v = tv;
     if (mat.emissive) {
       out.L = L + T * emission_of(sc, mat, tu, tv);
@@ -689,8 +690,9 @@ __global__ void __launch_bounds__(kBlock, FH_SHADE_BLOCKS) k_shade(SceneDev sc, 
     if (valid) {
       p = q[i];
       ShadeOut o;
-      shade_hit<LOBES>(sc, fr, rows, bs, depth, pool.hit[p], mk3(pool.ray_d[p]), mk3(pool.thr[p]), mk3(pool.rad[p]), pool.pixel[p], pool.nspp[p], o);
-      if (depth == 0) {
+      const bool first = depth != 0 || (pool.flags[p] & 4u) == 0u;
+      shade_hit<LOBES>(sc, fr, rows, bs, depth, pool.hit[p], mk3(pool.ray_d[p]), mk3(pool.thr[p]), mk3(pool.rad[p]), pool.pixel[p], pool.nspp[p], o, first);
+      if (depth == 0 && first) {
         pool.aov_position[p] = mk4(o.aov_position, 0.0f);
         pool.aov_normal[p] = mk4(o.aov_normal, 0.0f);
         pool.aov_albedo[p] = mk4(o.aov_albedo, 0.0f);
@@ -1021,7 +1023,34 @@ __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolD
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_accumulate(PoolDev pool, LayersDev layers, const uint32_t* owned, uint32_t n_owned, uint32_t n_batch)
+// FH_FLAG_REFERENCE_FIRSTHIT: the reference declares its payload outside the per-launch sample loop and never resets `firsthit`
+// (pt.cu:432-433), so within ONE launch of n_samples > 1 only the first sample that hits anything records AOVs and sees emitters directly
+// (:745-760), later primary misses add no sky (:509), and every sample averages the AOVs of that first hit again (:483-487).  The state is
+// one bit per pixel, carried across the passes of a launch: after the depth-0 trace this kernel walks each pixel's samples in order and marks
+// the paths that come after the first hitting one (flag 4).
+__global__ void __launch_bounds__(kBlock) k_firsthit_scan(PoolDev pool, const uint32_t* owned, uint32_t n_owned, uint32_t n_batch, uint32_t* seen_state)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_owned; i += gridDim.x * blockDim.x) {
+    const uint32_t image_idx = owned[i];
+    bool seen = seen_state[image_idx] != 0u;
+    for (uint32_t k = 0; k < n_batch; ++k) {
+      const uint32_t p = k * n_owned + i;
+      const uint32_t fl = pool.flags[p];
+      const bool in_queue = (fl & 2u) == 0u;  // otherwise the path ended in k_generate (missed the scene bounds): a primary miss
+      if (seen) {
+        pool.flags[p] = fl | 4u;
+        if (!in_queue) pool.rad[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // its sky contribution is dropped (pt.cu:509)
+      } else if (in_queue && __float_as_uint(pool.hit[p].w) != 0xffffffffu) {
+        seen = true;  // this sample is the launch's first hit: it behaves normally
+      }
+    }
+    seen_state[image_idx] = seen ? 1u : 0u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool QUIRK>
+__global__ void __launch_bounds__(kBlock) k_accumulate(PoolDev pool, LayersDev layers, const uint32_t* owned, uint32_t n_owned, uint32_t n_batch, float4* carry)
 {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_owned; i += gridDim.x * blockDim.x) {
     const uint32_t image_idx = owned[i];
@@ -1030,12 +1059,19 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(PoolDev pool, LayersDev l
     float depth = layers.depth[image_idx];
     const float4 tc4 = layers.texcoord[image_idx];
     float tcx = tc4.x, tcy = tc4.y;
+    // bug-compat mode: the payload's AOVs persist from the launch's first hit (pt.cu:483-487); carried across the passes of the launch
+    f3 apos = mk3(0.0f), anrm = mk3(0.0f), aalb = mk3(0.0f);
+    float au = 0.0f, av = 0.0f, ad = 0.0f;
+    if (QUIRK) {
+      apos = mk3(carry[4 * (size_t)image_idx]); anrm = mk3(carry[4 * (size_t)image_idx + 1]); aalb = mk3(carry[4 * (size_t)image_idx + 2]);
+      const float4 td = carry[4 * (size_t)image_idx + 3];
+      au = td.x; av = td.y; ad = td.z;
+    }
     for (uint32_t k = 0; k < n_batch; ++k) {
       const uint32_t p = k * n_owned + i;
       const f3 L = mk3(pool.rad[p]);
       const f3 radiance = bad3(L) ? mk3(0.0f) : L;
-      f3 apos = mk3(0.0f), anrm = mk3(0.0f), aalb = mk3(0.0f);
-      float au = 0.0f, av = 0.0f, ad = 0.0f;
+      if (!QUIRK) { apos = mk3(0.0f); anrm = mk3(0.0f); aalb = mk3(0.0f); au = av = ad = 0.0f; }
       if (pool.flags[p] & 1u) {
         apos = mk3(pool.aov_position[p]);
         anrm = mk3(pool.aov_normal[p]);
@@ -1053,6 +1089,10 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(PoolDev pool, LayersDev l
       tcy = coef * (fn * tcy + av);
       albedo = coef * (fn * albedo + aalb);
       n_spp++;
+    }
+    if (QUIRK) {
+      carry[4 * (size_t)image_idx] = mk4(apos, 0.0f); carry[4 * (size_t)image_idx + 1] = mk4(anrm, 0.0f); carry[4 * (size_t)image_idx + 2] = mk4(aalb, 0.0f);
+      carry[4 * (size_t)image_idx + 3] = make_float4(au, av, ad, 0.0f);
     }
     layers.sample_count[image_idx] = n_spp;
     layers.beauty[image_idx] = mk4(beauty, 1.0f);
@@ -1098,7 +1138,8 @@ void dispatch_shade(hipStream_t st, uint32_t grid, uint32_t lobes, const SceneDe
   if ((lobes & ~(uint32_t)L_DIFF) == 0) return launch_shade<L_DIFF>(st, grid, sc, fr, pool, cls, depth);
   if ((lobes & ~(uint32_t)L_METAL) == 0) return launch_shade<L_METAL>(st, grid, sc, fr, pool, cls, depth);
   if ((lobes & ~(uint32_t)(L_SPEC | L_DIFF)) == 0) return launch_shade<L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth);
-  if ((lobes & ~(uint32_t)(L_METAL | L_SPEC | L_DIFF)) == 0) return launch_shade<L_METAL | L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth);
+  if ((lobes & ~(uint32_t)(L_METAL | L_SPEC | L_DIFF)) == 0) return launch_shade<L_METAL | L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth);  // glTF metallic-roughness materials
+  if ((lobes & ~(uint32_t)(L_COAT | L_METAL | L_SPEC | L_DIFF)) == 0) return launch_shade<L_COAT | L_METAL | L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth);  // ... with KHR_materials_clearcoat
   return launch_shade<L_ALL>(st, grid, sc, fr, pool, cls, depth);
 }
 
@@ -1285,6 +1326,21 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2, ctx->d_trace_counters + 6, ctx->d_trace_counters + 7, ctx->d_trace_counters + 10};
   TraceCounters tc_shadow{ctx->d_trace_counters + 3, ctx->d_trace_counters + 4, ctx->d_trace_counters + 5, ctx->d_trace_counters + 8, ctx->d_trace_counters + 9, ctx->d_trace_counters + 18};
 
+  // FH_FLAG_REFERENCE_FIRSTHIT with more than one sample per launch: per-pixel state carried through the launch, passes run one after the other
+  const bool quirk = (ctx->flags & FH_FLAG_REFERENCE_FIRSTHIT) != 0 && n_samples > 1;
+  if (quirk) {
+    const size_t px = (size_t)ctx->width * ctx->height;
+    if (ctx->quirk_pixels != px) {
+      if (ctx->d_quirk_seen) (void)hipFree(ctx->d_quirk_seen);
+      if (ctx->d_quirk_aov) (void)hipFree(ctx->d_quirk_aov);
+      ctx->d_quirk_seen = nullptr; ctx->d_quirk_aov = nullptr; ctx->quirk_pixels = 0;
+      FH_HIP(hipMalloc((void**)&ctx->d_quirk_seen, px * sizeof(uint32_t)));
+      FH_HIP(hipMalloc((void**)&ctx->d_quirk_aov, px * 4 * sizeof(float4)));
+      ctx->quirk_pixels = px;
+    }
+    FH_HIP(hipMemsetAsync(ctx->d_quirk_seen, 0, px * sizeof(uint32_t), ctx->stream));   // a launch starts with firsthit = true and a zeroed payload
+    FH_HIP(hipMemsetAsync(ctx->d_quirk_aov, 0, px * 4 * sizeof(float4), ctx->stream));
+  }
   if (!ctx->render_pending) { (void)hipEventRecord(ctx->ev_render_begin, ctx->stream); ctx->render_pending = true; }
   // whatever the caller queued on the main stream before this call (clears, uploads) comes first on the second stream too
   FH_HIP(hipEventRecord(ctx->ev_enter, ctx->stream));
@@ -1319,8 +1375,13 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     // n_slots passes in flight (two by default): pass j lives in pool j % n_slots on the stream of that slot.  Only two things order consecutive passes: the sample
     // indices (k_generate reads what k_bump_issued of the pass before wrote) and the running means (k_accumulate of pass j
     // follows k_accumulate of pass j - 1, so the floating-point result is that of a serial run)
-    const int slot = (int)(ctx->pass_seq % (unsigned long long)ctx->n_slots), prev = (slot + ctx->n_slots - 1) % ctx->n_slots;
+    // (the bug-compat mode keeps every pass on the main stream: a pass needs the first-hit state the pass before it left)
+    // FH_FLAG_SERIAL_PASSES does the same for measurements: kernels then run alone on the GPU and their HIP-event spans are kernel times
+    const bool serial = quirk || (ctx->flags & FH_FLAG_SERIAL_PASSES) != 0;
+    const int n_slots = serial ? 1 : ctx->n_slots;
+    const int slot = serial ? 0 : (int)(ctx->pass_seq % (unsigned long long)n_slots), prev = serial ? ctx->last_slot_used : (slot + n_slots - 1) % n_slots;
     ctx->pass_seq++;
+    ctx->last_slot_used = slot;
     hipStream_t st = slot ? ctx->aux_stream[slot - 1] : ctx->stream;
     last_slot = slot;
     { const int rc = pool_ensure(ctx, slot, ctx->n_owned * batch); if (rc) return rc; }
@@ -1388,6 +1449,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         }
         ctx->stats.n_closest_launches++;
       }
+      if (quirk && depth == 0) hipLaunchKernelGGL(k_firsthit_scan, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pd, ctx->d_owned, ctx->n_owned, nb, ctx->d_quirk_seen);
       {
         Span sp(ctx, st, 6);
         hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pd, depth, ctx->n_classes, count ? ctx->d_trace_counters + 26 : nullptr);
@@ -1443,7 +1505,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     if (prev != slot && ctx->acc_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[prev], 0));
     {
       Span sp(ctx, st, 5);
-      hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb);
+      if (quirk) hipLaunchKernelGGL(k_accumulate<true>, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb, ctx->d_quirk_aov);
+      else hipLaunchKernelGGL(k_accumulate<false>, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb, (float4*)nullptr);
       ctx->stats.n_accumulate_launches++;
     }
     FH_HIP(hipEventRecord(ctx->ev_acc[slot], st));

@@ -10,6 +10,8 @@ LIB_PATH = os.environ.get("FH_LIB") or os.path.join(_HERE, "libfredholm_hip.so")
 FH_OK = 0
 FLAG_TIME_KERNELS = 1
 FLAG_COUNT_TRAVERSAL = 2
+FLAG_SERIAL_PASSES = 8
+FLAG_REFERENCE_FIRSTHIT = 4  # one fh_render(n_samples = k) = ONE reference launch of k samples, firsthit quirk included (pt.cu:432-433)
 
 MATERIAL_DTYPE = np.dtype([
     ("diffuse", "f4"), ("base_color", "f4", 3), ("base_color_texture_id", "i4"), ("diffuse_roughness", "f4"),

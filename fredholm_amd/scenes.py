@@ -137,6 +137,22 @@ def triangle_soup(n_tris=1_000_000, edge_scale=0.02):
     return _finish(v.reshape(-1, 3), mats, m)
 
 
+def soup_with_emitters(n_tris=1_000_000, edge_scale=0.02):
+    """BASELINE configs[4] stand-in (the rtcamp8 asset is not in the tree -- "C3 geometry + Cornell emitters"):
+    the triangle soup plus the Cornell ceiling panel (2 emissive triangles = 2 area lights, emission (17, 12, 4)) above it, facing down."""
+    sc = triangle_soup(n_tris, edge_scale)
+    panel = np.asarray(_quad((-0.6, 1.3, -0.6), (0.6, 1.3, -0.6), (0.6, 1.3, 0.6), (-0.6, 1.3, 0.6)), dtype=np.float32)  # normal -y
+    nm = sc["materials"].shape[0]
+    mats = default_materials(nm + 1)
+    mats[:nm] = sc["materials"]
+    mats["base_color"][nm] = (0.78, 0.78, 0.78)
+    mats["emission"][nm] = 1.0
+    mats["emission_color"][nm] = (17.0, 12.0, 4.0)
+    verts = np.concatenate([sc["vertices"], panel])
+    ids = np.concatenate([sc["material_ids"], np.asarray([nm, nm], np.uint32)])
+    return _finish(verts, ids, mats)
+
+
 SOUP_CAMERA = dict(origin=(0.0, 0.0, 3.0), fov=np.radians(60.0), F=100.0, focus=10000.0)
 SOUP_SUN = (-0.1, 1.0, 0.1)  # rtcamp8.cpp:142-146
 

@@ -121,6 +121,14 @@ typedef struct fh_stats {
 
 #define FH_FLAG_TIME_KERNELS 1u    /* bracket traversal/shade launches with HIP events (fh_stats *_ms) */
 #define FH_FLAG_COUNT_TRAVERSAL 2u /* instrumented traversal kernels: count node visits / triangle tests */
+/* bug-compatible multi-sample launches.  fh_render(n_samples = k) is by default k one-sample launches.  With this flag it reproduces
+ * what ONE reference launch of k samples computes: the reference never resets payload.firsthit inside a launch (pt.cu:432-433), so only
+ * the first sample of the launch that hits anything records AOVs / sees emitters directly (:745-760), primary misses after it add no sky
+ * (:509) and every sample averages that first hit's AOVs again (:483-487).  rtcamp8 renders 16 samples per launch (rtcamp8.cpp:183-189). */
+#define FH_FLAG_REFERENCE_FIRSTHIT 4u
+/* run the passes of fh_render one after the other on the main stream instead of two in flight: slower, but every kernel then runs alone
+ * on the GPU, so the HIP-event times of FH_FLAG_TIME_KERNELS are kernel times (with passes in flight they include the other stream's work) */
+#define FH_FLAG_SERIAL_PASSES 8u
 
 /* -- context: replaces optwl::Context + Renderer ctor/dtor (optwl.h:41-81, renderer.h:32-122) */
 int fh_ctx_create(int device, fh_ctx** out);

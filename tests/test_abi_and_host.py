@@ -453,6 +453,38 @@ def test_gltf_scene_graph_and_animation_match_between_cpp_and_python(tmp_path, s
     np.testing.assert_allclose(np.asarray(S.m_camera_transform)[:3, 3], [0.05, 1.0, 1.2])
 
 
+def test_sponza_class_gltf_loads_identically_through_both_loaders(tmp_path, scene_dump):
+    """BASELINE configs[3] asset class (fredholm_amd/scenes_sponza.py): ~277 k triangles after instancing, 26 PNG + baseline-JPEG textures
+    (4:4:4 / 4:2:0 / 4:2:2, restart intervals, every PNG filter), alpha cut-outs, metallic-roughness + normal maps, clearcoat, a
+    three-level node hierarchy with rotations and non-uniform scales, a camera node -- through the C++ loader (include/fredholm/scene.h)
+    and the Python one (fredholm_amd/scene.py), byte for byte"""
+    from fredholm_amd import scenes_sponza as SS
+    from fredholm_amd.scene import Scene
+    gltf = tmp_path / "sponza_like.gltf"
+    info = SS.write_sponza_gltf(str(gltf))
+    assert 250_000 <= info["triangles"] <= 300_000 and info["textures"] >= 20 and info["jpeg"] >= 8 and info["png"] >= 8 and info["nodes"] > 80
+    S = Scene()
+    S.load_model(str(gltf))
+    assert len(S.m_indices) == info["triangles"] and len(S.m_textures) == info["textures"] and S.m_has_camera_transform
+    want = _scene_chunks(S)
+    got = scene_dump(tmp_path / "dump.bin", -1.0, gltf)
+    names = ["vertices", "normals", "texcoords", "indices", "material_ids", "instance_ids", "materials", "o2w", "w2o", "camera", "submesh_offsets", "submesh_n_faces", "texture headers"]
+    assert len(got) == len(want)
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert a == b, names[k] if k < len(names) else f"texture {k - len(names)} ({S.m_textures[k - len(names)]['rgba8'].shape})"
+    # what the asset is supposed to exercise
+    m = S.m_materials
+    assert (m["base_color_texture_id"] >= 0).sum() >= 10 and (m["metallic_roughness_texture_id"] >= 0).sum() >= 6 and (m["normalmap_texture_id"] >= 0).sum() >= 6
+    assert (m["coat"] > 0).any() and (m["metalness"] == 1).any()
+    leaf = S.m_textures[int(m["base_color_texture_id"][8])]["rgba8"]
+    assert (leaf[..., 3] == 0).any() and (leaf[..., 3] == 255).any()  # the cut-out lives in the base colour's alpha (pt.cu:567-575)
+    o2w, _ = S.transforms_3x4()
+    lin = o2w.reshape(-1, 3, 4)[:, :, :3]
+    det = np.linalg.det(lin.astype(np.float64))
+    assert len(o2w) == len(S.m_submesh_offsets) > 70 and (np.abs(det - 1.0) > 0.05).any() and (np.abs(lin[:, 0, 2]) > 0.5).any()  # scaled and rotated instances
+    np.testing.assert_allclose(np.asarray(S.m_camera_transform)[:3, 3], SS.SPONZA_CAMERA["origin"], atol=1e-6)
+
+
 def test_obj_plus_camera_gltf_composition(tmp_path, scene_dump):
     """rtcamp8.cpp:114-115: load_scene(obj) then load_scene(camera gltf, clear=false)"""
     from fredholm_amd.scene import Scene

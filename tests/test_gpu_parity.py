@@ -406,6 +406,149 @@ def test_full_metal_seen_from_behind_still_transmits(oracle):
     assert np.isfinite(ref["beauty"][..., :3]).all() and S.n_lights() == 2
 
 
+@pytest.mark.parametrize("scene_name", ["cornell_towards_light", "soup_sky", "textured_cornell"])
+def test_reference_firsthit_bug_compat_mode(oracle, scene_name):
+    """FH_FLAG_REFERENCE_FIRSTHIT: fh_render(n_samples = 16) equals ONE reference launch of 16 samples (rtcamp8.cpp:183-189), in which
+    payload.firsthit is never reset (pt.cu:432-433, :509, :745-760) -- the checker's multi-sample launch reproduces that (test_oracle_anchors).
+    Three launches, so that the carried state is reset per launch; a pool of 4 samples per pixel, so that it is carried across passes."""
+    w, h, k, depth = 48, 40, 16, 4
+    bg = (0.1, 0.2, 0.4)
+    if scene_name == "cornell_towards_light":
+        sc, cam = scenes.cornell_box(), F.Camera(origin=(0.0, 1.2, 0.0), fov=0.5 * np.pi, F=100.0, focus=1e4, forward=(0.0, 1.0, -0.001))
+        setup = lambda x: None
+    elif scene_name == "soup_sky":
+        sc, cam = scenes.triangle_soup(20000, 0.08), F.Camera(**scenes.SOUP_CAMERA)
+
+        def setup(x):
+            x.set_directional_light((0, 0, 0), scenes.SOUP_SUN, 0.0)
+            x.load_arhosek_sky(3.0, 0.3)
+    else:
+        sc, cam = scenes.textured_cornell_box(), F.Camera(**scenes.CORNELL_CAMERA)
+        setup = lambda x: None
+    r = F.Renderer(0)
+    r.set_path_pool(w * h * 4)
+    r.load_scene(sc)
+    r.build_ias()
+    S = oracle.Scene(sc)
+    setup(r)
+    setup(S)
+    r.set_resolution(w, h)
+    L, Lo = F.RenderLayer(r, w, h), S.new_layers(w, h)
+    r.set_flags(N.FLAG_REFERENCE_FIRSTHIT)
+    for _ in range(3):
+        r.render(cam, bg, L, k, depth)
+        S.render(cam.params(), w, h, Lo, k, depth, bg=bg, n_threads=8)  # one launch of k samples
+    r.wait_for_completion()
+    quirk = {n: L.download(n) for n in F.RenderLayer.NAMES}
+    for name in F.RenderLayer.NAMES:
+        _assert_image_parity(quirk[name], Lo[name])
+    # and it is a different image from the default mode (k one-sample launches), which stays what it was
+    r.set_flags(0)
+    L.clear()
+    r.init_render_states()
+    Lo1 = S.new_layers(w, h)
+    for _ in range(3):
+        r.render(cam, bg, L, k, depth)
+        for _ in range(k):
+            S.render(cam.params(), w, h, Lo1, 1, depth, bg=bg, n_threads=8)
+    r.wait_for_completion()
+    plain = L.download("beauty")
+    _assert_image_parity(plain, Lo1["beauty"])
+    assert not _same(plain, quirk["beauty"])
+    # one sample per launch: the flag changes nothing
+    r.set_flags(N.FLAG_REFERENCE_FIRSTHIT)
+    L.clear()
+    r.init_render_states()
+    for _ in range(3 * k):
+        r.render(cam, bg, L, 1, depth)
+    r.wait_for_completion()
+    assert _same(L.download("beauty"), plain)
+    r.close()
+
+
+def test_moving_instances_refit_the_tree_and_match_checker_and_rebuild(oracle, monkeypatch):
+    """Renderer::set_time only moves instances (renderer.h:614-640: the reference rebuilds its IAS, never a GAS).  The flattened tree is
+    refitted then (bvh_build.hip: face records re-derived on the device, triangle copies refreshed, boxes recomputed bottom up) -- at three
+    animation times the refitted tree, a tree rebuilt from scratch and the checker agree bit for bit, on rays and on rendered frames; a
+    motion that blows the boxes up falls back to the rebuild by itself."""
+    base = scenes.triangle_soup(24000, 0.06)
+    nf = base["indices"].shape[0]
+    inst = (np.arange(nf) * 4 // nf).astype(np.uint32)  # four rigid bodies
+
+    def xforms(t):
+        o2w, w2o = np.zeros((4, 12), np.float32), np.zeros((4, 12), np.float32)
+        for k in range(4):
+            a = 0.35 * t * (k + 1)
+            c, s_ = np.cos(a), np.sin(a)
+            R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]) @ np.diag([1.0, 1.0 + 0.1 * k * t, 1.0])
+            T = np.array([0.15 * k * t, 0.05 * t * (k - 1.5), -0.1 * t * k])
+            M = np.eye(4)
+            M[:3, :3], M[:3, 3] = R, T
+            o2w[k] = M[:3].astype(np.float32).reshape(-1)
+            w2o[k] = np.linalg.inv(M)[:3].astype(np.float32).reshape(-1)
+        return o2w, w2o
+
+    sc = dict(base, instance_ids=inst)
+    sc["object_to_world"], sc["world_to_object"] = xforms(0.0)
+    cam = F.Camera(**scenes.SOUP_CAMERA)
+    w, h = 64, 40
+    r = F.Renderer(0)
+    r.load_scene(sc)
+    r.build_ias()
+    r.load_arhosek_sky(3.0, 0.3)
+    r.set_resolution(w, h)
+    L = F.RenderLayer(r, w, h)
+    rng = np.random.default_rng(8)
+    rays = _rays(rng, 30000, -1.4, 1.4)
+    refits = 0
+    for t in (0.4, 1.0, 1.7):
+        o2w, w2o = xforms(t)
+        r.set_transforms(o2w, w2o)
+        r.build_ias()                       # refit
+        st = r.stats()
+        tuv, prim = r.trace_rays(rays)
+        L.clear()
+        r.init_render_states()
+        r.render(cam, (0, 0, 0), L, 2, 6)
+        r.wait_for_completion()
+        img = L.download("beauty")
+        # the checker on the moved scene
+        sct = dict(sc, object_to_world=o2w, world_to_object=w2o)
+        S = oracle.Scene(sct)
+        S.load_arhosek_sky(3.0, 0.3)
+        tuv_o, prim_o = S.trace(rays)
+        assert np.array_equal(prim, prim_o) and np.array_equal(_bits(tuv), _bits(tuv_o)), t
+        Lo = S.new_layers(w, h)
+        for _ in range(2):
+            S.render(cam.params(), w, h, Lo, 1, 6, n_threads=8)
+        _assert_image_parity(img, Lo["beauty"])
+        # a renderer that rebuilds from scratch
+        monkeypatch.setenv("FH_REFIT", "0")
+        r.set_transforms(*xforms(0.0))
+        r.build_ias()
+        r.set_transforms(o2w, w2o)
+        r.build_ias()
+        monkeypatch.delenv("FH_REFIT")
+        tuv_b, prim_b = r.trace_rays(rays)
+        assert np.array_equal(prim, prim_b) and np.array_equal(_bits(tuv), _bits(tuv_b))
+        refits += 1
+    assert st["bvh_depth"] >= 4 and refits == 3
+    # exploding the bodies apart makes the refitted boxes much larger than the built ones: the library rebuilds by itself, same hits
+    o2w, w2o = xforms(0.0)
+    for k in range(4):
+        o2w[k, 3] += 40.0 * (k - 1.5)
+        w2o[k, 3] -= 40.0 * (k - 1.5)
+    r.set_transforms(o2w, w2o)
+    r.build_ias()
+    far_rays = rays.copy()
+    far_rays[:, 0] += 40.0 * (rng.integers(0, 4, len(rays)) - 1.5)
+    S = oracle.Scene(dict(sc, object_to_world=o2w, world_to_object=w2o))
+    tuv, prim = r.trace_rays(far_rays)
+    tuv_o, prim_o = S.trace(far_rays)
+    assert (prim != 0xFFFFFFFF).mean() > 0.2 and np.array_equal(prim, prim_o) and np.array_equal(_bits(tuv), _bits(tuv_o))
+    r.close()
+
+
 def test_small_path_pool_and_batching_do_not_change_results(oracle):
     sc = scenes.cornell_box()
     cam = F.Camera(**scenes.CORNELL_CAMERA)
