@@ -44,8 +44,8 @@ constexpr int kBlock = 256;
 constexpr uint32_t kLutReflFloats = 16 * 16 * 2, kLutSheenFloats = 16 * 16;  // lut.cu:5-93, :917-955
 constexpr uint32_t kMatLds = 32;  // material records staged in LDS by the shade kernels when the scene has at most this many
 #ifndef FH_SHADE_BLOCKS
-#define FH_SHADE_BLOCKS 1  // minimum resident workgroups per CU the shade kernels are compiled for (register budget = 512 / that per lane)
-#endif
+#define FH_SHADE_BLOCKS 2  // resident workgroups per CU the specialised shade kernels are compiled for (register budget = 512 / that per lane): they need 208-230 registers
+#endif                     // since their products go to memory as they are made (PoolSink); the generic seven-lobe kernel keeps one wave per SIMD (391 registers, no spills)
 
 struct SobolRows {  // rows of the generator matrices this kernel needs, staged in LDS (32 columns each)
   uint32_t m[4][32];
@@ -405,33 +405,73 @@ struct BounceSlots {
 
 struct SecRay { f3 o; float tmax; f3 d; bool active; f3 c; };
 
-// everything one shaded hit produces (pt.cu:680-944), independent of where it is stored
-struct ShadeOut {
-  bool emissive_done;  // first hit on an emitter: radiance updated, path ends, nothing else valid
-  bool shaded;         // secondary rays valid
-  bool cont;           // next ray valid
+// What one shaded hit produces (pt.cu:680-944) goes to a SINK as soon as it exists, so that a kernel that only stores the products
+// (k_shade) does not keep them alive in registers next to the BSDF state; k_tail, which traces the rays itself, collects them in
+// registers.  Sink interface:
+//   aov(position, normal, albedo, u, v)         first hit only                              (pt.cu:745-751)
+//   emissive(L)                                 first hit on an emitter: the path ends      (pt.cu:754-759)
+//   secondary(slot, origin, tmax, dir, active, contribution)      one per enabled NEE slot, in the reference's order
+//   light_pending(T, cos, f, pdf)               scenes with emitters: what the light ray's MIS weight needs once its hit is known
+//   next(origin, dir, T)                        the path continues
+struct ShadeOut {      // register sink (k_tail)
+  bool emissive_done = false;  // first hit on an emitter: radiance updated, path ends, nothing else valid
+  bool shaded = false;         // secondary rays valid
+  bool cont = false;           // next ray valid
   f3 L;                // radiance after a directly visible emitter
   f3 T;                // throughput for the next bounce (after Russian roulette)
   SecRay sec[SEC_COUNT];
   f3 lp_T, lp_f;       // light ray with emitters: throughput before the update, BSDF value
   float lp_cos, lp_pdf;
   f3 next_o, next_d;
-  f3 aov_position, aov_normal, aov_albedo;
-  float aov_u, aov_v;
+  FH_D ShadeOut() { for (uint32_t k = 0; k < SEC_COUNT; ++k) sec[k].active = false; }
+  FH_D void aov(f3, f3, f3, float, float) {}
+  FH_D void emissive(f3 l) { L = l; emissive_done = true; }
+  FH_D void secondary(uint32_t slot, f3 o, float tmax, f3 d, bool active, f3 c) { shaded = true; sec[slot] = SecRay{o, tmax, d, active, c}; }
+  FH_D void light_pending(f3 t, float c, f3 f, float pdf) { lp_T = t; lp_cos = c; lp_f = f; lp_pdf = pdf; }
+  FH_D void next(f3 o, f3 d, f3 t) { cont = true; next_o = o; next_d = d; T = t; }
 };
 
-template <uint32_t LOBES>
+struct PoolSink {      // memory sink (k_shade): path slot p of the pool
+  const PoolDev& pool;
+  uint32_t p;
+  float hit_t;
+  bool shaded = false, cont = false;
+  f3 origin;           // where the path's rays leave the surface (cell key of the bounce queues)
+  FH_D PoolSink(const PoolDev& pl, uint32_t slot, float t) : pool(pl), p(slot), hit_t(t), origin(mk3(0.0f)) {}
+  FH_D void aov(f3 position, f3 normal, f3 albedo, float u, float v)
+  {
+    pool.aov_position[p] = mk4(position, 0.0f);
+    pool.aov_normal[p] = mk4(normal, 0.0f);
+    pool.aov_albedo[p] = mk4(albedo, 0.0f);
+    pool.aov_texdepth[p] = make_float4(u, v, hit_t, 0.0f);
+    pool.flags[p] |= 1u;
+  }
+  FH_D void emissive(f3 l) { pool.rad[p] = mk4(l, 0.0f); }
+  FH_D void secondary(uint32_t slot, f3 o, float tmax, f3 d, bool active, f3 c)
+  {
+    store_secondary(pool, slot, p, o, tmax, d, active, c);
+    if (!shaded) origin = o;  // all rays of a path leave (almost) the same point
+    shaded = true;
+  }
+  FH_D void light_pending(f3 t, float c, f3 f, float pdf) { pool.lp_a[p] = mk4(t, c); pool.lp_b[p] = mk4(f, pdf); }
+  FH_D void next(f3 o, f3 d, f3 t)
+  {
+    pool.ray_o[p] = mk4(o, 1e9f);
+    pool.ray_d[p] = mk4(d, 0.0f);
+    pool.thr[p] = mk4(t, 0.0f);
+    if (!shaded) origin = o;
+    cont = true;
+  }
+};
+
+template <uint32_t LOBES, class Sink>
 FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& rows, const BounceSlots& bs, uint32_t depth, float4 hit, f3 rd, f3 T, f3 L, uint32_t image_idx, uint32_t n_spp,
-                    ShadeOut& out, bool first = true)
+                    Sink& out, bool first = true)
 {
   const uint32_t has_lights = bs.has_lights;
   const uint32_t prim = __float_as_uint(hit.w);
   const float bu = hit.y, bv = hit.z;
   const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
-  out.emissive_done = false; out.shaded = false; out.cont = false;
-  out.L = L; out.T = T;
-#pragma unroll
-  for (uint32_t k = 0; k < SEC_COUNT; ++k) out.sec[k].active = false;
 
   // surface (pt.cu:141-179) from the pre-transformed face record
   const float4 r0 = sc.face_rec[7 * (size_t)prim], r1 = sc.face_rec[7 * (size_t)prim + 1], r2 = sc.face_rec[7 * (size_t)prim + 2];
@@ -470,14 +510,12 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
   }
 
   if (depth == 0 && first) {  // first hit: AOVs and directly visible emitters (pt.cu:745-760); `first` is false only in the bug-compat mode (k_firsthit_scan)
-    out.aov_position = x; out.aov_normal = ns; out.aov_albedo = sp.base_color; out.aov_u = tu; out.aov_v = tv;
+    out.aov(x, ns, sp.base_color, tu, tv);
     if (mat.emissive) {
-      out.L = L + T * emission_of(sc, mat, tu, tv);
-      out.emissive_done = true;
+      out.emissive(L + T * emission_of(sc, mat, tu, tv));
       return;
     }
   }
-  out.shaded = true;
   const f3 wo = to_local(-rd, tangent, ns, bitangent);
   Bsdf<LOBES> bsdf;
   bsdf.init(wo, sp, entering, fr.lut);
@@ -494,7 +532,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
     const f3 f = bsdf.eval(wo, wi);
     const float pdf = 1.0f;
     const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
-    out.sec[SEC_DIR] = SecRay{so, 1e9f - 0.001f, sd, true, clamp01(T * w * f * abs_cos(wi) / pdf) * fr.dir_le};
+    out.secondary(SEC_DIR, so, 1e9f - 0.001f, sd, true, clamp01(T * w * f * abs_cos(wi) / pdf) * fr.dir_le);
   }
   // sky / constant background (pt.cu:817-857)
   {
@@ -503,7 +541,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
     const f3 f = bsdf.eval(wo, wi);
     const float pdf = abs_cos(wi) / kPi;
     const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
-    out.sec[SEC_SKY] = SecRay{so, 1e9f - 0.001f, sd, true, clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, sd)};
+    out.secondary(SEC_SKY, so, 1e9f - 0.001f, sd, true, clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, sd));
   }
   // area lights (pt.cu:860-889, :282-322)
   if (has_lights) {
@@ -529,7 +567,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
     const f3 f = bsdf.eval(wo, wi);
     const float pdf = r * r / fabsf(dot(-sd, ln)) * pdf_area;
     const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
-    out.sec[SEC_AREA] = SecRay{so, r - 0.001f, sd, facing, clamp01(T * w * f * abs_cos(wi) / pdf) * le};
+    out.secondary(SEC_AREA, so, r - 0.001f, sd, facing, clamp01(T * w * f * abs_cos(wi) / pdf) * le);
   }
   // BSDF-sampled light ray (pt.cu:893-925)
   {
@@ -543,13 +581,13 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
     const f3 lo = offset_origin(x, transmitted ? -ng : ng);
     if (has_lights) {
       // the MIS weight needs the hit (emitter or sky): finished once the closest hit is known
-      out.lp_T = T; out.lp_cos = abs_cos(wi); out.lp_f = f; out.lp_pdf = pdf;
-      out.sec[SEC_LIGHT] = SecRay{lo, 1e9f, ld, true, mk3(0.0f)};
+      out.light_pending(T, abs_cos(wi), f, pdf);
+      out.secondary(SEC_LIGHT, lo, 1e9f, ld, true, mk3(0.0f));
     } else {
       // no emitters: the ray contributes only if it escapes, with the sky's cosine pdf (pt.cu:917-919)
       const float pdf_light = abs_cos(wi) / kPi;
       const float w = pdf / (pdf + pdf_light);
-      out.sec[SEC_LIGHT] = SecRay{lo, 1e9f, ld, true, clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, ld)};
+      out.secondary(SEC_LIGHT, lo, 1e9f, ld, true, clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, ld));
     }
   }
   // next direction (pt.cu:928-943) and the next bounce's Russian roulette (pt.cu:457-471)
@@ -567,12 +605,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
     if (!bad3(Tn) && depth + 1u < fr.max_depth) {
       const float prr = clampf(lum(Tn), 0.0f, 1.0f);
       const float u = sobol_draw(rows.m[3], sidx, bs.dim_rr, fr.seed_hash);
-      if (!(u >= prr)) {
-        out.T = Tn / prr;
-        out.cont = true;
-        out.next_o = no;
-        out.next_d = wd;
-      }
+      if (!(u >= prr)) out.next(no, wd, Tn / prr);
     }
   }
 }
@@ -655,7 +688,7 @@ __global__ void __launch_bounds__(kSortBlock) k_cell_scatter(const uint32_t* cou
 }
 
 template <uint32_t LOBES>
-__global__ void __launch_bounds__(kBlock, FH_SHADE_BLOCKS) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
+__global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : FH_SHADE_BLOCKS)) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
 {
   __shared__ SobolRows rows;
   // the shade kernels run one wave per SIMD (512 registers per lane), so nothing hides a dependent global load: the small tables every
@@ -689,35 +722,13 @@ __global__ void __launch_bounds__(kBlock, FH_SHADE_BLOCKS) k_shade(SceneDev sc, 
     uint32_t p = 0, cell = 0;
     if (valid) {
       p = q[i];
-      ShadeOut o;
+      const float4 hit = pool.hit[p];
+      PoolSink o(pool, p, hit.x);
       const bool first = depth != 0 || (pool.flags[p] & 4u) == 0u;
-      shade_hit<LOBES>(sc, fr, rows, bs, depth, pool.hit[p], mk3(pool.ray_d[p]), mk3(pool.thr[p]), mk3(pool.rad[p]), pool.pixel[p], pool.nspp[p], o, first);
-      if (depth == 0 && first) {
-        pool.aov_position[p] = mk4(o.aov_position, 0.0f);
-        pool.aov_normal[p] = mk4(o.aov_normal, 0.0f);
-        pool.aov_albedo[p] = mk4(o.aov_albedo, 0.0f);
-        pool.aov_texdepth[p] = make_float4(o.aov_u, o.aov_v, pool.hit[p].x, 0.0f);
-        pool.flags[p] |= 1u;
-      }
-      if (o.emissive_done) pool.rad[p] = mk4(o.L, 0.0f);
+      shade_hit<LOBES>(sc, fr, rows, bs, depth, hit, mk3(pool.ray_d[p]), mk3(pool.thr[p]), mk3(pool.rad[p]), pool.pixel[p], pool.nspp[p], o, first);
       shaded = o.shaded;
       cont = o.cont;
-      if (shaded) {
-        if (fr.has_dir) store_secondary(pool, SEC_DIR, p, o.sec[SEC_DIR].o, o.sec[SEC_DIR].tmax, o.sec[SEC_DIR].d, o.sec[SEC_DIR].active, o.sec[SEC_DIR].c);
-        store_secondary(pool, SEC_SKY, p, o.sec[SEC_SKY].o, o.sec[SEC_SKY].tmax, o.sec[SEC_SKY].d, o.sec[SEC_SKY].active, o.sec[SEC_SKY].c);
-        if (bs.has_lights) {
-          store_secondary(pool, SEC_AREA, p, o.sec[SEC_AREA].o, o.sec[SEC_AREA].tmax, o.sec[SEC_AREA].d, o.sec[SEC_AREA].active, o.sec[SEC_AREA].c);
-          pool.lp_a[p] = mk4(o.lp_T, o.lp_cos);
-          pool.lp_b[p] = mk4(o.lp_f, o.lp_pdf);
-        }
-        store_secondary(pool, SEC_LIGHT, p, o.sec[SEC_LIGHT].o, o.sec[SEC_LIGHT].tmax, o.sec[SEC_LIGHT].d, o.sec[SEC_LIGHT].active, o.sec[SEC_LIGHT].c);
-      }
-      if (cont) {
-        pool.ray_o[p] = mk4(o.next_o, 1e9f);
-        pool.ray_d[p] = mk4(o.next_d, 0.0f);
-        pool.thr[p] = mk4(o.T, 0.0f);
-      }
-      if (shaded || cont) cell = cell_of(fr, shaded ? o.sec[SEC_SKY].o : o.next_o);  // all rays of a path leave (almost) the same point
+      if (shaded || cont) cell = cell_of(fr, o.origin);
     }
     queue_push_keyed(&cnt[CNT_SEC], pool.q_sec, pool.key_sec, shaded, p, cell);
     queue_push_keyed(&cnt_next[CNT_RAD], pool.q_rad[qnext], pool.key_rad, cont, p, cell);
