@@ -30,7 +30,7 @@ int main(int argc, char** argv)
   std::string out_dir = "output", ibl;
   int width = 1920, height = 1080, n_spp = 16, max_depth = 5;
   float fps = 24.0f, max_time = 9.5f, fov_deg = 60.0f, F = 100.0f, focus = 8.0f;
-  bool bloom = false, sun = false, sky = false;
+  bool bloom = false, sun = false, sky = false, reference_launches = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value after %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -49,6 +49,7 @@ int main(int argc, char** argv)
     else if (a == "--bloom") bloom = true;
     else if (a == "--sun") sun = true;
     else if (a == "--sky") sky = true;
+    else if (a == "--reference-launches") reference_launches = true;  // one launch of --spp samples per frame exactly as the reference computes it (firsthit quirk)
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
   if (scene_files.empty()) { std::fprintf(stderr, "usage: %s --scene file.obj|file.gltf [--scene ...] [--out DIR] [--width W --height H --spp N --depth D] [--fps F --max-time T] [--bloom] [--sun] [--sky] [--ibl env.hdr]\n", argv[0]); return 2; }
@@ -61,6 +62,7 @@ int main(int argc, char** argv)
     renderer.create_program_group();
     renderer.create_pipeline();
     renderer.set_resolution(uint32_t(width), uint32_t(height));
+    if (reference_launches) renderer.set_reference_launch_semantics(true);
 
     const size_t n_px = size_t(width) * size_t(height);
     cwl::CUDABuffer<float4> layer_beauty(n_px), layer_position(n_px), layer_normal(n_px), layer_texcoord(n_px), layer_albedo(n_px), layer_denoised(n_px);

@@ -7,6 +7,8 @@
 #include <cstring>
 
 #include "../../include/fredholm/image_io.h"
+#include <hip/hip_gl_interop.h>
+
 #include "context.h"
 #include "fh_bsdf.h"
 #include "fh_trace.h"
@@ -334,7 +336,7 @@ int fh_ctx_destroy(fh_ctx* ctx)
   void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
                   ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl,
                   ctx->d_bloom_weights, ctx->d_quirk_seen, ctx->d_quirk_aov, ctx->d_obj_vertices, ctx->d_obj_normals, ctx->d_obj_texcoords, ctx->d_obj_indices, ctx->d_face_meta, ctx->d_o2w, ctx->d_w2o,
-                  ctx->d_bvh8_box};
+                  ctx->d_bvh8_box, ctx->d_denoise_tmp[0], ctx->d_denoise_tmp[1]};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -647,6 +649,45 @@ int fh_post_process(fh_ctx* ctx, const float* in, float* hi, float* tmp, int w, 
   CTX_CHECK(ctx);
   if (!in || !hi || !tmp || !out || !pp || w <= 0 || h <= 0) return fail(ctx, FH_E_INVALID, "fh_post_process: bad argument");
   return post_process_submit(ctx, in, hi, tmp, w, h, pp, out);
+}
+
+int fh_denoise(fh_ctx* ctx, uint32_t width, uint32_t height, const float* beauty, const float* normal, const float* albedo, float* denoised, int upscale2x)
+{
+  CTX_CHECK(ctx);
+  if (!beauty || !normal || !albedo || !denoised || width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, FH_E_INVALID, "fh_denoise: bad argument");
+  return denoise_submit(ctx, (int)width, (int)height, beauty, normal, albedo, denoised, upscale2x ? 1 : 0);
+}
+
+// OpenGL interop (cwl::CUDAGLBuffer, cwl/include/cwl/buffer.h:88-143: cuGraphicsGLRegisterBuffer + map + mapped pointer, unmapped and
+// unregistered in the destructor).  Needs a current OpenGL context on the calling thread, like the reference.
+int fh_gl_register_buffer(fh_ctx* ctx, unsigned int gl_buffer, void** resource, void** device_ptr, uint64_t* bytes)
+{
+  CTX_CHECK(ctx);
+  if (!resource || !device_ptr) return fail(ctx, FH_E_INVALID, "fh_gl_register_buffer: null argument");
+  *resource = nullptr; *device_ptr = nullptr;
+  hipGraphicsResource_t res = nullptr;
+  FH_HIP(hipGraphicsGLRegisterBuffer(&res, (GLuint)gl_buffer, hipGraphicsRegisterFlagsNone));
+  hipError_t e = hipGraphicsMapResources(1, &res, ctx->stream);
+  size_t size = 0;
+  void* ptr = nullptr;
+  if (e == hipSuccess) e = hipGraphicsResourceGetMappedPointer(&ptr, &size, res);
+  if (e != hipSuccess) {
+    (void)hipGraphicsUnregisterResource(res);
+    return fail(ctx, FH_E_HIP, std::string("fh_gl_register_buffer: ") + hipGetErrorString(e));
+  }
+  *resource = (void*)res; *device_ptr = ptr;
+  if (bytes) *bytes = (uint64_t)size;
+  return FH_OK;
+}
+int fh_gl_unregister_buffer(fh_ctx* ctx, void* resource)
+{
+  CTX_CHECK(ctx);
+  if (!resource) return FH_OK;
+  hipGraphicsResource_t res = (hipGraphicsResource_t)resource;
+  (void)hipStreamSynchronize(ctx->stream);
+  FH_HIP(hipGraphicsUnmapResources(1, &res, ctx->stream));
+  FH_HIP(hipGraphicsUnregisterResource(res));
+  return FH_OK;
 }
 
 int fh_malloc(fh_ctx* ctx, uint64_t bytes, void** out)

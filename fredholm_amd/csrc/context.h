@@ -133,6 +133,10 @@ struct fh_ctx {
   float* d_bloom_weights = nullptr;
   float bloom_sigma_cached = -1.0f, bloom_wsum = 0.0f;
 
+  // denoiser slot (post.hip): ping-pong buffers of the a-trous filter
+  float4* d_denoise_tmp[2] = {nullptr, nullptr};
+  size_t denoise_pixels = 0;
+
   // stats
   fh_stats stats{};
   unsigned long long* d_trace_counters = nullptr;  // nodes, tris, rays of the closest-hit kernel, then of the secondary kernel
@@ -157,4 +161,5 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
 int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity);   // render.hip
 void pool_release(fh_ctx* ctx);
 int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int w, int h, const fh_post_params* pp, float* out);  // post.hip
+int denoise_submit(fh_ctx* ctx, int w, int h, const float* beauty, const float* normal, const float* albedo, float* out, int upscale);  // post.hip
 }  // namespace fh

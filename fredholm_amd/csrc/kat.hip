@@ -170,6 +170,16 @@ __global__ void __launch_bounds__(256) k_bw_copy(const float4* src, float4* dst,
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// the product's texture unit (include/fh_texture_unit.h) on the device, for comparison with the checker's independent texture unit
+__global__ void k_tex2d(fht_texture tex, const float* srgb_lut, uint32_t n, const float* uv, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float o[4];
+  fht_tex2d(&tex, srgb_lut, uv[2 * i], uv[2 * i + 1], o);
+  out[4 * i] = o[0]; out[4 * i + 1] = o[1]; out[4 * i + 2] = o[2]; out[4 * i + 3] = o[3];
+}
+
 __global__ void k_sky(HosekSky st, f3 sun, float intensity, uint32_t n, const float* d, float* out)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,6 +458,23 @@ int fh_measure_bandwidth(fh_ctx* ctx, uint64_t bytes, uint32_t iters, double* re
   (void)hipEventDestroy(m0); (void)hipEventDestroy(m1);
   const double memcpy_gbs = 2.0 * (double)n * 16.0 * iters / (ms_m * 1e-3) / 1e9;
   if (memcpy_gbs > *copy_gbs) *copy_gbs = memcpy_gbs;
+  return FH_OK;
+}
+int fh_kat_tex2d(fh_ctx* ctx, const uint8_t* rgba8, const float* rgba32f, uint32_t width, uint32_t height, int srgb, uint32_t n, const float* uv2, float* out4)
+{
+  KCTX(ctx);
+  if ((!rgba8 && !rgba32f) || !uv2 || !out4 || width == 0 || height == 0) return fail(ctx, FH_E_INVALID, "fh_kat_tex2d: bad argument");
+  Tmp<uint8_t> t8;
+  Tmp<float> t32, lut, uv, o;
+  const size_t texels = (size_t)width * height * 4;
+  if (rgba8) FH_HIP(t8.up(rgba8, texels)); else FH_HIP(t32.up(rgba32f, texels));
+  float h_lut[256];
+  for (int i = 0; i < 256; ++i) h_lut[i] = fht_srgb_to_linear((float)i * (1.0f / 255.0f));
+  FH_HIP(lut.up(h_lut, 256)); FH_HIP(uv.up(uv2, 2ull * n)); FH_HIP(o.up(nullptr, 4ull * n));
+  const fht_texture tex{rgba8 ? t8.p : nullptr, rgba8 ? nullptr : t32.p, width, height, srgb ? 1u : 0u};
+  hipLaunchKernelGGL(k_tex2d, dim3(blocks(n)), dim3(256), 0, ctx->stream, tex, lut.p, n, uv.p, o.p);
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(o.down(out4));
   return FH_OK;
 }
 

@@ -83,6 +83,61 @@ __global__ void __launch_bounds__(256) k_tone_map(const float4* in, int w, int h
   out[i + w * j] = make_float4(r, g, b, 1.0f);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Denoiser slot.  The reference calls NVIDIA's OptiX AI denoiser (fredholm/include/fredholm/denoiser.h:14-146: HDR model, albedo + normal
+// guides, optional 2x upscale) -- a proprietary network with no counterpart here and nothing to be bit-compatible with.  What fills the slot is
+// the classic guided filter it replaced in many renderers: the edge-avoiding a-trous wavelet filter (Dammertz, Sewtz, Hanika, Lensch, HPG 2010)
+// on albedo-demodulated radiance, five passes of a 5x5 B3-spline kernel with hole sizes 1, 2, 4, 8, 16, edge-stopping weights on colour
+// (relative to the local level, sigma halved per pass), normal and albedo.  Same inputs and output as the reference's class; `upscale` doubles the output by pixel replication.
+constexpr float kDnSigmaColor = 2.0f, kDnSigmaNormal = 0.35f, kDnSigmaAlbedo = 0.2f, kDnAlbedoFloor = 0.01f;  // colour: relative to the mean of the two irradiances
+constexpr int kDnPasses = 5;
+
+__device__ __forceinline__ float dn_floor(float a) { return fmaxf(a, kDnAlbedoFloor); }
+__device__ __forceinline__ float dn_finite(float v) { return (v != v || fabsf(v) > 3.0e38f) ? 0.0f : v; }
+
+// pass `it`: src = irradiance of the previous pass (pass 0 reads beauty and demodulates); the last pass re-modulates and writes alpha 1
+__global__ void __launch_bounds__(256) k_atrous(const float4* src, const float4* beauty, const float4* normal, const float4* albedo, int w, int h, int it, int last, int upscale, float4* dst)
+{
+  const int x = blockIdx.x * 16 + threadIdx.x, y = blockIdx.y * 16 + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const int step = 1 << it;
+  const float kern[3] = {3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
+  const float inv_sc = 1.0f / (kDnSigmaColor * kDnSigmaColor * (1.0f / (float)(1 << (2 * it)))), inv_sn = 1.0f / (kDnSigmaNormal * kDnSigmaNormal),
+              inv_sa = 1.0f / (kDnSigmaAlbedo * kDnSigmaAlbedo);
+  auto irradiance = [&](int i) -> float4 {
+    if (it != 0) return src[i];
+    const float4 b = beauty[i], a = albedo[i];
+    return make_float4(dn_finite(b.x) / dn_floor(a.x), dn_finite(b.y) / dn_floor(a.y), dn_finite(b.z) / dn_floor(a.z), 0.0f);
+  };
+  const int p = x + w * y;
+  const float4 cp = irradiance(p), np = normal[p], ap = albedo[p];
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f, sw = 0.0f;
+  for (int dy = -2; dy <= 2; ++dy)
+    for (int dx = -2; dx <= 2; ++dx) {
+      int qx = x + dx * step, qy = y + dy * step;
+      qx = qx < 0 ? 0 : (qx > w - 1 ? w - 1 : qx);
+      qy = qy < 0 ? 0 : (qy > h - 1 ? h - 1 : qy);
+      const int q = qx + w * qy;
+      const float4 cq = irradiance(q), nq = normal[q], aq = albedo[q];
+      const float dcx = cq.x - cp.x, dcy = cq.y - cp.y, dcz = cq.z - cp.z;
+      const float dnx = nq.x - np.x, dny = nq.y - np.y, dnz = nq.z - np.z;
+      const float dax = aq.x - ap.x, day = aq.y - ap.y, daz = aq.z - ap.z;
+      const float m = (cq.x + cq.y + cq.z) + (cp.x + cp.y + cp.z);  // colour distance relative to the local level: HDR input
+      const float den = m * m * (1.0f / 9.0f) + 1e-4f;
+      const float e = ((dcx * dcx + dcy * dcy + dcz * dcz) / den) * inv_sc + (dnx * dnx + dny * dny + dnz * dnz) * inv_sn + (dax * dax + day * day + daz * daz) * inv_sa;
+      const float wgt = kern[dx < 0 ? -dx : dx] * kern[dy < 0 ? -dy : dy] * fhe_exp(-e);
+      sx += wgt * cq.x; sy += wgt * cq.y; sz += wgt * cq.z; sw += wgt;
+    }
+  const float inv = 1.0f / sw;  // the centre tap has weight 9/64: never zero
+  float4 o = make_float4(sx * inv, sy * inv, sz * inv, 0.0f);
+  if (!last) { dst[p] = o; return; }
+  o = make_float4(o.x * dn_floor(ap.x), o.y * dn_floor(ap.y), o.z * dn_floor(ap.z), 1.0f);
+  if (!upscale) { dst[p] = o; return; }
+  const int w2 = 2 * w;
+  dst[2 * x + w2 * (2 * y)] = o; dst[2 * x + 1 + w2 * (2 * y)] = o; dst[2 * x + w2 * (2 * y + 1)] = o; dst[2 * x + 1 + w2 * (2 * y + 1)] = o;
+}
+
 }  // namespace
 
 int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int w, int h, const fh_post_params* pp, float* out)
@@ -118,6 +173,28 @@ int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int
   }
   const float exposure = exposure_from_ev100(ev100_of(1.0f, 1.0f, pp->ISO));
   hipLaunchKernelGGL(k_tone_map, grid, block, 0, st, (const float4*)tmp, w, h, gw, gh, exposure, pp->chromatic_aberration, (float4*)out);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+int denoise_submit(fh_ctx* ctx, int w, int h, const float* beauty, const float* normal, const float* albedo, float* out, int upscale)
+{
+  hipStream_t st = ctx->stream;
+  const size_t px = (size_t)w * h;
+  if (ctx->denoise_pixels < px) {  // two ping-pong irradiance buffers, kept in the context
+    for (int k = 0; k < 2; ++k) { if (ctx->d_denoise_tmp[k]) (void)hipFree(ctx->d_denoise_tmp[k]); ctx->d_denoise_tmp[k] = nullptr; }
+    ctx->denoise_pixels = 0;
+    for (int k = 0; k < 2; ++k) FH_HIP(hipMalloc((void**)&ctx->d_denoise_tmp[k], px * sizeof(float4)));
+    ctx->denoise_pixels = px;
+  }
+  const dim3 grid((w + 15) / 16, (h + 15) / 16), block(16, 16);
+  const float4* src = nullptr;
+  for (int it = 0; it < kDnPasses; ++it) {
+    const int last = it == kDnPasses - 1;
+    float4* dst = last ? (float4*)out : ctx->d_denoise_tmp[it & 1];
+    hipLaunchKernelGGL(k_atrous, grid, block, 0, st, src, (const float4*)beauty, (const float4*)normal, (const float4*)albedo, w, h, it, last, upscale, dst);
+    src = dst;
+  }
   FH_HIP(hipGetLastError());
   return FH_OK;
 }

@@ -358,6 +358,11 @@ class Renderer:
         self._ck(N.lib().fh_post_process(self._ctx, C.c_void_p(beauty_in_ptr), C.c_void_p(high_ptr), C.c_void_p(temp_ptr), int(width), int(height), C.byref(pp), C.c_void_p(beauty_out_ptr)),
                  "fh_post_process")
 
+    def denoise(self, width, height, beauty_ptr, normal_ptr, albedo_ptr, denoised_ptr, upscale=False):
+        """the denoiser slot (Denoiser::denoise, denoiser.h:87-95): edge-avoiding a-trous filter guided by the normal and albedo layers"""
+        self._ck(N.lib().fh_denoise(self._ctx, C.c_uint32(int(width)), C.c_uint32(int(height)), C.c_void_p(beauty_ptr), C.c_void_p(normal_ptr), C.c_void_p(albedo_ptr),
+                                    C.c_void_p(denoised_ptr), int(bool(upscale))), "fh_denoise")
+
     # -- parity-test hooks
     def measure_bandwidth(self, nbytes=1 << 30, iters=8):
         """(read GB/s, copy GB/s) of this GPU's HBM, measured with streaming kernels (fh_measure_bandwidth)"""

@@ -87,6 +87,10 @@ class Renderer
   }
   void wait_for_completion() { cwl::check(m_ctx, fh_sync(m_ctx), "fh_sync"); }  // renderer.h:736
 
+  // not in the reference: render(n_samples = k) as ONE reference launch of k samples, payload.firsthit quirk included (pt.cu:432-433;
+  // rtcamp8 renders 16 per launch, rtcamp8.cpp:183-189), instead of k one-sample launches
+  void set_reference_launch_semantics(bool on) { cwl::check(m_ctx, fh_set_flags(m_ctx, on ? FH_FLAG_REFERENCE_FIRSTHIT : 0u), "fh_set_flags"); }
+
  private:
   static fh_camera camera_from(const Mat4& m, const Camera& camera)
   {

@@ -182,6 +182,17 @@ int fh_reset_stats(fh_ctx* ctx);
 /* -- post chain: post_process_kernel_launch (fredholm/kernels/src/post-process.cu:5-35); all device pointers, float4 images */
 int fh_post_process(fh_ctx* ctx, const float* beauty_in, float* beauty_high_luminance, float* beauty_temp, int width, int height, const fh_post_params* params, float* beauty_out);
 
+/* Denoiser slot (Denoiser::denoise, fredholm/include/fredholm/denoiser.h:87-95).  The reference invokes NVIDIA's OptiX AI denoiser (HDR model with
+ * albedo + normal guide layers, optionally the 2x upscaling model), a proprietary network; the slot is filled by an edge-avoiding a-trous wavelet
+ * filter (Dammertz et al. 2010) on albedo-demodulated radiance with the same inputs and output: float4 beauty / normal / albedo layers of
+ * width x height pixels in, float4 denoised out (2*width x 2*height when upscale2x, by pixel replication).  Asynchronous on the context stream. */
+int fh_denoise(fh_ctx* ctx, uint32_t width, uint32_t height, const float* beauty, const float* normal, const float* albedo, float* denoised, int upscale2x);
+
+/* OpenGL interop for display (cwl::CUDAGLBuffer, cwl/include/cwl/buffer.h:88-143): register an OpenGL buffer object, map it and return the
+ * device pointer the renderer can write AOVs to; unregister unmaps.  A current OpenGL context is required on the calling thread. */
+int fh_gl_register_buffer(fh_ctx* ctx, unsigned int gl_buffer, void** resource, void** device_ptr, uint64_t* bytes);
+int fh_gl_unregister_buffer(fh_ctx* ctx, void* resource);
+
 /* -- device memory helpers (stand in for cwl::CUDABuffer, cwl/include/cwl/buffer.h:18-85) */
 int fh_malloc(fh_ctx* ctx, uint64_t bytes, void** out);
 int fh_free(fh_ctx* ctx, void* ptr);
@@ -226,6 +237,9 @@ int fh_kat_offset_origin(fh_ctx* ctx, uint32_t n, const float* p3, const float* 
 enum { FH_MATH_ALBEDO_REFLECTION = 0, FH_MATH_ALBEDO_SHEEN, FH_MATH_ONB, FH_MATH_TO_LOCAL, FH_MATH_TO_WORLD, FH_MATH_SPHERICAL, FH_MATH_LUMINANCE,
        FH_MATH_UCHIMURA, FH_MATH_LINEAR_TO_SRGB, FH_MATH_EXPOSURE, FH_MATH_TONE_MAP_TAIL, FH_MATH_POST_LUMINANCE, FH_MATH_COUNT };
 int fh_kat_math(fh_ctx* ctx, int kind, uint32_t n, const float* in, float* out);
+/* tex2D<float4>() of the software texture unit (include/fh_texture_unit.h: cwl/texture.h:35-47 semantics) evaluated on the device for n (u, v)
+   pairs on an RGBA8 texture (rgba8, optionally sRGB) or a float4 texture (rgba32f); exactly one of the two texel pointers is non-NULL */
+int fh_kat_tex2d(fh_ctx* ctx, const uint8_t* rgba8, const float* rgba32f, uint32_t width, uint32_t height, int srgb, uint32_t n, const float* uv2, float* out4);
 /* measured HBM bandwidth of this GPU (GB/s): a streaming float4 read and a float4 copy (read + written bytes) over `bytes`-sized buffers,
    `iters` launches each.  The "measured HBM roofline" SURVEY.md 8(d) asks for; use buffers well beyond the 256 MiB Infinity Cache. */
 int fh_measure_bandwidth(fh_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gbs, double* copy_gbs);

@@ -27,8 +27,8 @@
 // Third-party arithmetic not in the tree (OptiX BVH traversal + triangle test, CUDA tex2D) is
 // replaced by a binned-SAH BVH + the watertight test of Woop/Benthin/Wald 2013; closest hits are
 // made independent of BVH shape by breaking equal-t ties towards the lower face index.
-// Textures go through the normative software texture unit of include/fh_texture_unit.h (CUDA tex2D semantics as
-// documented; the hardware's exact arithmetic is not in the tree): base colour / specular / roughness / metalness /
+// Textures go through the checker's own texture unit (oracle/otexture.h: CUDA tex2D semantics as documented, written from the definition and
+// independent of the product's include/fh_texture_unit.h; the hardware's exact arithmetic is not in the tree): base colour / specular / roughness / metalness /
 // coat lookups (pt.cu:181-280), bump and normal maps (pt.cu:709-742), emission textures (pt.cu:131-139), the alpha
 // any-hit test (pt.cu:545-678) and the lat-long IBL (pt.cu:344-350).
 #include <algorithm>
@@ -38,7 +38,7 @@
 #include <thread>
 #include <vector>
 
-#include "../include/fh_texture_unit.h"
+#include "otexture.h"
 #include "obsdf.h"
 
 namespace orc {
@@ -81,9 +81,9 @@ struct Scene {
   std::vector<V3> wtri;  // 3 per face
   std::vector<BvhNode> nodes; std::vector<uint32_t> order;
   // textures
-  std::vector<std::vector<uint8_t>> texels; std::vector<fht_texture> textures; float srgb_lut[256];
+  std::vector<std::vector<uint8_t>> texels; std::vector<OTexture> textures;
   std::vector<uint8_t> face_alpha;  // face needs the any-hit alpha test
-  std::vector<float> ibl_data; fht_texture ibl{}; bool has_ibl = false;
+  std::vector<float> ibl_data; OTexture ibl{}; bool has_ibl = false;
   // environment
   bool has_dir = false; DirLight dir{};
   bool has_hosek = false; HosekState hosek{};
@@ -143,7 +143,7 @@ static inline bool tri_test(const RayPre& r, V3 org, V3 p0, V3 p1, V3 p2, float&
 static inline V4 tex4(const Scene& s, int id, V2 uv)
 {
   float o[4];
-  fht_tex2d(&s.textures[id], s.srgb_lut, uv.x, uv.y, o);
+  tex2d(s.textures[id], uv.x, uv.y, o);
   return v4(o[0], o[1], o[2], o[3]);
 }
 // __anyhit__* (pt.cu:545-678)
@@ -499,7 +499,7 @@ static inline V3 env_radiance(const Scene& s, const Frame& fr, V3 d)
     float phi = fhe_atan2(d.z, d.x);
     if (phi < 0) phi += 2.0f * kPi;
     float o[4];
-    fht_tex2d(&s.ibl, nullptr, phi / (2.0f * kPi), theta / kPi, o);
+    tex2d(s.ibl, phi / (2.0f * kPi), theta / kPi, o);
     return s.sky_intensity * v3(o[0], o[1], o[2]);
   }
   return s.has_hosek ? sky_radiance(s, d) : fr.bg;
@@ -517,7 +517,7 @@ static void closest_hit_radiance(const Scene& s, const Frame& fr, const Hit& h, 
   const ShadingParams sp = shading_params(s, mat, si.uv);
   V3 tangent = si.tangent, normal = si.ns, bitangent = si.bitangent;
   if (mat.heightmap_tex >= 0) {  // pt.cu:709-731
-    const fht_texture& hm = s.textures[mat.heightmap_tex];
+    const OTexture& hm = s.textures[mat.heightmap_tex];
     const float du = 1.0f / hm.width, dv = 1.0f / hm.height;
     const float hv = tex4(s, mat.heightmap_tex, si.uv).x;
     const float dfdu = tex4(s, mat.heightmap_tex, v2(si.uv.x + du, si.uv.y)).x - hv;
@@ -951,13 +951,12 @@ void* orc_scene_create(uint32_t n_verts, const float* verts, const float* normal
   if (inst_ids) std::memcpy(s->inst_ids.data(), inst_ids, 4ull * n_faces);
   s->mats.resize(n_mats);
   std::memcpy(s->mats.data(), mats180, 180ull * n_mats);
-  for (int i = 0; i < 256; ++i) s->srgb_lut[i] = fht_srgb_to_linear((float)i * (1.0f / 255.0f));
   const TexDesc* td = (const TexDesc*)tex_descs;
   s->texels.resize(n_tex);
   s->textures.resize(n_tex);
   for (uint32_t i = 0; i < n_tex; ++i) {
     s->texels[i].assign(td[i].rgba8, td[i].rgba8 + (size_t)td[i].width * td[i].height * 4);
-    s->textures[i] = fht_texture{s->texels[i].data(), nullptr, td[i].width, td[i].height, td[i].srgb ? 1u : 0u};
+    s->textures[i] = OTexture{s->texels[i].data(), nullptr, td[i].width, td[i].height, td[i].srgb != 0};
   }
   for (const Material& m : s->mats) {
     const int ids[11] = {m.base_color_tex, m.specular_color_tex, m.specular_roughness_tex, m.metalness_tex, m.metallic_roughness_tex, m.coat_tex, m.coat_roughness_tex, m.emission_tex,
@@ -1006,7 +1005,7 @@ void orc_set_ibl(void* h, const float* rgba, uint32_t w, uint32_t hh)
   s->has_ibl = rgba != nullptr;
   if (!rgba) return;
   s->ibl_data.assign(rgba, rgba + 4ull * w * hh);
-  s->ibl = fht_texture{nullptr, s->ibl_data.data(), w, hh, 0u};
+  s->ibl = OTexture{nullptr, s->ibl_data.data(), w, hh, false};
 }
 void orc_set_hosek(void* h, int enable, float turbidity, float albedo)
 {
@@ -1105,10 +1104,59 @@ void orc_math(int kind, int n, const float* in, float* out)
 }
 void orc_tex2d(const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb, int n, const float* uv, float* out)
 {
-  float lut[256];
-  for (int i = 0; i < 256; ++i) lut[i] = fht_srgb_to_linear((float)i * (1.0f / 255.0f));
-  const fht_texture t{rgba8, nullptr, w, h, srgb ? 1u : 0u};
-  for (int i = 0; i < n; ++i) fht_tex2d(&t, lut, uv[2 * i], uv[2 * i + 1], out + 4 * i);
+  const OTexture t{rgba8, nullptr, w, h, srgb != 0};
+  for (int i = 0; i < n; ++i) tex2d(t, uv[2 * i], uv[2 * i + 1], out + 4 * i);
+}
+// the denoiser slot: edge-avoiding a-trous wavelet filter (Dammertz et al. 2010) on albedo-demodulated radiance, restated from the definition
+// in include/fredholm_hip.h (fh_denoise): 5 passes of the 5x5 B3-spline kernel with holes 1, 2, 4, 8, 16; weights exp(-(|dc|^2/(mean level)^2/sc_i^2 + |dn|^2/sn^2 + |da|^2/sa^2))
+void orc_denoise(uint32_t w, uint32_t h, const float* beauty, const float* normal, const float* albedo, float* out, int upscale)
+{
+  const float sigma_c = 2.0f, sigma_n = 0.35f, sigma_a = 0.2f, floor_a = 0.01f;
+  const float kern[3] = {3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
+  const size_t px = (size_t)w * h;
+  auto finite = [](float v) { return (v != v || fabsf(v) > 3.0e38f) ? 0.0f : v; };
+  std::vector<float> a(4 * px), b(4 * px);
+  for (size_t i = 0; i < px; ++i)
+    for (int c = 0; c < 3; ++c) a[4 * i + c] = finite(beauty[4 * i + c]) / fmaxf(albedo[4 * i + c], floor_a);
+  for (int it = 0; it < 5; ++it) {
+    const int step = 1 << it;
+    const float inv_sc = 1.0f / (sigma_c * sigma_c * (1.0f / (float)(1 << (2 * it)))), inv_sn = 1.0f / (sigma_n * sigma_n), inv_sa = 1.0f / (sigma_a * sigma_a);
+    for (int y = 0; y < (int)h; ++y)
+      for (int x = 0; x < (int)w; ++x) {
+        const size_t p = x + (size_t)w * y;
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, sw = 0.0f;
+        for (int dy = -2; dy <= 2; ++dy)
+          for (int dx = -2; dx <= 2; ++dx) {
+            const int qx = std::min(std::max(x + dx * step, 0), (int)w - 1), qy = std::min(std::max(y + dy * step, 0), (int)h - 1);
+            const size_t q = qx + (size_t)w * qy;
+            const float dcx = a[4 * q] - a[4 * p], dcy = a[4 * q + 1] - a[4 * p + 1], dcz = a[4 * q + 2] - a[4 * p + 2];
+            const float dnx = normal[4 * q] - normal[4 * p], dny = normal[4 * q + 1] - normal[4 * p + 1], dnz = normal[4 * q + 2] - normal[4 * p + 2];
+            const float dax = albedo[4 * q] - albedo[4 * p], day = albedo[4 * q + 1] - albedo[4 * p + 1], daz = albedo[4 * q + 2] - albedo[4 * p + 2];
+            const float m = (a[4 * q] + a[4 * q + 1] + a[4 * q + 2]) + (a[4 * p] + a[4 * p + 1] + a[4 * p + 2]);
+            const float den = m * m * (1.0f / 9.0f) + 1e-4f;  // colour distance relative to the mean level of the two pixels
+            const float e = ((dcx * dcx + dcy * dcy + dcz * dcz) / den) * inv_sc + (dnx * dnx + dny * dny + dnz * dnz) * inv_sn + (dax * dax + day * day + daz * daz) * inv_sa;
+            const float wgt = kern[std::abs(dx)] * kern[std::abs(dy)] * fhe_exp(-e);
+            sx += wgt * a[4 * q]; sy += wgt * a[4 * q + 1]; sz += wgt * a[4 * q + 2]; sw += wgt;
+          }
+        const float inv = 1.0f / sw;
+        b[4 * p] = sx * inv; b[4 * p + 1] = sy * inv; b[4 * p + 2] = sz * inv; b[4 * p + 3] = 0.0f;
+      }
+    a.swap(b);
+  }
+  for (int y = 0; y < (int)h; ++y)
+    for (int x = 0; x < (int)w; ++x) {
+      const size_t p = x + (size_t)w * y;
+      const float o[4] = {a[4 * p] * fmaxf(albedo[4 * p], floor_a), a[4 * p + 1] * fmaxf(albedo[4 * p + 1], floor_a), a[4 * p + 2] * fmaxf(albedo[4 * p + 2], floor_a), 1.0f};
+      if (!upscale) { std::memcpy(out + 4 * p, o, 16); continue; }
+      const size_t w2 = 2 * (size_t)w;
+      for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i) std::memcpy(out + 4 * ((2 * x + i) + w2 * (2 * y + j)), o, 16);
+    }
+}
+void orc_tex2d_f32(const float* rgba32f, uint32_t w, uint32_t h, int n, const float* uv, float* out)
+{
+  const OTexture t{nullptr, rgba32f, w, h, false};
+  for (int i = 0; i < n; ++i) tex2d(t, uv[2 * i], uv[2 * i + 1], out + 4 * i);
 }
 int orc_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 

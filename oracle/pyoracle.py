@@ -16,7 +16,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("oracle.cpp", "obsdf.h", "osampler.h", "ovec.h")] + [os.path.join(_HERE, "..", "include", "fh_elementary.h"), os.path.join(_HERE, "..", "include", "fh_texture_unit.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.cpp", "obsdf.h", "osampler.h", "ovec.h", "otexture.h")] + [os.path.join(_HERE, "..", "include", "fh_elementary.h")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -262,6 +262,24 @@ def tex2d(rgba8, srgb, uv):
     uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
     out = np.zeros((uv.shape[0], 4), dtype=np.float32)
     lib().orc_tex2d(_p(img), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0]), int(bool(srgb)), int(uv.shape[0]), _p(uv), _p(out))
+    return out
+
+
+def denoise(beauty, normal, albedo, upscale=False):
+    """the checker's restatement of the denoiser slot (edge-avoiding a-trous filter; fh_denoise)"""
+    b, n, a = (np.ascontiguousarray(x, dtype=np.float32) for x in (beauty, normal, albedo))
+    h, w = b.shape[:2]
+    out = np.zeros((2 * h, 2 * w, 4) if upscale else (h, w, 4), np.float32)
+    lib().orc_denoise(C.c_uint32(w), C.c_uint32(h), _p(b), _p(n), _p(a), _p(out), int(bool(upscale)))
+    return out
+
+
+def tex2d_f32(rgba32f, uv):
+    """the same for a float4 texture (the lat-long IBL path)"""
+    img = np.ascontiguousarray(rgba32f, dtype=np.float32)
+    uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((uv.shape[0], 4), dtype=np.float32)
+    lib().orc_tex2d_f32(_p(img), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0]), int(uv.shape[0]), _p(uv), _p(out))
     return out
 
 

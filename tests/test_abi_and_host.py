@@ -202,6 +202,38 @@ def test_cpp_facade_compiles_and_links(tmp_path):
         assert run.returncode == 1 and "no HIP device" in run.stderr  # loud failure, no fallback
 
 
+def test_gl_interop_buffer_facade_compiles_against_the_controllers_usage(tmp_path):
+    """cwl::CUDAGLBuffer (cwl/buffer.h:88-143) over fh_gl_register_buffer + oglw::Buffer: the calls app/controller.cpp:80-123 and app/gui.cpp:330-347
+    make on the AOV layers compile against the drop-in headers (linking needs the application's OpenGL, which a headless box does not have)"""
+    src = tmp_path / "gl_layers.cpp"
+    src.write_text("""
+#define FH_WITH_OPENGL
+#include "cwl/buffer.h"
+#include "fredholm/denoiser.h"
+#include "fredholm/types.h"
+#include <memory>
+struct Layers {
+  std::unique_ptr<cwl::CUDAGLBuffer<float4>> beauty, normal, albedo, denoised;
+  std::unique_ptr<cwl::CUDAGLBuffer<float>> depth;
+  std::unique_ptr<fredholm::Denoiser> denoiser;
+  void init(uint32_t w, uint32_t h) {
+    beauty = std::make_unique<cwl::CUDAGLBuffer<float4>>(w * h);
+    normal = std::make_unique<cwl::CUDAGLBuffer<float4>>(w * h);
+    albedo = std::make_unique<cwl::CUDAGLBuffer<float4>>(w * h);
+    denoised = std::make_unique<cwl::CUDAGLBuffer<float4>>(w * h);
+    depth = std::make_unique<cwl::CUDAGLBuffer<float>>(w * h);
+    denoiser = std::make_unique<fredholm::Denoiser>(nullptr, w, h, beauty->get_device_ptr(), normal->get_device_ptr(), albedo->get_device_ptr(), denoised->get_device_ptr());
+    beauty->clear(); depth->clear();
+    denoiser->denoise(); denoiser->wait_for_completion();
+    std::vector<float4> host; denoised->copy_from_device_to_host(host);
+    beauty->get_gl_buffer().bindToShaderStorageBuffer(0);
+  }
+};
+""")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 # ---------------------------------------------------------------- image files (include/fredholm/image_io.h, fredholm_amd/image_io.py)
 def _png_bytes(w, h, depth, ctype, rows, extra=b""):
     import struct

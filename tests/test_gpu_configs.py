@@ -223,3 +223,24 @@ def test_two_rank_bench_step_gathers_the_unsharded_frame(tmp_path):
     line = [ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and "gather" in out["config"]["gather"]
+
+
+def test_gl_interop_entry_points_fail_cleanly_without_an_opengl_context():
+    """fh_gl_register_buffer (cwl::CUDAGLBuffer's backend) needs a current OpenGL context; on a headless box it must return an error, not take the
+    process down.  Probed in a child process so that a misbehaving GL stack cannot end the test run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import ctypes as C, sys; sys.path.insert(0, %r)\n"
+        "import fredholm_amd as F; from fredholm_amd import native as N\n"
+        "r = F.Renderer(0); res, ptr, n = C.c_void_p(), C.c_void_p(), C.c_uint64()\n"
+        "rc = N.lib().fh_gl_register_buffer(r._ctx, 12345, C.byref(res), C.byref(ptr), C.byref(n))\n"
+        "print('rc', rc, N.lib().fh_last_error(r._ctx)); assert rc != 0 and not ptr.value\n"
+        "assert N.lib().fh_gl_unregister_buffer(r._ctx, None) == 0\n"
+        "r.close(); print('clean')\n") % root
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    if run.returncode < 0:
+        pytest.skip(f"the HIP runtime's GL interop died with signal {-run.returncode} without an OpenGL context on this box")
+    assert run.returncode == 0 and "clean" in run.stdout, run.stdout + run.stderr

@@ -603,6 +603,29 @@ def test_transforms_and_instances(oracle):
     _assert_image_parity(gpu["normal"], ref["normal"])
 
 
+def test_texture_unit_matches_the_checkers_independent_one(renderer, oracle):
+    """the product's texture unit (include/fh_texture_unit.h, on the device) against the checker's own (oracle/otexture.h, written from the
+    stated definition, sharing no code): wrap addressing for negative / large coordinates, texel-centre and 1.8 fixed-point weight edges, sRGB
+    decode before filtering, non-square sizes, the float4 (IBL) path, NaN coordinates"""
+    rng = np.random.default_rng(12)
+    for (h, w), srgb in (((7, 5), False), ((16, 16), True), ((33, 64), True), ((1, 1), False), ((2, 128), False)):
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        uv = rng.uniform(-3.0, 3.0, (20000, 2)).astype(np.float32)
+        k = np.arange(2048)
+        edges = np.stack([(k % (4 * w)) / np.float32(4 * w), (k // 7 % (4 * h)) / np.float32(4 * h)], 1).astype(np.float32)  # texel centres and borders
+        fixed = np.stack([(0.5 + k / 512.0) / w, (0.5 + (k * 3 % 512) / 512.0) / h], 1).astype(np.float32)            # every 1/512 of a texel: weight rounding
+        special = np.array([[0, 0], [1, 1], [-1e-7, 1 - 1e-7], [1e6, -1e6], [np.nan, 0.5], [0.5, np.nan], [1e30, 0.25]], np.float32)
+        uv = np.concatenate([uv, edges, fixed, special])
+        got = np.zeros((uv.shape[0], 4), np.float32)
+        _kat(renderer, "fh_kat_tex2d", N.ptr(img), None, C.c_uint32(w), C.c_uint32(h), int(srgb), int(uv.shape[0]), N.ptr(uv), N.ptr(got))
+        assert _same(got, oracle.tex2d(img, srgb, uv)), (h, w, srgb)
+    env = scenes.gradient_ibl(16, 8)
+    uv = rng.uniform(-2.0, 2.0, (20000, 2)).astype(np.float32)
+    got = np.zeros((uv.shape[0], 4), np.float32)
+    _kat(renderer, "fh_kat_tex2d", None, N.ptr(env), C.c_uint32(16), C.c_uint32(8), 0, int(uv.shape[0]), N.ptr(uv), N.ptr(got))
+    assert _same(got, oracle.tex2d_f32(env, uv))
+
+
 def test_textured_scene_matches_checker(oracle):
     """every texture slot of the reference: base colour (sRGB), specular colour, roughness, metalness, metallic-roughness,
     coat, coat roughness, emission, height map, normal map, base-colour alpha and alpha-texture cut-outs"""
@@ -709,6 +732,46 @@ def test_tile_ownership_matches_library_and_shards_reassemble():
 
 
 # ------------------------------------------------------------------ post-process
+def test_denoiser_slot_matches_checker_and_denoises(renderer, oracle):
+    """Denoiser::denoise (denoiser.h:87-95) is NVIDIA's AI denoiser in the reference; the slot runs an edge-avoiding a-trous filter guided by the
+    same normal / albedo layers (fh_denoise).  Bit-identical to the checker's restatement; flat input stays flat; a noisy render gets closer to
+    the converged one; the upscaling mode doubles the output."""
+    sc = scenes.cornell_box()
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    w, h = 160, 120
+    r = F.Renderer(0)
+    r.load_scene(sc)
+    r.build_ias()
+    r.set_resolution(w, h)
+    L = F.RenderLayer(r, w, h)
+    r.render(cam, (0, 0, 0), L, 1, 5)
+    r.wait_for_completion()
+    noisy = {n: L.download(n) for n in ("beauty", "normal", "albedo")}
+    out, out2 = F.renderer.DeviceBuffer(r, w * h * 16), F.renderer.DeviceBuffer(r, 4 * w * h * 16)
+    r.denoise(w, h, L.ptrs["beauty"], L.ptrs["normal"], L.ptrs["albedo"], out.ptr)
+    r.denoise(w, h, L.ptrs["beauty"], L.ptrs["normal"], L.ptrs["albedo"], out2.ptr, upscale=True)
+    r.wait_for_completion()
+    got, got2 = out.download(np.float32, (h, w, 4)), out2.download(np.float32, (2 * h, 2 * w, 4))
+    want = oracle.denoise(noisy["beauty"], noisy["normal"], noisy["albedo"])
+    assert _same(got, want)
+    assert _same(got2, oracle.denoise(noisy["beauty"], noisy["normal"], noisy["albedo"], upscale=True))
+    assert _same(got2[::2, ::2], got) and _same(got2[1::2, 1::2], got) and (got[..., 3] == 1).all()
+    # closer to a converged render than the input was
+    r.render(cam, (0, 0, 0), L, 1023, 5)
+    r.wait_for_completion()
+    ref = L.download("beauty")[..., :3]
+    err_in, err_out = np.abs(noisy["beauty"][..., :3] - ref).mean(), np.abs(got[..., :3] - ref).mean()
+    assert err_out < 0.65 * err_in, (err_in, err_out)  # 1 spp Cornell box: the mean absolute error halves
+    # a flat image with flat guides is a fixed point
+    flat = np.full((h, w, 4), 0.37, np.float32)
+    b = F.renderer.DeviceBuffer(r, w * h * 16)
+    b.upload(flat)
+    r.denoise(w, h, b.ptr, b.ptr, b.ptr, out.ptr)
+    r.wait_for_completion()
+    assert np.allclose(out.download(np.float32, (h, w, 4))[..., :3], 0.37, rtol=2e-6)
+    r.close()
+
+
 @pytest.mark.parametrize("use_bloom", [False, True])
 def test_post_process_identical_including_unwritten_border(renderer, oracle, use_bloom):
     rng = np.random.default_rng(12)
@@ -891,7 +954,7 @@ def test_animated_gltf_batch_driver_matches_python_path_and_checker(tmp_path, or
     r.build_ias()
     L = F.RenderLayer(r, w, h)
     cam = F.Camera(fov=0.5 * np.pi, F=100.0, focus=10000.0)
-    bufs = [F.renderer.DeviceBuffer(r, w * h * 16) for _ in range(3)]
+    bufs = [F.renderer.DeviceBuffer(r, w * h * 16) for _ in range(4)]
     for b in bufs:
         b.clear()  # pixels outside the floor-division post-process grid are never written (post-process.cu:9-11)
     time = np.float32(0.0)
@@ -902,7 +965,8 @@ def test_animated_gltf_batch_driver_matches_python_path_and_checker(tmp_path, or
         r.set_time(float(time))
         r.render(cam, (0, 0, 0), L, spp, depth)
         r.wait_for_completion()
-        r.post_process(L.ptrs["beauty"], bufs[0].ptr, bufs[1].ptr, w, h, F.PostProcessParams(use_bloom=True), bufs[2].ptr)
+        r.denoise(w, h, L.ptrs["beauty"], L.ptrs["normal"], L.ptrs["albedo"], bufs[3].ptr)  # the driver's denoiser slot (rtcamp8.cpp:191-196)
+        r.post_process(bufs[3].ptr, bufs[0].ptr, bufs[1].ptr, w, h, F.PostProcessParams(use_bloom=True), bufs[2].ptr)
         r.wait_for_completion()
         pp = bufs[2].download(np.float32, (h, w, 4))
         with np.errstate(invalid="ignore"):  # std::fmin(std::fmax(255 v, 0), 255) maps NaN to 0 (rtcamp8.cpp:270-277 uses std::clamp)
