@@ -2,7 +2,7 @@
 
 The reference decodes images with stb_image (fredholm/src/scene.cpp:7-66): 8-bit RGBA with a vertical flip for material
 textures, float RGBA without a flip for the IBL.  PNG (non-interlaced), binary PPM/PGM and Radiance .hdr are read here from
-their published specifications (baseline JPEG included; progressive JPEG is rejected).  Writers exist for tests and tools."""
+their published specifications (JPEG: sequential and progressive Huffman DCT).  Writers exist for tests and tools."""
 import struct
 import zlib
 
@@ -178,7 +178,7 @@ def load_rgba8(path, flip_vertically=True):
         if data[:2] == b"\x89P": img = decode_png(data)
         elif data[:2] in (b"P5", b"P6"): img = decode_pnm(data)
         elif data[:2] == b"\xff\xd8": img = decode_jpeg(data)
-        else: raise ValueError(f"failed to load {path}: only PNG, baseline JPEG and binary PPM/PGM images are supported in this build")
+        else: raise ValueError(f"failed to load {path}: only PNG, JPEG (sequential or progressive Huffman) and binary PPM/PGM images are supported in this build")
     except ValueError:
         raise
     except Exception as e:  # ran off the end of a damaged file, undefined table, zlib error ...: one error type for callers
@@ -310,7 +310,7 @@ def write_hdr(path, rgb, rle=False):
                 f.write(rgbe[y].tobytes())
 
 
-# ------------------------------------------------------------------------------------------------ baseline JPEG (ITU-T T.81)
+# ------------------------------------------------------------------------------------------------ JPEG (ITU-T T.81): sequential and progressive Huffman DCT
 _ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
 
@@ -338,6 +338,255 @@ def _idct_block(coef):
     ws = np.stack(one_d([c[k, :] for k in range(8)], CB - P1), axis=0)          # pass 1: columns; ws[k, i]
     out = np.stack(one_d([ws[:, k] for k in range(8)], CB + P1 + 3), axis=1)    # pass 2: rows; out[i, k]
     return np.clip(out + 128, 0, 255).astype(np.uint8)
+
+
+def _jpeg_finish(comps, width, height, hmax, vmax, adobe):
+    """component planes (uint8, MCU-padded) -> uint8 [h, w, 4]: triangle-filter upsampling and fixed-point YCbCr -> RGB, shared by the sequential and
+    the progressive decoder"""
+    def upsampled(c):
+        fx, fy = hmax // c["h"], vmax // c["v"]
+        p = c["plane"].astype(np.int32)
+        if fx == 1 and fy == 1:
+            return p
+        H, W = p.shape
+
+        def shifted(a, dy, dx):  # a[y + dy, x + dx] with edge replication
+            ys = np.clip(np.arange(H) + dy, 0, H - 1)
+            xs = np.clip(np.arange(W) + dx, 0, W - 1)
+            return a[np.ix_(ys, xs)]
+        if fx == 2 and fy == 1:
+            out = np.zeros((H, 2 * W), np.int32)
+            out[:, 0::2] = (3 * p + shifted(p, 0, -1) + 1) >> 2
+            out[:, 1::2] = (3 * p + shifted(p, 0, 1) + 2) >> 2
+            return out
+        if fx == 1 and fy == 2:
+            out = np.zeros((2 * H, W), np.int32)
+            out[0::2] = (3 * p + shifted(p, -1, 0) + 1) >> 2
+            out[1::2] = (3 * p + shifted(p, 1, 0) + 2) >> 2
+            return out
+        out = np.zeros((2 * H, 2 * W), np.int32)
+        for oy, dy in ((0, -1), (1, 1)):
+            near_col = 3 * p + shifted(p, dy, 0)
+            for ox, dx, rnd in ((0, -1, 8), (1, 1, 7)):
+                far_col = 3 * shifted(p, 0, dx) + shifted(p, dy, dx)
+                out[oy::2, ox::2] = (3 * near_col + far_col + rnd) >> 4
+        return out
+    img = np.full((height, width, 4), 255, dtype=np.uint8)
+    if len(comps) == 1:
+        img[..., :3] = comps[0]["plane"][:height, :width, None]
+        return img
+    Y, cb, cr = (upsampled(c)[:height, :width].astype(np.int64) for c in comps)
+    if adobe is None or adobe != 0:
+        cb, cr = cb - 128, cr - 128
+        img[..., 0] = np.clip(Y + ((91881 * cr + 32768) >> 16), 0, 255)
+        img[..., 1] = np.clip(Y + ((-22554 * cb - 46802 * cr + 32768) >> 16), 0, 255)
+        img[..., 2] = np.clip(Y + ((116130 * cb + 32768) >> 16), 0, 255)
+    else:
+        img[..., 0], img[..., 1], img[..., 2] = Y, cb, cr
+    return img
+
+
+def _decode_jpeg_progressive(data):
+    """SOF2 files (annex G): every scan adds a band of coefficients (spectral selection) or one more bit of them (successive approximation) to a
+    coefficient store that is dequantised and transformed once, after the last scan.  Same arithmetic after entropy decoding as the sequential
+    path; bit-identical to include/fredholm/image_io.h: JpegDecoder (progressive part)."""
+    pos = 2
+    q, dc, ac = {}, {}, {}
+    comps, width, height, restart, adobe = [], 0, 0, 0, None
+    state = {"bits": 0, "n": 0, "pos": 0, "marker": False}
+
+    def bit():
+        if state["n"] == 0:
+            b = 0
+            if not state["marker"] and state["pos"] < len(data):
+                b = data[state["pos"]]
+                if b == 0xFF:
+                    b2 = data[state["pos"] + 1] if state["pos"] + 1 < len(data) else 0xD9
+                    if b2 == 0: state["pos"] += 2
+                    else: state["marker"], b = True, 0
+                else: state["pos"] += 1
+            state["bits"], state["n"] = b, 8
+        state["n"] -= 1
+        return (state["bits"] >> state["n"]) & 1
+
+    def receive(k):
+        v = 0
+        for _ in range(k): v = (v << 1) | bit()
+        return v
+
+    def extend(v, k):
+        return 0 if k == 0 else (v - (1 << k) + 1 if v < (1 << (k - 1)) else v)
+
+    def decode(tab):
+        counts, syms = tab
+        code = first = index = 0
+        for ln in range(16):
+            code |= bit()
+            cnt = counts[ln]
+            if code - cnt < first: return syms[index + (code - first)]
+            index += cnt
+            first = (first + cnt) << 1
+            code <<= 1
+        raise ValueError("jpeg: bad Huffman code")
+
+    def scan(d):
+        ns = d[0]
+        if ns < 1 or ns > len(comps) or len(d) < 4 + 2 * ns: raise ValueError("jpeg: bad SOS")
+        sc = []
+        for i in range(ns):
+            c = next((c for c in comps if c["id"] == d[1 + 2 * i]), None)
+            if c is None: raise ValueError("jpeg: bad scan component")
+            c["td"], c["ta"] = d[2 + 2 * i] >> 4, d[2 + 2 * i] & 15
+            sc.append(c)
+        Ss, Se, Ah, Al = d[1 + 2 * ns], d[2 + 2 * ns], d[3 + 2 * ns] >> 4, d[3 + 2 * ns] & 15
+        if Ss > Se or Se > 63 or (Ss == 0 and Se != 0) or (Ss > 0 and ns != 1) or Al > 13 or (Ah and Ah != Al + 1): raise ValueError("jpeg: bad progressive scan parameters")
+        for c in sc:
+            if (Ss == 0 and Ah == 0 and c["td"] not in dc) or (Ss > 0 and c["ta"] not in ac): raise ValueError("jpeg: missing table")
+        if ns > 1:
+            units = [[(c, y * c["v"] + by, x * c["h"] + bx) for c in sc for by in range(c["v"]) for bx in range(c["h"])] for y in range(my) for x in range(mx)]
+        else:
+            c = sc[0]
+            units = [[(c, y, x)] for y in range(c["nby"]) for x in range(c["nbx"])]
+        state["n"], state["marker"] = 0, False
+        for c in comps: c["pred"] = 0
+        eobrun = 0
+        p1, m1 = 1 << Al, -(1 << Al)
+        for ui, unit in enumerate(units):
+            if restart and ui and ui % restart == 0:
+                state["n"], state["marker"] = 0, False
+                while state["pos"] + 1 < len(data) and not (data[state["pos"]] == 0xFF and 0xD0 <= data[state["pos"] + 1] <= 0xD7): state["pos"] += 1
+                state["pos"] += 2
+                for c in comps: c["pred"] = 0
+                eobrun = 0
+            for c, by, bx in unit:
+                blk = c["coef"][by, bx]
+                if Ss == 0:
+                    if Ah == 0:
+                        t = decode(dc[c["td"]])
+                        if t > 11: raise ValueError("jpeg: bad DC size")
+                        c["pred"] += extend(receive(t), t)
+                        blk[0] = c["pred"] * (1 << Al)
+                    elif bit():
+                        blk[0] |= p1
+                    continue
+                tab = ac[c["ta"]]
+                if Ah == 0:
+                    if eobrun:
+                        eobrun -= 1
+                        continue
+                    k = Ss
+                    while k <= Se:
+                        rs = decode(tab)
+                        r, sz = rs >> 4, rs & 15
+                        if sz == 0:
+                            if r < 15:
+                                eobrun = (1 << r) - 1
+                                if r: eobrun += receive(r)
+                                break
+                            k += 16
+                            continue
+                        k += r
+                        if k > Se: raise ValueError("jpeg: bad AC run")
+                        blk[_ZIGZAG[k]] = extend(receive(sz), sz) * (1 << Al)
+                        k += 1
+                    continue
+                # refinement of an AC band (annex G.2.3)
+                k = Ss
+                if eobrun == 0:
+                    while k <= Se:
+                        rs = decode(tab)
+                        r, sz = rs >> 4, rs & 15
+                        value = 0
+                        if sz:
+                            if sz != 1: raise ValueError("jpeg: bad refinement code")
+                            value = p1 if bit() else m1
+                        elif r != 15:
+                            eobrun = 1 << r
+                            if r: eobrun += receive(r)
+                            break
+                        while k <= Se:
+                            z = _ZIGZAG[k]
+                            if blk[z] != 0:
+                                if bit() and (blk[z] & p1) == 0: blk[z] += p1 if blk[z] >= 0 else m1
+                            else:
+                                r -= 1
+                                if r < 0: break
+                            k += 1
+                        if value:
+                            if k > Se: raise ValueError("jpeg: bad AC run")
+                            blk[_ZIGZAG[k]] = value
+                        k += 1
+                if eobrun > 0:
+                    while k <= Se:
+                        z = _ZIGZAG[k]
+                        if blk[z] != 0 and bit() and (blk[z] & p1) == 0: blk[z] += p1 if blk[z] >= 0 else m1
+                        k += 1
+                    eobrun -= 1
+
+    def tables(d):
+        p = 0
+        while p < len(d):
+            tc, th = d[p] >> 4, d[p] & 15
+            counts = list(d[p + 1:p + 17])
+            total = sum(counts)
+            syms = d[p + 17:p + 17 + total]
+            if tc > 1 or th > 3 or len(syms) != total: raise ValueError("jpeg: bad DHT")
+            (ac if tc else dc)[th] = (counts, syms)
+            p += 17 + total
+    seen_scan = False
+    while True:
+        while pos + 1 < len(data) and not (data[pos] == 0xFF and data[pos + 1] not in (0x00, 0xFF)): pos += 1
+        if pos + 1 >= len(data): raise ValueError("jpeg: truncated")
+        marker = data[pos + 1]
+        pos += 2
+        if marker == 0xD9: break
+        if 0xD0 <= marker <= 0xD7: continue
+        n = (data[pos] << 8) | data[pos + 1]
+        d = data[pos + 2:pos + n]
+        if marker == 0xC2:
+            if comps: raise ValueError("jpeg: more than one frame")
+            if d[0] != 8: raise ValueError("jpeg: only 8-bit samples are supported")
+            height, width, nc = (d[1] << 8) | d[2], (d[3] << 8) | d[4], d[5]
+            if width <= 0 or height <= 0: raise ValueError("jpeg: bad dimensions")
+            if nc not in (1, 3): raise ValueError("jpeg: only 1- and 3-component images are supported")
+            comps = [{"id": d[6 + 3 * i], "h": d[7 + 3 * i] >> 4, "v": d[7 + 3 * i] & 15, "tq": d[8 + 3 * i], "pred": 0} for i in range(nc)]
+            if any(not (1 <= c["h"] <= 2 and 1 <= c["v"] <= 2) for c in comps): raise ValueError("jpeg: unsupported sampling factors")
+            if nc == 1: comps[0]["h"] = comps[0]["v"] = 1
+            hmax, vmax = max(c["h"] for c in comps), max(c["v"] for c in comps)
+            mx, my = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+            for c in comps:
+                c["bw"], c["bh"] = mx * c["h"] * 8, my * c["v"] * 8
+                c["nbx"], c["nby"] = -(-(-(-width * c["h"] // hmax)) // 8), -(-(-(-height * c["v"] // vmax)) // 8)  # blocks a non-interleaved scan covers
+                c["coef"] = np.zeros((c["bh"] // 8, c["bw"] // 8, 64), dtype=np.int64)  # natural order
+        elif marker == 0xC4: tables(d)
+        elif marker == 0xDB:
+            p = 0
+            while p < len(d):
+                pq, tq = d[p] >> 4, d[p] & 15
+                p += 1
+                tab = np.zeros(64, dtype=np.int64)
+                for i in range(64):
+                    tab[_ZIGZAG[i]] = ((d[p] << 8) | d[p + 1]) if pq else d[p]
+                    p += pq + 1
+                q[tq] = tab
+        elif marker == 0xDD: restart = (d[0] << 8) | d[1]
+        elif marker == 0xEE and d[:5] == b"Adobe": adobe = d[11]
+        elif marker == 0xDA:
+            if not comps: raise ValueError("jpeg: scan before frame")
+            state["pos"] = pos + n
+            scan(d)
+            seen_scan = True
+            pos = state["pos"]
+            continue
+        pos += n
+    if not seen_scan: raise ValueError("jpeg: no image data")
+    for c in comps:
+        if c["tq"] not in q: raise ValueError("jpeg: missing table")
+        c["plane"] = np.zeros((c["bh"], c["bw"]), dtype=np.uint8)
+        for by in range(c["bh"] // 8):
+            for bx in range(c["bw"] // 8):
+                c["plane"][by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] = _idct_block(c["coef"][by, bx] * q[c["tq"]])
+    return _jpeg_finish(comps, width, height, hmax, vmax, adobe)
 
 
 def decode_jpeg(data):
@@ -377,7 +626,7 @@ def decode_jpeg(data):
             comps = [{"id": d[6 + 3 * i], "h": d[7 + 3 * i] >> 4, "v": d[7 + 3 * i] & 15, "tq": d[8 + 3 * i], "pred": 0} for i in range(nc)]
             if any(not (1 <= c["h"] <= 2 and 1 <= c["v"] <= 2) for c in comps): raise ValueError("jpeg: unsupported sampling factors")
             if nc == 1: comps[0]["h"] = comps[0]["v"] = 1
-        elif marker == 0xC2: raise ValueError("jpeg: progressive files are not supported")
+        elif marker == 0xC2: return _decode_jpeg_progressive(data)
         elif 0xC3 <= marker <= 0xCF and marker not in (0xC4, 0xC8, 0xCC): raise ValueError("jpeg: unsupported coding process")
         elif marker == 0xC4: tables(d, {0: dc, 1: ac})
         elif marker == 0xDB:
@@ -471,47 +720,7 @@ def decode_jpeg(data):
                         y0, x0 = (y * c["v"] + by) * 8, (x * c["h"] + bx) * 8
                         c["plane"][y0:y0 + 8, x0:x0 + 8] = _idct_block(coef)
 
-    def upsampled(c):
-        fx, fy = hmax // c["h"], vmax // c["v"]
-        p = c["plane"].astype(np.int32)
-        if fx == 1 and fy == 1:
-            return p
-        H, W = p.shape
-
-        def shifted(a, dy, dx):  # a[y + dy, x + dx] with edge replication
-            ys = np.clip(np.arange(H) + dy, 0, H - 1)
-            xs = np.clip(np.arange(W) + dx, 0, W - 1)
-            return a[np.ix_(ys, xs)]
-        if fx == 2 and fy == 1:
-            out = np.zeros((H, 2 * W), np.int32)
-            out[:, 0::2] = (3 * p + shifted(p, 0, -1) + 1) >> 2
-            out[:, 1::2] = (3 * p + shifted(p, 0, 1) + 2) >> 2
-            return out
-        if fx == 1 and fy == 2:
-            out = np.zeros((2 * H, W), np.int32)
-            out[0::2] = (3 * p + shifted(p, -1, 0) + 1) >> 2
-            out[1::2] = (3 * p + shifted(p, 1, 0) + 2) >> 2
-            return out
-        out = np.zeros((2 * H, 2 * W), np.int32)
-        for oy, dy in ((0, -1), (1, 1)):
-            near_col = 3 * p + shifted(p, dy, 0)
-            for ox, dx, rnd in ((0, -1, 8), (1, 1, 7)):
-                far_col = 3 * shifted(p, 0, dx) + shifted(p, dy, dx)
-                out[oy::2, ox::2] = (3 * near_col + far_col + rnd) >> 4
-        return out
-    img = np.full((height, width, 4), 255, dtype=np.uint8)
-    if len(comps) == 1:
-        img[..., :3] = comps[0]["plane"][:height, :width, None]
-        return img
-    Y, cb, cr = (upsampled(c)[:height, :width].astype(np.int64) for c in comps)
-    if adobe is None or adobe != 0:
-        cb, cr = cb - 128, cr - 128
-        img[..., 0] = np.clip(Y + ((91881 * cr + 32768) >> 16), 0, 255)
-        img[..., 1] = np.clip(Y + ((-22554 * cb - 46802 * cr + 32768) >> 16), 0, 255)
-        img[..., 2] = np.clip(Y + ((116130 * cb + 32768) >> 16), 0, 255)
-    else:
-        img[..., 0], img[..., 1], img[..., 2] = Y, cb, cr
-    return img
+    return _jpeg_finish(comps, width, height, hmax, vmax, adobe)
 
 
 _STD_LUMA_Q = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
@@ -645,4 +854,178 @@ def write_jpeg(path, img, quality=90, subsampling=(1, 1), restart_interval=0):
     for ci in range(len(planes)):
         sos += bytes([ci + 1, 0x00 if ci == 0 else 0x11])
     out += seg(0xDA, sos + b"\0\x3f\0") + bytes(stream) + b"\xff\xd9"
+    open(path, "wb").write(bytes(out))
+
+
+def write_jpeg_progressive(path, img, quality=90, subsampling=(1, 1), restart_interval=0, script=None):
+    """Progressive-DCT JPEG writer (SOF2, ITU-T T.81 annex G) for tests: spectral selection and successive approximation with end-of-band
+    runs.  Same colour transform, quantisation and sampling as write_jpeg.  `script` = list of scans (component indices, Ss, Se, Ah, Al);
+    default: the usual 10-scan progression for colour (DC at 1 bit less, luma AC in two bands at 2 bits less, chroma AC, then the refinements)
+    or its 6-scan grey counterpart.  The DC tables are annex K's; the AC table is a flat one that holds every symbol, EOBn included."""
+    img = np.asarray(img, dtype=np.uint8)
+    grey = img.ndim == 2
+    h, w = img.shape[:2]
+    scale = 5000 // quality if quality < 50 else 200 - 2 * quality
+    qt = [np.clip((t * scale + 50) // 100, 1, 255).astype(np.int64) for t in (_STD_LUMA_Q, _STD_CHROMA_Q)]
+    if grey:
+        planes, samp = [img.astype(np.float64)], [(1, 1)]
+    else:
+        r, g, b = (img[..., k].astype(np.float64) for k in range(3))
+        planes = [0.299 * r + 0.587 * g + 0.114 * b, -0.168736 * r - 0.331264 * g + 0.5 * b + 128.0, 0.5 * r - 0.418688 * g - 0.081312 * b + 128.0]
+        samp = [tuple(subsampling), (1, 1), (1, 1)]
+    hmax, vmax = samp[0]
+    mx, my = -(-w // (8 * hmax)), -(-h // (8 * vmax))
+    k = np.arange(8)
+    Cm = np.sqrt(2.0 / 8) * np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16)
+    Cm[0] /= np.sqrt(2.0)
+    coefs, dims = [], []   # per component: int64 [by, bx, 64] (zigzag order) over the MCU-padded block grid; (blocks_x, blocks_y) that a non-interleaved scan covers
+    for ci, (p, (sh, sv)) in enumerate(zip(planes, samp)):
+        fx, fy = hmax // sh, vmax // sv
+        full = np.pad(p, ((0, my * 8 * vmax - h), (0, mx * 8 * hmax - w)), mode="edge")
+        sub = full.reshape(full.shape[0] // fy, fy, full.shape[1] // fx, fx).mean(axis=(1, 3)) - 128.0
+        nby, nbx = sub.shape[0] // 8, sub.shape[1] // 8
+        blocks = sub.reshape(nby, 8, nbx, 8).transpose(0, 2, 1, 3)
+        dct = np.einsum("ij,yxjk,lk->yxil", Cm, blocks, Cm).reshape(nby, nbx, 64)
+        coefs.append(np.rint(dct / qt[0 if ci == 0 else 1]).astype(np.int64)[..., _ZIGZAG])
+        cw, ch = -(-w * sh // hmax), -(-h * sv // vmax)
+        dims.append((-(-cw // 8), -(-ch // 8)))
+    nc = len(planes)
+    if script is None:
+        script = ([(list(range(nc)), 0, 0, 0, 1), ([0], 1, 5, 0, 2)] + ([([2], 1, 63, 0, 1), ([1], 1, 63, 0, 1)] if nc == 3 else []) + [([0], 6, 63, 0, 2), ([0], 1, 63, 2, 1),
+                  (list(range(nc)), 0, 0, 1, 0)] + ([([2], 1, 63, 1, 0), ([1], 1, 63, 1, 0)] if nc == 3 else []) + [([0], 1, 63, 1, 0)])
+
+    def codes(bits, vals):
+        out, code, i = {}, 0, 0
+        for ln in range(1, 17):
+            for _ in range(bits[ln - 1]):
+                out[vals[i]] = (code, ln)
+                code += 1
+                i += 1
+            code <<= 1
+        return out
+    flat_ac = ([0] * 7 + [128, 128] + [0] * 7, list(range(256)))  # every symbol (EOB0..EOB14, ZRL, all run/size pairs): 128 codes of 8 bits, 128 of 9
+    hd = [codes(*_STD_DC_L), codes(*_STD_DC_C)]
+    ha = codes(*flat_ac)
+
+    def seg(marker, body):
+        return bytes([0xFF, marker]) + struct.pack(">H", len(body) + 2) + bytes(body)
+    out = bytearray(b"\xff\xd8" + seg(0xE0, b"JFIF\0\x01\x01\0\0\x01\0\x01\0\0"))
+    for t in range(1 if grey else 2):
+        out += seg(0xDB, bytes([t]) + bytes(int(v) for v in qt[t][_ZIGZAG]))
+    sof = struct.pack(">BHHB", 8, h, w, nc)
+    for ci, (sh, sv) in enumerate(samp):
+        sof += bytes([ci + 1, (sh << 4) | sv, 0 if ci == 0 else 1])
+    out += seg(0xC2, sof)
+    for cls, tid, (bits, vals) in ((0, 0, _STD_DC_L), (1, 0, flat_ac)) + (() if grey else ((0, 1, _STD_DC_C),)):
+        out += seg(0xC4, bytes([(cls << 4) | tid]) + bytes(bits) + bytes(vals))
+    if restart_interval:
+        out += seg(0xDD, struct.pack(">H", restart_interval))
+
+    for comps_in_scan, Ss, Se, Ah, Al in script:
+        stream, state = bytearray(), {"acc": 0, "n": 0}
+
+        def put(code, ln):
+            if ln == 0: return
+            state["acc"], state["n"] = (state["acc"] << ln) | (code & ((1 << ln) - 1)), state["n"] + ln
+            while state["n"] >= 8:
+                byte = (state["acc"] >> (state["n"] - 8)) & 0xFF
+                stream.append(byte)
+                if byte == 0xFF: stream.append(0)
+                state["n"] -= 8
+            state["acc"] &= (1 << state["n"]) - 1
+
+        def flush():
+            if state["n"]: put((1 << (8 - state["n"])) - 1, 8 - state["n"])
+            state["acc"] = state["n"] = 0
+
+        def size_bits(v):
+            a = abs(int(v))
+            n = a.bit_length()
+            return n, (v if v >= 0 else v + (1 << n) - 1) & ((1 << n) - 1)
+        # the blocks of the scan, in coding order, with restart boundaries counted in MCUs
+        if len(comps_in_scan) > 1:
+            units = [[(ci, y * samp[ci][1] + by, x * samp[ci][0] + bx) for ci in comps_in_scan for by in range(samp[ci][1]) for bx in range(samp[ci][0])] for y in range(my) for x in range(mx)]
+        else:
+            ci = comps_in_scan[0]
+            units = [[(ci, y, x)] for y in range(dims[ci][1]) for x in range(dims[ci][0])]
+        pred = [0] * nc
+        eobrun, pending = 0, []   # pending: correction bits that follow the EOB run / the next symbol (refinement scans)
+
+        def emit_eobrun():
+            nonlocal eobrun, pending
+            if eobrun:
+                nb = eobrun.bit_length() - 1
+                put(*ha[nb << 4])
+                if nb: put(eobrun & ((1 << nb) - 1), nb)
+                eobrun = 0
+            for bit_ in pending: put(bit_, 1)
+            pending = []
+        for ui, unit in enumerate(units):
+            if restart_interval and ui and ui % restart_interval == 0:
+                emit_eobrun()
+                flush()
+                stream.extend([0xFF, 0xD0 + ((ui // restart_interval - 1) & 7)])
+                pred = [0] * nc
+            for ci, by, bx in unit:
+                c = coefs[ci][by, bx]
+                if Ss == 0:  # DC
+                    if Ah == 0:
+                        v = int(c[0]) >> Al  # arithmetic shift: the point transform of annex G.1.2.1
+                        n, bits = size_bits(v - pred[ci])
+                        pred[ci] = v
+                        put(*hd[0 if ci == 0 else 1][n])
+                        put(bits, n)
+                    else:
+                        put((int(c[0]) >> Al) & 1, 1)
+                    continue
+                if Ah == 0:  # AC first pass: magnitudes divided by 2^Al towards zero
+                    vals = [(abs(int(v)) >> Al) * (1 if v >= 0 else -1) for v in c[Ss:Se + 1]]
+                    run = 0
+                    last = max([i for i, v in enumerate(vals) if v] or [-1])
+                    for i in range(last + 1):
+                        if vals[i] == 0:
+                            run += 1
+                            continue
+                        emit_eobrun()
+                        while run > 15:
+                            put(*ha[0xF0]); run -= 16
+                        n, bits = size_bits(vals[i])
+                        put(*ha[(run << 4) | n]); put(bits, n)
+                        run = 0
+                    if last < Se - Ss:
+                        eobrun += 1
+                        if eobrun == 0x7FFF: emit_eobrun()
+                    continue
+                # AC refinement (annex G.1.2.3): newly non-zero coefficients are coded with their sign, already non-zero ones get one correction bit
+                absv = [abs(int(v)) >> Al for v in c[Ss:Se + 1]]
+                eob = max([i for i, a in enumerate(absv) if a == 1] or [-1])  # last newly non-zero coefficient
+                run, buffered = 0, []
+                for i, a in enumerate(absv):
+                    if a == 0:
+                        run += 1
+                        continue
+                    while run > 15 and i <= eob:
+                        emit_eobrun()
+                        put(*ha[0xF0]); run -= 16
+                        for bit_ in buffered: put(bit_, 1)
+                        buffered = []
+                    if a > 1:
+                        buffered.append(a & 1)
+                        continue
+                    emit_eobrun()
+                    put(*ha[(run << 4) | 1])
+                    put(0 if c[Ss + i] < 0 else 1, 1)
+                    for bit_ in buffered: put(bit_, 1)
+                    buffered, run = [], 0
+                if run > 0 or buffered:
+                    eobrun += 1
+                    pending += buffered
+                    if eobrun == 0x7FFF or len(pending) > 900: emit_eobrun()
+        emit_eobrun()
+        flush()
+        sos = bytes([len(comps_in_scan)])
+        for ci in comps_in_scan:
+            sos += bytes([ci + 1, ((0 if ci == 0 else 1) << 4) | 0])
+        out += seg(0xDA, sos + bytes([Ss, Se, (Ah << 4) | Al])) + bytes(stream)
+    out += b"\xff\xd9"
     open(path, "wb").write(bytes(out))

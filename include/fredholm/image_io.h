@@ -4,8 +4,8 @@
 //   Texture      (fredholm/src/scene.cpp:7-37):  stbi_load(..., STBI_rgb_alpha) with stbi_set_flip_vertically_on_load(true)
 //   FloatTexture (fredholm/src/scene.cpp:39-66): stbi_loadf(..., STBI_rgb_alpha) without the flip (IBL)
 // This header restates the published formats it needs from their specifications: PNG (W3C PNG 2nd ed.: zlib/deflate RFC 1950/1951,
-// the five scanline filters, colour types 0/2/3/4/6 at 8 or 16 bits, non-interlaced), baseline JPEG (ITU-T T.81 sequential Huffman),
-// binary PPM/PGM, and Radiance RGBE .hdr (flat and new-style run-length scanlines).  Progressive JPEG and interlaced PNG are
+// the five scanline filters, colour types 0/2/3/4/6 at 8 or 16 bits, non-interlaced), JPEG (ITU-T T.81 Huffman DCT: sequential and progressive),
+// binary PPM/PGM, and Radiance RGBE .hdr (flat and new-style run-length scanlines).  Arithmetic-coded JPEG and interlaced PNG are
 // rejected with an exception, never decoded wrongly.
 // Conversion conventions follow stb_image's documented behaviour: grey -> r=g=b, missing alpha -> 255 (1.0f for .hdr),
 // 16-bit samples -> high byte, palette -> RGBA through PLTE/tRNS, .hdr texel = mantissa * 2^(exponent - 136).
@@ -336,9 +336,9 @@ inline Image8 decode_pnm(const std::vector<uint8_t>& file)  // binary P5 / P6, m
   return img;
 }
 
-// ---------------------------------------------------------------------------------------------- baseline JPEG (ITU-T T.81)
-// Sequential Huffman DCT frames (SOF0 / SOF1, 8-bit), 1 or 3 components, sampling factors 1 and 2, restart intervals, JFIF YCbCr.
-// Progressive, arithmetic-coded, 12-bit and 4-component files are rejected.  Everything after entropy decoding is integer arithmetic,
+// ---------------------------------------------------------------------------------------------- JPEG (ITU-T T.81)
+// Sequential (SOF0 / SOF1) and progressive (SOF2: spectral selection + successive approximation, end-of-band runs) Huffman DCT frames, 8-bit,
+// 1 or 3 components, sampling factors 1 and 2, restart intervals, JFIF YCbCr.  Arithmetic-coded, lossless, 12-bit and 4-component files are rejected.  Everything after entropy decoding is integer arithmetic,
 // so that this decoder and fredholm_amd/image_io.py produce identical bytes:
 //   IDCT      Loeffler-Ligtenberg-Moschytz 1-D flow graph, 13-bit constants, two passes (the scaling of the IJG "slow integer" IDCT)
 //   upsample  triangle filter: 3/4 nearer + 1/4 farther sample per axis, rounding constants 1,2 (one axis) and 8,7 (two axes)
@@ -352,15 +352,28 @@ class JpegDecoder {
   {
     if (m_f.size() < 4 || m_f[0] != 0xff || m_f[1] != 0xd8) throw std::runtime_error("jpeg: bad signature");
     m_pos = 2;
+    bool seen_scan = false;
     for (;;) {
       const int marker = next_marker();
-      if (marker == 0xd9) throw std::runtime_error("jpeg: no image data");
-      if (marker == 0xda) break;
+      if (marker == 0xd9) {
+        if (m_progressive && seen_scan) return finish_progressive();
+        throw std::runtime_error("jpeg: no image data");
+      }
+      if (marker >= 0xd0 && marker <= 0xd7) continue;  // a restart marker left over at the end of a scan
+      if (marker == 0xda) {
+        if (!m_progressive) break;
+        scan_progressive();
+        seen_scan = true;
+        continue;
+      }
       const size_t len = seg_length();
       const uint8_t* d = &m_f[m_pos + 2];
       const size_t n = len - 2;
-      if (marker == 0xc0 || marker == 0xc1) frame(d, n);
-      else if (marker == 0xc2) throw std::runtime_error("jpeg: progressive files are not supported");
+      if (marker == 0xc0 || marker == 0xc1 || marker == 0xc2) {
+        if (!m_comp.empty()) throw std::runtime_error("jpeg: more than one frame");
+        frame(d, n);
+        if (marker == 0xc2) begin_progressive();
+      }
       else if (marker >= 0xc3 && marker <= 0xcf && marker != 0xc4 && marker != 0xc8 && marker != 0xcc) throw std::runtime_error("jpeg: unsupported coding process");
       else if (marker == 0xc4) huffman_tables(d, n);
       else if (marker == 0xdb) quant_tables(d, n);
@@ -373,7 +386,13 @@ class JpegDecoder {
   }
 
  private:
-  struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0, bw = 0, bh = 0; std::vector<uint8_t> plane; };
+  struct Component {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0, bw = 0, bh = 0;
+    std::vector<uint8_t> plane;
+    int nbx = 0, nby = 0;        // progressive: blocks a scan of this component alone covers (its own size, not the MCU-padded one)
+    std::vector<int> coef;       // progressive: quantised coefficients of every block of the padded grid, natural order
+  };
+  bool m_progressive = false;
   struct Table { uint16_t count[17] = {}; uint8_t symbol[256] = {}; bool set = false; };
   const std::vector<uint8_t>& m_f;
   size_t m_pos = 0;
@@ -586,6 +605,147 @@ class JpegDecoder {
       }
   }
 
+  // ---- progressive DCT (SOF2, annex G): every scan adds a band of coefficients (spectral selection) or one more bit of them (successive
+  // approximation) to the coefficient store; dequantisation and the IDCT run once, after the last scan
+  void begin_progressive()
+  {
+    m_progressive = true;
+    const int mcu_w = 8 * m_hmax, mcu_h = 8 * m_vmax;
+    const int mx = (m_width + mcu_w - 1) / mcu_w, my = (m_height + mcu_h - 1) / mcu_h;
+    for (Component& c : m_comp) {
+      c.bw = mx * c.h * 8; c.bh = my * c.v * 8;
+      const int cw = (m_width * c.h + m_hmax - 1) / m_hmax, ch = (m_height * c.v + m_vmax - 1) / m_vmax;
+      c.nbx = (cw + 7) / 8; c.nby = (ch + 7) / 8;
+      c.coef.assign(size_t(c.bw / 8) * size_t(c.bh / 8) * 64, 0);
+    }
+  }
+  static const uint8_t* zigzag()
+  {
+    static const uint8_t zz[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    return zz;
+  }
+  void refine_nonzero(int& v, int p1, int m1)
+  {
+    if (bit() && (v & p1) == 0) v += v >= 0 ? p1 : m1;
+  }
+  void scan_progressive()
+  {
+    const size_t len = seg_length();
+    const uint8_t* d = &m_f[m_pos + 2];
+    if (m_comp.empty()) throw std::runtime_error("jpeg: scan before frame");
+    const int ns = d[0];
+    if (ns < 1 || ns > int(m_comp.size()) || len < size_t(6 + 2 * ns)) throw std::runtime_error("jpeg: bad SOS");
+    Component* sc[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < ns; ++i) {
+      for (Component& cc : m_comp) if (cc.id == d[1 + 2 * i]) sc[i] = &cc;
+      if (!sc[i]) throw std::runtime_error("jpeg: bad scan component");
+      sc[i]->td = d[2 + 2 * i] >> 4; sc[i]->ta = d[2 + 2 * i] & 15;
+    }
+    const int Ss = d[1 + 2 * ns], Se = d[2 + 2 * ns], Ah = d[3 + 2 * ns] >> 4, Al = d[3 + 2 * ns] & 15;
+    if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13 || (Ah && Ah != Al + 1)) throw std::runtime_error("jpeg: bad progressive scan parameters");
+    for (int i = 0; i < ns; ++i)
+      if (sc[i]->td > 3 || sc[i]->ta > 3 || (Ss == 0 && Ah == 0 && !m_dc[sc[i]->td].set) || (Ss > 0 && !m_ac[sc[i]->ta].set)) throw std::runtime_error("jpeg: missing table");
+    m_pos += len;
+    m_nbits = 0;
+    m_hit_marker = false;
+    for (Component& c : m_comp) c.pred = 0;
+    const uint8_t* zz = zigzag();
+    const int mcu_w = 8 * m_hmax, mcu_h = 8 * m_vmax;
+    const int mx = (m_width + mcu_w - 1) / mcu_w, my = (m_height + mcu_h - 1) / mcu_h;
+    const int ux = ns > 1 ? mx : sc[0]->nbx, uy = ns > 1 ? my : sc[0]->nby;
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    int eobrun = 0, count = 0;
+    auto block = [&](Component& c, int by, int bx) {
+      int* blk = &c.coef[(size_t(by) * size_t(c.bw / 8) + size_t(bx)) * 64];
+      if (Ss == 0) {
+        if (Ah == 0) {
+          const int t = decode(m_dc[c.td]);
+          if (t > 11) throw std::runtime_error("jpeg: bad DC size");
+          c.pred += extend(receive(t), t);
+          blk[0] = c.pred * (1 << Al);
+        } else if (bit()) blk[0] |= p1;
+        return;
+      }
+      const Table& tab = m_ac[c.ta];
+      if (Ah == 0) {
+        if (eobrun) { --eobrun; return; }
+        for (int k = Ss; k <= Se;) {
+          const int rs = decode(tab);
+          const int r = rs >> 4, sz = rs & 15;
+          if (sz == 0) {
+            if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += receive(r); break; }
+            k += 16;
+            continue;
+          }
+          k += r;
+          if (k > Se) throw std::runtime_error("jpeg: bad AC run");
+          blk[zz[k]] = extend(receive(sz), sz) * (1 << Al);
+          ++k;
+        }
+        return;
+      }
+      int k = Ss;  // refinement of an AC band (annex G.2.3)
+      if (eobrun == 0) {
+        for (; k <= Se; ++k) {
+          const int rs = decode(tab);
+          int r = rs >> 4;
+          const int sz = rs & 15;
+          int value = 0;
+          if (sz) {
+            if (sz != 1) throw std::runtime_error("jpeg: bad refinement code");
+            value = bit() ? p1 : m1;
+          } else if (r != 15) {
+            eobrun = 1 << r;
+            if (r) eobrun += receive(r);
+            break;
+          }
+          for (; k <= Se; ++k) {
+            int& v = blk[zz[k]];
+            if (v != 0) refine_nonzero(v, p1, m1);
+            else if (--r < 0) break;
+          }
+          if (value) {
+            if (k > Se) throw std::runtime_error("jpeg: bad AC run");
+            blk[zz[k]] = value;
+          }
+        }
+      }
+      if (eobrun > 0) {
+        for (; k <= Se; ++k) {
+          int& v = blk[zz[k]];
+          if (v != 0) refine_nonzero(v, p1, m1);
+        }
+        --eobrun;
+      }
+    };
+    for (int y = 0; y < uy; ++y)
+      for (int x = 0; x < ux; ++x) {
+        if (m_restart && count && count % m_restart == 0) { restart(); eobrun = 0; }
+        ++count;
+        if (ns > 1) {
+          for (int i = 0; i < ns; ++i)
+            for (int by = 0; by < sc[i]->v; ++by)
+              for (int bx = 0; bx < sc[i]->h; ++bx) block(*sc[i], y * sc[i]->v + by, x * sc[i]->h + bx);
+        } else block(*sc[0], y, x);
+      }
+  }
+  Image8 finish_progressive()
+  {
+    for (Component& c : m_comp) {
+      if (!m_q_set[c.tq]) throw std::runtime_error("jpeg: missing table");
+      c.plane.assign(size_t(c.bw) * size_t(c.bh), 0);
+      for (int by = 0; by < c.bh / 8; ++by)
+        for (int bx = 0; bx < c.bw / 8; ++bx) {
+          const int* q = &c.coef[(size_t(by) * size_t(c.bw / 8) + size_t(bx)) * 64];
+          int coef[64];
+          for (int i = 0; i < 64; ++i) coef[i] = q[i] * m_q[c.tq][i];
+          idct(coef, &c.plane[size_t(by * 8) * size_t(c.bw) + size_t(bx * 8)], c.bw);
+        }
+    }
+    return finish();
+  }
+
   // full-resolution plane of a component (triangle-filter upsampling)
   std::vector<uint8_t> upsampled(const Component& c) const
   {
@@ -658,7 +818,7 @@ inline Image8 load_rgba8(const std::filesystem::path& path, bool flip_vertically
   if (file.size() >= 8 && file[0] == 0x89 && file[1] == 'P') img = decode_png(file);
   else if (file.size() >= 2 && file[0] == 'P' && (file[1] == '5' || file[1] == '6')) img = decode_pnm(file);
   else if (file.size() >= 2 && file[0] == 0xff && file[1] == 0xd8) img = decode_jpeg(file);
-  else throw std::runtime_error("failed to load " + path.generic_string() + ": only PNG, baseline JPEG and binary PPM/PGM images are supported in this build");
+  else throw std::runtime_error("failed to load " + path.generic_string() + ": only PNG, JPEG (sequential or progressive Huffman) and binary PPM/PGM images are supported in this build");
   if (flip_vertically) {
     const size_t rb = (size_t)img.width * 4;
     std::vector<uint8_t> tmp(rb);

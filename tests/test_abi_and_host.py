@@ -346,13 +346,68 @@ def test_jpeg_decoders_agree_and_reconstruct(tmp_path, image_dump):
     flat = np.full((16, 16, 3), (120, 120, 120), np.uint8)
     I.write_jpeg(tmp_path / "flat.jpg", flat, quality=100)
     assert np.abs(I.load_rgba8(tmp_path / "flat.jpg", False)[..., :3].astype(int) - 120).max() <= 1
-    # progressive frames are rejected by both, not mis-decoded
+    # a sequential stream relabelled as progressive (SOF2) has scan parameters no progressive scan may have: rejected by both, not mis-decoded
     data = bytearray((tmp_path / "s11_0.jpg").read_bytes())
     data[data.index(b"\xff\xc0") + 1] = 0xC2
     (tmp_path / "prog.jpg").write_bytes(bytes(data))
     for loader in (lambda: I.load_rgba8(tmp_path / "prog.jpg"), lambda: image_dump("rgba8", tmp_path / "prog.jpg")):
         with pytest.raises(ValueError, match="progressive"):
             loader()
+
+
+def test_progressive_jpeg_decoders_agree_with_each_other_and_with_the_sequential_decode(tmp_path, image_dump):
+    """progressive JPEG (SOF2; stb_image, which the reference uses, decodes it -- scene.cpp:16): spectral selection, successive approximation
+    with refinement scans, end-of-band runs, restart intervals, interleaved DC scans and per-component AC scans whose block grid differs from the
+    MCU grid.  The same quantised coefficients written sequentially and progressively must decode to IDENTICAL bytes, through the C++ reader and
+    through the Python reader; a stream cut after its first scans decodes to an approximation."""
+    from fredholm_amd import image_io as I
+    rng = np.random.default_rng(33)
+    yy, xx = np.mgrid[0:45, 0:70]
+    img = np.stack([80 + 1.5 * xx + 0.5 * yy, 200 - 2.0 * yy + 0.3 * xx, 60 + 1.2 * (xx + yy)], axis=-1)
+    img[10:30, 20:50] = rng.integers(0, 256, (20, 30, 3))  # a busy patch: long runs, many refinement bits, large EOB runs around it
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    n = 0
+    for sub in ((1, 1), (2, 1), (1, 2), (2, 2)):
+        for ri in (0, 3):
+            seq, pro = tmp_path / f"seq{sub[0]}{sub[1]}_{ri}.jpg", tmp_path / f"pro{sub[0]}{sub[1]}_{ri}.jpg"
+            I.write_jpeg(seq, img, quality=88, subsampling=sub, restart_interval=ri)
+            I.write_jpeg_progressive(pro, img, quality=88, subsampling=sub, restart_interval=ri)
+            assert b"\xff\xc2" in pro.read_bytes() and pro.read_bytes().count(b"\xff\xda") == 10
+            want = I.load_rgba8(seq, False)
+            py, cpp = I.load_rgba8(pro, False), image_dump("rgba8", pro)
+            assert np.array_equal(py, want) and np.array_equal(cpp, want), (sub, ri)
+            assert np.array_equal(image_dump("rgba8_flip", pro), want[::-1])
+            n += 1
+    assert n == 8
+    g = tmp_path / "grey_pro.jpg"
+    I.write_jpeg(tmp_path / "grey_seq.jpg", img[..., 1], quality=75)
+    I.write_jpeg_progressive(g, img[..., 1], quality=75)
+    assert np.array_equal(I.load_rgba8(g, False), I.load_rgba8(tmp_path / "grey_seq.jpg", False)) and np.array_equal(image_dump("rgba8", g), I.load_rgba8(g, False))
+    # other scan scripts: no successive approximation at all; one band per scan; DC only (a legal file: every scan is optional)
+    scripts = {"spectral_only": [([0, 1, 2], 0, 0, 0, 0), ([0], 1, 9, 0, 0), ([0], 10, 63, 0, 0), ([1], 1, 63, 0, 0), ([2], 1, 63, 0, 0)],
+               "deep_approximation": [([0, 1, 2], 0, 0, 0, 2), ([0, 1, 2], 0, 0, 2, 1), ([0, 1, 2], 0, 0, 1, 0)] + [([c], 1, 63, 0, 3) for c in (0, 1, 2)] +
+                                     [([c], 1, 63, a + 1, a) for a in (2, 1, 0) for c in (0, 1, 2)]}
+    I.write_jpeg(tmp_path / "ref.jpg", img, quality=92, subsampling=(2, 2))
+    want = I.load_rgba8(tmp_path / "ref.jpg", False)
+    for name, script in scripts.items():
+        f = tmp_path / f"{name}.jpg"
+        I.write_jpeg_progressive(f, img, quality=92, subsampling=(2, 2), script=script)
+        assert np.array_equal(I.load_rgba8(f, False), want) and np.array_equal(image_dump("rgba8", f), want), name
+    coarse = tmp_path / "coarse.jpg"
+    I.write_jpeg_progressive(coarse, img, quality=92, subsampling=(2, 2), script=[([0, 1, 2], 0, 0, 0, 1), ([0], 1, 5, 0, 2)])
+    py, cpp = I.load_rgba8(coarse, False), image_dump("rgba8", coarse)
+    err = np.abs(py[..., :3].astype(int) - want[..., :3].astype(int))
+    assert np.array_equal(py, cpp) and 1.0 < err.mean() < 40.0  # a preview, neither exact nor garbage
+    # damaged progressive streams raise, never crash or hang
+    data = pro.read_bytes()
+    for cut in (len(data) // 3, len(data) // 2, len(data) - 40):
+        bad = tmp_path / "cut.jpg"
+        bad.write_bytes(data[:cut])
+        for loader in (lambda: I.load_rgba8(bad), lambda: image_dump("rgba8", bad)):
+            try:
+                loader()  # a cut inside entropy data decodes the rest as zero bits -- allowed -- or raises ValueError
+            except ValueError:
+                pass
 
 
 def test_png_writer_round_trip(tmp_path, image_dump):
