@@ -608,6 +608,7 @@ int fh_sync(fh_ctx* ctx)
       else if (s.kind == 4) ctx->stats.generate_ms += ms;
       else if (s.kind == 5) ctx->stats.accumulate_ms += ms;
       else if (s.kind == 6) ctx->stats.queue_ms += ms;
+      else if (s.kind == 7) ctx->stats.post_ms += ms;
       else ctx->stats.shade_ms += ms;
     }
     ctx->event_pool.push_back(s.a);

@@ -143,6 +143,11 @@ __global__ void __launch_bounds__(256) k_atrous(const float4* src, const float4*
 int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int w, int h, const fh_post_params* pp, float* out)
 {
   hipStream_t st = ctx->stream;
+  // FH_FLAG_TIME_KERNELS: HIP events around the whole chain (fh_stats.post_ms, reduced at fh_sync like the render spans: kind 7)
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  const bool timed = (ctx->flags & FH_FLAG_TIME_KERNELS) != 0;
+  auto take = [&]() { hipEvent_t e = nullptr; if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+  if (timed) { ev_a = take(); ev_b = take(); (void)hipEventRecord(ev_a, st); }
   const int bx = w / kT > 1 ? w / kT : 1, by = h / kT > 1 ? h / kT : 1;  // floor division, post-process.cu:9-11
   const int gw = bx * kT < w ? bx * kT : w, gh = by * kT < h ? by * kT : h;
   const dim3 grid(bx, by), block(kT, kT);
@@ -173,6 +178,7 @@ int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int
   }
   const float exposure = exposure_from_ev100(ev100_of(1.0f, 1.0f, pp->ISO));
   hipLaunchKernelGGL(k_tone_map, grid, block, 0, st, (const float4*)tmp, w, h, gw, gh, exposure, pp->chromatic_aberration, (float4*)out);
+  if (timed) { (void)hipEventRecord(ev_b, st); ctx->spans.push_back({ev_a, ev_b, 7}); ctx->stats.n_post_launches++; }
   FH_HIP(hipGetLastError());
   return FH_OK;
 }

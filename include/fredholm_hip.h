@@ -117,6 +117,8 @@ typedef struct fh_stats {
   uint64_t n_generate_launches, n_accumulate_launches, n_shade_launches, n_tail_launches;
   uint64_t shaded_hits; /* surface hits shaded by the k_shade kernels (only when FH_FLAG_COUNT_TRAVERSAL) */
   uint64_t bvh_depth;   /* levels of the wide BVH = entries of the LDS traversal stack */
+  double post_ms;       /* summed HIP-event time of the fh_post_process chains (threshold + blur + tone map) */
+  uint64_t n_post_launches;
 } fh_stats;
 
 #define FH_FLAG_TIME_KERNELS 1u    /* bracket traversal/shade launches with HIP events (fh_stats *_ms) */
