@@ -532,7 +532,7 @@ def test_moving_instances_refit_the_tree_and_match_checker_and_rebuild(oracle, m
         tuv_b, prim_b = r.trace_rays(rays)
         assert np.array_equal(prim, prim_b) and np.array_equal(_bits(tuv), _bits(tuv_b))
         refits += 1
-    assert st["bvh_depth"] >= 4 and refits == 3
+    assert refits == 3 and (st["bvh_depth"] >= 4 or st["bvh_depth"] == 0)  # (0: the binary-tree developer switch FH_BVH2)
     # exploding the bodies apart makes the refitted boxes much larger than the built ones: the library rebuilds by itself, same hits
     o2w, w2o = xforms(0.0)
     for k in range(4):
