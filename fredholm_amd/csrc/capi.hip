@@ -138,7 +138,11 @@ int rebuild_device_scene(fh_ctx* ctx)
     const uint32_t lobes = material_lobes(ctx->h_materials[i]);
     mats[i].lobes = lobes;
     mats[i].emissive = material_emissive(ctx->h_materials[i]) ? 1u : 0u;
-    mats[i].alpha = (ctx->h_materials[i].base_color_texture_id >= 0 || ctx->h_materials[i].alpha_texture_id >= 0) ? 1u : 0u;
+    {  // alpha: 1 = some fetch of the material's textures can fail the any-hit test; 2 = only a non-finite texture coordinate can (the texture unit returns 0 for it)
+      const int32_t bt = ctx->h_materials[i].base_color_texture_id, at = ctx->h_materials[i].alpha_texture_id;
+      const bool cuts = (bt >= 0 && ctx->h_tex_alpha_cuts[(size_t)bt]) || (at >= 0 && ctx->h_tex_red_cuts[(size_t)at]);
+      mats[i].alpha = cuts ? 1u : ((bt >= 0 || at >= 0) ? 2u : 0u);
+    }
     uint32_t c = 0;
     for (; c < ctx->n_classes; ++c)
       if (ctx->class_lobes[c] == lobes) break;
@@ -158,6 +162,7 @@ int rebuild_device_scene(fh_ctx* ctx)
   std::vector<uint8_t> cls(nf);
   std::vector<uint2> meta(nf);
   std::vector<AreaLightDev> lights;
+  std::vector<uint8_t> alpha_bits(nf, 0);  // bit 0: test the base-colour texture's alpha, bit 1: test the alpha texture's red
   bool any_alpha = false;
   for (uint32_t f = 0; f < nf; ++f) {
     const uint32_t inst = ctx->h_instance_ids.empty() ? 0u : ctx->h_instance_ids[f];
@@ -167,8 +172,19 @@ int rebuild_device_scene(fh_ctx* ctx)
     for (int k = 0; k < 3; ++k)
       if (ctx->h_indices[3ull * f + k] >= nv) return fail(ctx, FH_E_INVALID, "vertex index out of range");
     meta[f] = make_uint2(mid, inst);
-    cls[f] = (uint8_t)(mats[mid].cls | (mats[mid].emissive ? 0x80u : 0u) | (mats[mid].alpha ? 0x40u : 0u));
-    if (mats[mid].alpha) any_alpha = true;
+    bool alpha = mats[mid].alpha == 1u;
+    if (mats[mid].alpha) {
+      bool wild = false;  // opaque textures: the test can only fail where the interpolated coordinate is NaN or overflows
+      for (int k = 0; k < 3; ++k) {
+        const size_t v = ctx->h_indices[3ull * f + k];
+        if (!(std::fabs(ctx->h_texcoords[2 * v]) < 1e30f) || !(std::fabs(ctx->h_texcoords[2 * v + 1]) < 1e30f)) wild = true;
+      }
+      alpha = alpha || wild;
+      const int32_t bt = ctx->h_materials[mid].base_color_texture_id, at = ctx->h_materials[mid].alpha_texture_id;
+      alpha_bits[f] = (uint8_t)(((bt >= 0 && (wild || ctx->h_tex_alpha_cuts[(size_t)bt])) ? 1u : 0u) | ((at >= 0 && (wild || ctx->h_tex_red_cuts[(size_t)at])) ? 2u : 0u));
+    }
+    cls[f] = (uint8_t)(mats[mid].cls | (mats[mid].emissive ? 0x80u : 0u) | (alpha ? 0x40u : 0u));
+    if (alpha) any_alpha = true;
     if (mats[mid].emissive) lights.push_back({f, mid});  // renderer.h:388-402, face order
   }
   auto re_alloc = [&](auto*& ptr, size_t bytes) -> hipError_t {
@@ -196,6 +212,34 @@ int rebuild_device_scene(fh_ctx* ctx)
   ctx->n_lights = (uint32_t)lights.size();
   ctx->n_materials = nm;
   ctx->has_alpha = any_alpha;
+  if (ctx->d_alpha_rec) { (void)hipFree(ctx->d_alpha_rec); ctx->d_alpha_rec = nullptr; }
+  if (any_alpha) {
+    // everything the any-hit test of a face reads, in one 64-byte line: the three texture coordinates and the two textures it may have to look at
+    std::vector<uint4> rec(4ull * nf, make_uint4(0u, 0u, 0u, 0u));
+    auto bits = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u; };
+    for (uint32_t f = 0; f < nf; ++f) {
+      if (!alpha_bits[f]) continue;
+      const fh_material& m = ctx->h_materials[ctx->h_material_ids[f]];
+      const float* tc = ctx->h_texcoords.data();
+      const size_t v0 = ctx->h_indices[3ull * f], v1 = ctx->h_indices[3ull * f + 1], v2 = ctx->h_indices[3ull * f + 2];
+      rec[4ull * f] = make_uint4(bits(tc[2 * v0]), bits(tc[2 * v0 + 1]), bits(tc[2 * v1]), bits(tc[2 * v1 + 1]));
+      uint32_t flags = alpha_bits[f];
+      if ((flags & 2u) && ctx->h_tex_desc[(size_t)m.alpha_texture_id].srgb) flags |= 4u;
+      rec[4ull * f + 1] = make_uint4(bits(tc[2 * v2]), bits(tc[2 * v2 + 1]), flags, 0u);
+      if (flags & 1u) {
+        const fht_texture& t = ctx->h_tex_desc[(size_t)m.base_color_texture_id];
+        const unsigned long long p = (unsigned long long)(uintptr_t)t.rgba8;
+        rec[4ull * f + 2] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), t.width, t.height);
+      }
+      if (flags & 2u) {
+        const fht_texture& t = ctx->h_tex_desc[(size_t)m.alpha_texture_id];
+        const unsigned long long p = (unsigned long long)(uintptr_t)t.rgba8;
+        rec[4ull * f + 3] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), t.width, t.height);
+      }
+    }
+    FH_HIP(hipMalloc((void**)&ctx->d_alpha_rec, rec.size() * sizeof(uint4)));
+    FH_HIP(hipMemcpy(ctx->d_alpha_rec, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice));
+  }
   ctx->refit_ok = false;  // new topology: the next build is a full one
   return transform_faces(ctx);
 }
@@ -212,11 +256,24 @@ int upload_textures(fh_ctx* ctx, uint32_t n, const fh_texture_desc* descs)
     FH_HIP(hipMalloc((void**)&ctx->d_srgb_lut, sizeof lut));
     FH_HIP(hipMemcpy(ctx->d_srgb_lut, lut, sizeof lut, hipMemcpyHostToDevice));
   }
+  ctx->h_tex_alpha_cuts.assign(n, 0);
+  ctx->h_tex_red_cuts.assign(n, 0);
+  ctx->h_tex_desc.clear();
   if (n == 0) return FH_OK;
   size_t total = 0;
   for (uint32_t i = 0; i < n; ++i) {
     if (!descs[i].rgba8 || descs[i].width == 0 || descs[i].height == 0) return fail(ctx, FH_E_INVALID, "fh_scene_upload: empty texture");
     total += (size_t)descs[i].width * descs[i].height * 4;
+    // The any-hit programs discard a hit when the filtered alpha (base-colour texture) or red (alpha texture) is below 0.5 (pt.cu:545-678).  A filtered
+    // value is a convex combination of texel values (weights are multiples of 2^-16 that sum to exactly 1), so a texture whose every texel decodes to
+    // >= 0.501 can never discard a hit: faces that only reference such textures need no any-hit test at all (most base-colour maps are opaque).
+    const uint8_t* px = descs[i].rgba8;
+    const size_t n_px = (size_t)descs[i].width * descs[i].height;
+    uint8_t min_a = 255, min_r = 255;
+    for (size_t k = 0; k < n_px; ++k) { min_r = px[4 * k] < min_r ? px[4 * k] : min_r; min_a = px[4 * k + 3] < min_a ? px[4 * k + 3] : min_a; }
+    const float red = descs[i].srgb ? fht_srgb_to_linear((float)min_r * (1.0f / 255.0f)) : (float)min_r * (1.0f / 255.0f);
+    ctx->h_tex_alpha_cuts[i] = (float)min_a * (1.0f / 255.0f) < 0.501f ? 1 : 0;
+    ctx->h_tex_red_cuts[i] = red < 0.501f ? 1 : 0;
   }
   FH_HIP(hipMalloc((void**)&ctx->d_texels, total));
   std::vector<fht_texture> t(n);
@@ -229,6 +286,7 @@ int upload_textures(fh_ctx* ctx, uint32_t n, const fh_texture_desc* descs)
   }
   FH_HIP(hipMalloc((void**)&ctx->d_textures, n * sizeof(fht_texture)));
   FH_HIP(hipMemcpy(ctx->d_textures, t.data(), n * sizeof(fht_texture), hipMemcpyHostToDevice));
+  ctx->h_tex_desc = t;
   return FH_OK;
 }
 
@@ -289,6 +347,20 @@ int fh_ctx_create(int device, fh_ctx** out)
   if (hipMalloc((void**)&ctx->d_lut_sheen, kLutSheenBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_trace_counters, 32 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
   if (hipMemcpy(ctx->d_sobol, kSobolMatrices, kSobolMatricesBytes, hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
+  {
+    // byte-indexed form of the generator matrices: entry [dim][k][b] = XOR of the columns 8k + j selected by the bits j of b, so that the XOR over the 32 index
+    // bits (sobol.cu:10716-10727) becomes four table reads (fh_sampler.h: sobol_row_bytes); the integrator kernels stage the tables of their dimensions in LDS
+    std::vector<uint32_t> bytes((size_t)1024 * 4 * 256);
+    const uint32_t* mat = kSobolMatrices;
+    for (uint32_t dim = 0; dim < 1024u; ++dim)
+      for (uint32_t k = 0; k < 4u; ++k) {
+        uint32_t* t = &bytes[((size_t)dim * 4 + k) * 256];
+        t[0] = 0u;
+        for (uint32_t b = 1; b < 256u; ++b) t[b] = t[b & (b - 1u)] ^ mat[dim * 52u + 8u * k + (uint32_t)__builtin_ctz(b)];
+      }
+    if (hipMalloc((void**)&ctx->d_sobol_bytes, bytes.size() * sizeof(uint32_t)) != hipSuccess) return bail("hipMalloc failed");
+    if (hipMemcpy(ctx->d_sobol_bytes, bytes.data(), bytes.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
+  }
   (void)hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
   (void)hipMemset(ctx->d_trace_counters, 0, 32 * sizeof(unsigned long long));
@@ -320,6 +392,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_TAIL_PATHS", 64, 1 << 30, t.tail_paths);
     env_off("FH_SORT", t.sort_queues);
     t.debug_tail = getenv("FH_DEBUG_TAIL") != nullptr;
+    if (const char* e = getenv("FH_NO_ALPHA")) t.ignore_alpha = e[0] == '1';
   }
   (void)hipEventCreate(&ctx->ev_render_begin);
   (void)hipEventCreate(&ctx->ev_render_end);
@@ -333,7 +406,7 @@ int fh_ctx_destroy(fh_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   pool_release(ctx);
-  void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
+  void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_sobol_bytes, ctx->d_alpha_rec, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
                   ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl,
                   ctx->d_bloom_weights, ctx->d_quirk_seen, ctx->d_quirk_aov, ctx->d_obj_vertices, ctx->d_obj_normals, ctx->d_obj_texcoords, ctx->d_obj_indices, ctx->d_face_meta, ctx->d_o2w, ctx->d_w2o,
                   ctx->d_bvh8_box, ctx->d_denoise_tmp[0], ctx->d_denoise_tmp[1]};

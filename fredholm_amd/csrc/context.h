@@ -19,6 +19,7 @@ struct fh_ctx {
 
   // constant tables
   uint32_t* d_sobol = nullptr;
+  uint32_t* d_sobol_bytes = nullptr;  // [1024 dims][4 index bytes][256]: byte-indexed generator matrices (capi.hip: fh_ctx_create)
   float* d_lut_refl = nullptr;
   float* d_lut_sheen = nullptr;
 
@@ -44,8 +45,10 @@ struct fh_ctx {
   float4* d_w2o = nullptr;
   uint32_t n_xf_alloc = 0;
   // textures (renderer.h:372-386): one device blob of texels + descriptors + the sRGB table
-  std::vector<std::vector<uint8_t>> h_textures;
-  std::vector<uint32_t> h_tex_w, h_tex_h, h_tex_srgb;
+  // per texture: can a filtered fetch of its alpha channel / of its red channel come out below the any-hit threshold 0.5 (upload_textures)?
+  std::vector<uint8_t> h_tex_alpha_cuts, h_tex_red_cuts;
+  std::vector<fht_texture> h_tex_desc;  // the descriptors as uploaded (device pointers)
+  uint4* d_alpha_rec = nullptr;         // 4 x 16 bytes per face when the scene has cut-outs: what the any-hit test of that face reads (fh_trace.h: alpha_pass)
   uint8_t* d_texels = nullptr;
   fht_texture* d_textures = nullptr;
   float* d_srgb_lut = nullptr;
@@ -127,6 +130,7 @@ struct fh_ctx {
     uint32_t tail_paths = 65536;    // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
     bool debug_tail = false;        // FH_DEBUG_TAIL
+    bool ignore_alpha = false;      // FH_NO_ALPHA=1 (timing experiments only: wrong images): cut-out textures are not tested during traversal
   } tun;
 
   // bloom weights of the last sigma used (post.hip): no allocation, upload or host synchronisation per frame

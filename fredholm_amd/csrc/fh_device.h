@@ -57,6 +57,7 @@ struct SceneDev {
   const fht_texture* textures;  // software texture unit (include/fh_texture_unit.h)
   const float* srgb_lut;        // 256-entry sRGB -> linear table
   uint32_t n_textures;
+  const uint4* alpha_rec;       // per face, scenes with cut-outs only: (uv0, uv1), (uv2, flags), (alpha-carrying base texture), (alpha texture)
   uint32_t has_alpha;           // some faces carry an alpha cut-out (pt.cu:545-678): traversal runs the any-hit test for them
   Bvh2Dev bvh2;
   Bvh8Dev bvh8;
@@ -84,7 +85,8 @@ struct FrameDev {
   f3 scene_lo, scene_hi;
   f3 cell_scale;  // 2^kCellBits / (scene_hi - scene_lo)
   // tables
-  const uint32_t* sobol;  // 1024 x 52
+  const uint32_t* sobol;        // 1024 x 52
+  const uint32_t* sobol_bytes;  // 1024 x 4 x 256, byte-indexed form
   BsdfTables lut;
 };
 

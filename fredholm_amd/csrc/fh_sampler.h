@@ -147,6 +147,13 @@ FH_HD uint32_t sobol_row(Ptr row, uint32_t index)
   return r;
 }
 
+// the same XOR from the byte-indexed form of the row ([4][256]: one table per byte of the index, fh_ctx_create): four reads, three XORs
+template <typename Ptr>
+FH_HD uint32_t sobol_row_bytes(Ptr t, uint32_t index)
+{
+  return t[index & 255u] ^ t[256u + ((index >> 8) & 255u)] ^ t[512u + ((index >> 16) & 255u)] ^ t[768u + (index >> 24)];
+}
+
 // 1-D draw: Owen-scrambled Sobol' point `sobol_index32` in dimension `dim` (sobol.cu:10733-10742).
 // sobol_index32 = uint32(image_idx + n_spp*W*H) as seeded by pt.cu:386.
 template <typename Ptr>
@@ -154,6 +161,13 @@ FH_HD float sobol_draw(Ptr row_of_dim, uint32_t sobol_index32, uint32_t dim, uin
 {
   const uint32_t index = owen_scramble(sobol_index32, seed_hash);
   const uint32_t v = owen_scramble(sobol_row(row_of_dim, index), hash_combine(seed_hash, dim));
+  return v * (1.0f / 4294967296.0f);
+}
+template <typename Ptr>
+FH_HD float sobol_draw_bytes(Ptr tables_of_dim, uint32_t sobol_index32, uint32_t dim, uint32_t seed_hash)
+{
+  const uint32_t index = owen_scramble(sobol_index32, seed_hash);
+  const uint32_t v = owen_scramble(sobol_row_bytes(tables_of_dim, index), hash_combine(seed_hash, dim));
   return v * (1.0f / 4294967296.0f);
 }
 

@@ -104,15 +104,22 @@ FH_D float4 tex_rgba(const SceneDev& sc, int id, float u, float v)
 }
 FH_D bool alpha_pass(const SceneDev& sc, uint32_t prim, float bu, float bv)
 {
-  const size_t fb = 7 * (size_t)prim;
-  const float4 r0 = sc.face_rec[fb], r1 = sc.face_rec[fb + 1], r2 = sc.face_rec[fb + 2], r3 = sc.face_rec[fb + 3], r4 = sc.face_rec[fb + 4], r5 = sc.face_rec[fb + 5];
+  // one 64-byte record per face (capi.hip: rebuild_device_scene): texture coordinates of the three vertices + the textures that can actually cut
+  // (a texture whose every texel is opaque is not listed: a filtered fetch of it cannot come out below 0.5)
+  const uint4* r = sc.alpha_rec + 4 * (size_t)prim;
+  const uint4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
   const float bw = 1.0f - bu - bv;
-  const float tu = bw * r0.w + bu * r2.w + bv * r4.w;
-  const float tv = bw * r1.w + bu * r3.w + bv * r5.w;
-  const MaterialDev& m = sc.materials[__float_as_uint(sc.face_rec[fb + 6].x)];
-  const int base_tex = __float_as_int(m.w[4]), alpha_tex = __float_as_int(m.w[44]);
-  if (base_tex >= 0 && tex_rgba(sc, base_tex, tu, tv).w < 0.5f) return false;
-  if (alpha_tex >= 0 && tex_rgba(sc, alpha_tex, tu, tv).x < 0.5f) return false;
+  const float tu = bw * __uint_as_float(q0.x) + bu * __uint_as_float(q0.z) + bv * __uint_as_float(q1.x);
+  const float tv = bw * __uint_as_float(q0.y) + bu * __uint_as_float(q0.w) + bv * __uint_as_float(q1.y);
+  const uint32_t flags = q1.z;
+  if (flags & 1u) {  // alpha of the base-colour texture
+    const uint8_t* tex = (const uint8_t*)(uintptr_t)(((unsigned long long)q2.y << 32) | q2.x);
+    if (fht_tex2d_channel8(tex, q2.z, q2.w, nullptr, 3u, tu, tv) < 0.5f) return false;
+  }
+  if (flags & 2u) {  // red of the alpha texture
+    const uint8_t* tex = (const uint8_t*)(uintptr_t)(((unsigned long long)q3.y << 32) | q3.x);
+    if (fht_tex2d_channel8(tex, q3.z, q3.w, (flags & 4u) ? sc.srgb_lut : nullptr, 0u, tu, tv) < 0.5f) return false;
+  }
   return true;
 }
 

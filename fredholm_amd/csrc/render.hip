@@ -47,16 +47,20 @@ constexpr uint32_t kMatLds = 32;  // material records staged in LDS by the shade
 #define FH_SHADE_BLOCKS 2  // resident workgroups per CU the specialised shade kernels are compiled for (register budget = 512 / that per lane): they need 208-230 registers
 #endif                     // since their products go to memory as they are made (PoolSink); the generic seven-lobe kernel keeps one wave per SIMD (391 registers, no spills)
 
-struct SobolRows {  // rows of the generator matrices this kernel needs, staged in LDS (32 columns each)
-  uint32_t m[4][32];
+// generator matrices of the N Sobol' dimensions a kernel draws from, staged in LDS in their byte-indexed form (4 KB per dimension, FrameDev::sobol_bytes):
+// the XOR over the 32 index bits is four LDS reads instead of 32 bit tests (~85 instructions less per draw; the shade kernels draw three or four per hit)
+template <int N>
+struct SobolRows {
+  uint32_t m[N][1024];
 };
 
-FH_D void load_sobol_rows(SobolRows& rows, const uint32_t* table, const uint32_t dims[4])
+template <int N>
+FH_D void load_sobol_rows(SobolRows<N>& rows, const uint32_t* tables, const uint32_t* dims)
 {
-  if (threadIdx.x < 128) {
-    const uint32_t r = threadIdx.x >> 5, c = threadIdx.x & 31;
-    rows.m[r][c] = table[(dims[r] & 1023u) * 52u + c];
-  }
+  static_assert(kBlock == 256, "one uint4 per thread and dimension");
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+    reinterpret_cast<uint4*>(rows.m[r])[threadIdx.x] = reinterpret_cast<const uint4*>(tables + (size_t)(dims[r] & 1023u) * 1024u)[threadIdx.x];
   __syncthreads();
 }
 
@@ -77,9 +81,9 @@ FH_D f3 env_radiance(const FrameDev& fr, f3 d)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, const uint32_t* issued, const uint32_t* owned, uint32_t n_owned, uint32_t n_paths)
 {
-  __shared__ SobolRows rows;
-  const uint32_t dims[4] = {1u, 1u, 1u, 1u};
-  load_sobol_rows(rows, fr.sobol, dims);
+  __shared__ SobolRows<1> rows;
+  const uint32_t dims[1] = {1u};
+  load_sobol_rows<1>(rows, fr.sobol_bytes, dims);
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t base = blockIdx.x * blockDim.x; base < n_paths; base += stride) {
     const uint32_t p = base + threadIdx.x;
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
       const f3 dir = xform_dir(fr.cam_xf, d);
       // Russian roulette of bounce 0 has probability 1 but still consumes (and can fail on) a draw, pt.cu:457-461
       const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
-      const float rr = sobol_draw(rows.m[0], sidx, 1u, fr.seed_hash);
+      const float rr = sobol_draw_bytes(rows.m[0], sidx, 1u, fr.seed_hash);
       alive = fr.max_depth > 0 && !(rr >= 1.0f);
       // camera rays that miss the (padded) scene bounds cannot hit anything: they are finished right here
       // (radiance = 0 + 1 * environment, pt.cu:504-523) and never enter the traversal queue, so the waves of
@@ -396,10 +400,10 @@ struct BounceSlots {
     slot_light = slot_sky + 1u + has_lights;
     slot_next = slot_light + 1u;
   }
-  FH_D void load_rows(SobolRows& rows, const uint32_t* table) const
+  FH_D void load_rows(SobolRows<4>& rows, const uint32_t* tables) const
   {
     const uint32_t dims[4] = {dim_area, dim_light, dim_next, dim_rr};
-    load_sobol_rows(rows, table, dims);
+    load_sobol_rows<4>(rows, tables, dims);
   }
 };
 
@@ -465,7 +469,7 @@ struct PoolSink {      // memory sink (k_shade): path slot p of the pool
 };
 
 template <uint32_t LOBES, class Sink>
-FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& rows, const BounceSlots& bs, uint32_t depth, float4 hit, f3 rd, f3 T, f3 L, uint32_t image_idx, uint32_t n_spp,
+FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows<4>& rows, const BounceSlots& bs, uint32_t depth, float4 hit, f3 rd, f3 T, f3 L, uint32_t image_idx, uint32_t n_spp,
                     Sink& out, bool first = true)
 {
   const uint32_t has_lights = bs.has_lights;
@@ -545,7 +549,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
   }
   // area lights (pt.cu:860-889, :282-322)
   if (has_lights) {
-    const float u1 = sobol_draw(rows.m[0], sidx, bs.dim_area, fr.seed_hash);
+    const float u1 = sobol_draw_bytes(rows.m[0], sidx, bs.dim_area, fr.seed_hash);
     const f2 u2 = cmj_draw(n_spp, image_idx, bs.slot_area, fr.seed_hash);
     uint32_t li = (uint32_t)(u1 * sc.n_lights);
     li = li < sc.n_lights - 1u ? li : sc.n_lights - 1u;
@@ -573,7 +577,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
   {
     f3 f;
     float pdf;
-    const float u1 = sobol_draw(rows.m[1], sidx, bs.dim_light, fr.seed_hash);
+    const float u1 = sobol_draw_bytes(rows.m[1], sidx, bs.dim_light, fr.seed_hash);
     const f2 u2 = cmj_draw(n_spp, image_idx, bs.slot_light, fr.seed_hash);
     const f3 wi = bsdf.sample(wo, u1, u2, f, pdf);
     const f3 ld = to_world(wi, tangent, ns, bitangent);
@@ -594,7 +598,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
   {
     f3 f;
     float pdf;
-    const float u1 = sobol_draw(rows.m[2], sidx, bs.dim_next, fr.seed_hash);
+    const float u1 = sobol_draw_bytes(rows.m[2], sidx, bs.dim_next, fr.seed_hash);
     const f2 u2 = cmj_draw(n_spp, image_idx, bs.slot_next, fr.seed_hash);
     const f3 wi = bsdf.sample(wo, u1, u2, f, pdf);
     const f3 wd = to_world(wi, tangent, ns, bitangent);
@@ -604,7 +608,7 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows& row
     const f3 no = offset_origin(x, transmitted ? -ng : ng);
     if (!bad3(Tn) && depth + 1u < fr.max_depth) {
       const float prr = clampf(lum(Tn), 0.0f, 1.0f);
-      const float u = sobol_draw(rows.m[3], sidx, bs.dim_rr, fr.seed_hash);
+      const float u = sobol_draw_bytes(rows.m[3], sidx, bs.dim_rr, fr.seed_hash);
       if (!(u >= prr)) out.next(no, wd, Tn / prr);
     }
   }
@@ -690,7 +694,7 @@ __global__ void __launch_bounds__(kSortBlock) k_cell_scatter(const uint32_t* cou
 template <uint32_t LOBES>
 __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : FH_SHADE_BLOCKS)) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
 {
-  __shared__ SobolRows rows;
+  __shared__ SobolRows<4> rows;
   // the shade kernels run one wave per SIMD (512 registers per lane), so nothing hides a dependent global load: the small tables every
   // hit reads -- the two albedo LUTs and, when there are few of them, the material records -- are staged in LDS once per workgroup
   __shared__ float s_lut[kLutReflFloats + kLutSheenFloats];
@@ -707,7 +711,7 @@ __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : FH_SHADE_BLOCKS)
   }
   BounceSlots bs;
   bs.set(fr, sc.n_lights, depth);
-  bs.load_rows(rows, fr.sobol);  // (ends with the workgroup barrier that also publishes the tables above)
+  bs.load_rows(rows, fr.sobol_bytes);  // (ends with the workgroup barrier that also publishes the tables above)
 
   uint32_t* cnt = pool.counters + depth * kCounterStride;
   uint32_t* cnt_next = cnt + kCounterStride;
@@ -966,7 +970,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, 
 // kernels, hence the same bits.
 __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth)
 {
-  __shared__ SobolRows rows;
+  __shared__ SobolRows<4> rows;
   __shared__ float s_lut[kLutReflFloats + kLutSheenFloats];  // as in k_shade: small tables every hit reads live in LDS
   __shared__ MaterialDev s_mat[kMatLds];
   for (uint32_t i = threadIdx.x; i < kLutReflFloats; i += blockDim.x) s_lut[i] = fr.lut.reflection[i];
@@ -999,7 +1003,7 @@ __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolD
       BounceSlots bs;
       bs.set(fr, sc.n_lights, depth);
       __syncthreads();  // rows of the previous bounce are no longer read
-      bs.load_rows(rows, fr.sobol);
+      bs.load_rows(rows, fr.sobol_bytes);
       if (alive) {
         HitRec h;
         uint32_t a = 0, b = 0;
@@ -1189,7 +1193,8 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.textures = ctx->d_textures;
   s.srgb_lut = ctx->d_srgb_lut;
   s.n_textures = ctx->n_textures;
-  s.has_alpha = ctx->has_alpha ? 1u : 0u;
+  s.alpha_rec = ctx->d_alpha_rec;
+  s.has_alpha = (ctx->has_alpha && !ctx->tun.ignore_alpha) ? 1u : 0u;
   s.bvh2.nodes = ctx->d_bvh2_nodes;
   s.bvh2.tris = ctx->d_bvh2_tris;
   s.bvh2.n_nodes = ctx->bvh2_n_nodes;
@@ -1324,6 +1329,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     fr.cell_scale = mk3(ex > 0.0f ? cells / ex : 0.0f, ey > 0.0f ? cells / ey : 0.0f, ez > 0.0f ? cells / ez : 0.0f);
   }
   fr.sobol = ctx->d_sobol;
+  fr.sobol_bytes = ctx->d_sobol_bytes;
   fr.lut.reflection = ctx->d_lut_refl;
   fr.lut.sheen = ctx->d_lut_sheen;
 

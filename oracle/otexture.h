@@ -64,7 +64,7 @@ inline void axis(float coord, uint32_t n, long long& index, int& weight256)
 // tex2D<float4>(texture, u, v)
 inline void tex2d(const OTexture& t, float u, float v, float out[4])
 {
-  if (std::isnan(u) || std::isnan(v) || t.width == 0 || t.height == 0) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+  if (!std::isfinite(u) || !std::isfinite(v) || t.width == 0 || t.height == 0) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }  // a NaN or infinite coordinate fetches 0
   long long i, j;
   int wa, wb;
   axis(u, t.width, i, wa);

@@ -45,6 +45,25 @@ __global__ void __launch_bounds__(256) k_rate(int iters, float* out, unsigned lo
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(m) : "v"(q));
       a[0] += __uint_as_float(m & 0xffu);
+    } else if (KIND >= 6) {  // integer / compare / select instructions on 16 independent registers
+      unsigned int* u = reinterpret_cast<unsigned int*>(a);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (KIND == 6) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(q));
+        if (KIND == 7) asm volatile("v_mul_u32_u24_e32 %0, %0, %1" : "+v"(u[i]) : "v"(q));
+        if (KIND == 8) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        if (KIND == 9) asm volatile("v_cvt_f32_ubyte2_e32 %0, %1" : "=v"(a[i]) : "v"(q));
+        if (KIND == 10) asm volatile("v_cmp_nle_f32_e64 s[20:21], %0, %1" : : "v"(a[i]), "v"(s) : "s20", "s21");
+        if (KIND == 11) asm volatile("v_cndmask_b32_e64 %0, %0, 0, s[20:21]" : "+v"(u[i]) : : "s20", "s21");
+        if (KIND == 12) asm volatile("v_bfe_u32 %0, %0, 5, 3" : "+v"(u[i]));
+        if (KIND == 13) asm volatile("v_xor_b32_e32 %0, %0, %1" : "+v"(u[i]) : "v"(q));
+        if (KIND == 14) asm volatile("v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(u[i]) : "v"(q));
+        if (KIND == 15) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(u[i]) : "v"(q), "v"(u[(i + 1) & 15]));
+        if (KIND == 16) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(*reinterpret_cast<double*>(&p[i])) : "v"(*reinterpret_cast<const double*>(&s2)), "v"(*reinterpret_cast<const double*>(&o2)));
+        if (KIND == 17) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(q), "v"(u[(i + 1) & 15]));
+        if (KIND == 18) asm volatile("v_rcp_f32_e32 %0, %0" : "+v"(a[i]));
+        if (KIND == 19) asm volatile("v_sqrt_f32_e32 %0, %0" : "+v"(a[i]));
+      }
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -91,5 +110,19 @@ int main()
   run<3>("v_max3_f32", n_cus);
   run<4>("v_pk_mul_f32", n_cus);
   run<5>("v_lshl_or_b32", n_cus);
+  run<6>("v_mul_lo_u32", n_cus);
+  run<7>("v_mul_u32_u24", n_cus);
+  run<8>("v_max_f32", n_cus);
+  run<9>("v_cvt_f32_ubyte2", n_cus);
+  run<10>("v_cmp_nle_f32 (sgpr)", n_cus);
+  run<11>("v_cndmask (sgpr)", n_cus);
+  run<12>("v_bfe_u32", n_cus);
+  run<13>("v_xor_b32", n_cus);
+  run<14>("v_lshlrev_b32 sdwa", n_cus);
+  run<15>("v_mad_u32_u24", n_cus);
+  run<16>("v_fma_f64", n_cus);
+  run<17>("v_or3_b32", n_cus);
+  run<18>("v_rcp_f32", n_cus);
+  run<19>("v_sqrt_f32", n_cus);
   return 0;
 }
