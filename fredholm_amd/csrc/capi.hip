@@ -393,6 +393,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_off("FH_SORT", t.sort_queues);
     t.debug_tail = getenv("FH_DEBUG_TAIL") != nullptr;
     if (const char* e = getenv("FH_NO_ALPHA")) t.ignore_alpha = e[0] == '1';
+    if (const char* e = getenv("FH_FORCE_ALPHA")) t.force_alpha = e[0] == '1';
   }
   (void)hipEventCreate(&ctx->ev_render_begin);
   (void)hipEventCreate(&ctx->ev_render_end);

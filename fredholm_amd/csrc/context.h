@@ -130,6 +130,7 @@ struct fh_ctx {
     uint32_t tail_paths = 65536;    // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
     bool debug_tail = false;        // FH_DEBUG_TAIL
+    bool force_alpha = false;       // FH_FORCE_ALPHA=1 (timing experiments): the kernels with the any-hit path compiled in, whatever the scene
     bool ignore_alpha = false;      // FH_NO_ALPHA=1 (timing experiments only: wrong images): cut-out textures are not tested during traversal
   } tun;
 

@@ -102,7 +102,7 @@ FH_D float4 tex_rgba(const SceneDev& sc, int id, float u, float v)
   fht_tex2d(&sc.textures[id], sc.srgb_lut, u, v, o);
   return make_float4(o[0], o[1], o[2], o[3]);
 }
-FH_D bool alpha_pass(const SceneDev& sc, uint32_t prim, float bu, float bv)
+__device__ __attribute__((noinline)) bool alpha_pass(const SceneDev& sc, uint32_t prim, float bu, float bv)
 {
   // one 64-byte record per face (capi.hip: rebuild_device_scene): texture coordinates of the three vertices + the textures that can actually cut
   // (a texture whose every texel is opaque is not listed: a filtered fetch of it cannot come out below 0.5)

@@ -1194,7 +1194,7 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.srgb_lut = ctx->d_srgb_lut;
   s.n_textures = ctx->n_textures;
   s.alpha_rec = ctx->d_alpha_rec;
-  s.has_alpha = (ctx->has_alpha && !ctx->tun.ignore_alpha) ? 1u : 0u;
+  s.has_alpha = ((ctx->has_alpha && !ctx->tun.ignore_alpha) || ctx->tun.force_alpha) ? 1u : 0u;
   s.bvh2.nodes = ctx->d_bvh2_nodes;
   s.bvh2.tris = ctx->d_bvh2_tris;
   s.bvh2.n_nodes = ctx->bvh2_n_nodes;

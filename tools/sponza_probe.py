@@ -25,7 +25,7 @@ for k in ("closest", "shadow"):
     print(f"{k}: rays {rays} nodes/ray {n/max(rays,1):.2f} tris/ray {t/max(rays,1):.2f} node lane util {n/max(64*wn,1):.3f} tri lane util {t/max(64*wt,1):.3f} "
           f"wave node steps/ray {wn/max(rays,1):.3f} wave tri steps/ray {wt/max(rays,1):.3f}", flush=True)
 print("bvh depth", s.get("bvh_depth"), "shaded hits", s.get("shaded_hits"))
-for flags, name in ((N.FLAG_SERIAL_PASSES, "alone"), (0, "pipelined")):
+for flags, name in ((N.FLAG_SERIAL_PASSES | N.FLAG_TIME_KERNELS, "alone"), (0, "pipelined")):
     r.set_flags(flags)
     L.clear(); r.init_render_states()
     r.render(cam, w["bg"], L, spp, w["depth"]); r.wait_for_completion()   # warm-up (adaptive tail depth, pools)
