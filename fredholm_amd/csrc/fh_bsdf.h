@@ -32,15 +32,15 @@ struct MatParams {  // the reference's ShadingParams (shared.h:173-199) after fi
 
 
 FH_HD float abs_cos(f3 w) { return fabsf(w.y); }
-FH_HD float sin_t(f3 w) { return sqrtf(fmaxf(1.0f - w.y * w.y, 0.0f)); }
-FH_HD float sin_p(f3 w) { return w.z / sqrtf(fmaxf(1.0f - w.y * w.y, 0.0f)); }
-FH_HD float cos_p(f3 w) { return w.x / sqrtf(fmaxf(1.0f - w.y * w.y, 0.0f)); }
+FH_HD float sin_t(f3 w) { return sqrt_cr(fmaxf(1.0f - w.y * w.y, 0.0f)); }
+FH_HD float sin_p(f3 w) { return w.z / sqrt_cr(fmaxf(1.0f - w.y * w.y, 0.0f)); }
+FH_HD float cos_p(f3 w) { return w.x / sqrt_cr(fmaxf(1.0f - w.y * w.y, 0.0f)); }
 FH_HD f3 reflect_about(f3 w, f3 n) { return normalize(-w + 2.0f * dot(w, n) * n); }
 FH_HD bool refract_through(f3 w, f3 n, float ni, float nt, f3& wt)
 {
   const f3 th = -ni / nt * (w - dot(w, n) * n);
   if (dot(th, th) > 1.0f) return false;
-  const f3 tp = -sqrtf(fmaxf(1.0f - dot(th, th), 0.0f)) * n;
+  const f3 tp = -sqrt_cr(fmaxf(1.0f - dot(th, th), 0.0f)) * n;
   wt = th + tp;
   return true;
 }
@@ -48,7 +48,7 @@ FH_HD float fresnel_dielectric(float c, float ior)
 {
   const float temp = ior * ior + c * c - 1.0f;
   if (temp < 0.0f) return 1.0f;
-  const float g = sqrtf(temp);
+  const float g = sqrt_cr(temp);
   const float t0 = (g - c) / (g + c);
   const float t1 = ((g + c) * c - 1.0f) / ((g - c) * c + 1.0f);
   return 0.5f * t0 * t0 * (1.0f + t1 * t1);
@@ -72,7 +72,7 @@ FH_HD float ggx_D(float ax, float ay, f3 wh)
 FH_HD float ggx_lambda(float ax, float ay, f3 w)
 {
   const float t = (ax * ax * w.x * w.x + ay * ay * w.z * w.z) / (w.y * w.y);
-  return 0.5f * (-1.0f + sqrtf(1.0f + t));
+  return 0.5f * (-1.0f + sqrt_cr(1.0f + t));
 }
 FH_HD float ggx_G2(float ax, float ay, f3 wo, f3 wi) { return 1.0f / (1.0f + ggx_lambda(ax, ay, wo) + ggx_lambda(ax, ay, wi)); }
 FH_HD float ggx_Dvis(float ax, float ay, f3 w, f3 wh)

@@ -90,28 +90,39 @@ struct FrameDev {
   BsdfTables lut;
 };
 
+// A path's state is kept in records, not in one array per field: after the first bounce the queues hold path slots in spatial order, so every access to
+// slot p is a random one and a kernel that touches n fields of a path touched n cache lines.  With records the closest-hit kernel reads a ray and writes its
+// hit in ONE 64-byte line, the shade kernel finds ray, throughput and hit in that same line, and the up to four secondary rays of a path are contiguous.
+// Rec<T, STRIDE>[p] addresses field T of record p (STRIDE in units of T), so kernels keep writing pool.ray_o[p].
+template <typename T, uint32_t STRIDE>
+struct Rec {
+  T* base;
+  FH_HD T& operator[](size_t p) const { return base[p * STRIDE]; }
+};
+
 struct PoolDev {
   uint32_t capacity;
-  float4* ray_o;  // origin.xyz, tmax
-  float4* ray_d;  // direction.xyz, -
-  float4* thr;    // throughput.xyz, -
-  float4* rad;    // radiance.xyz, -
-  float4* hit;    // t, u, v, face id bits (0xffffffff = miss)
-  uint32_t* pixel;
-  uint32_t* nspp;
+  // 64-byte path record
+  Rec<float4, 4> ray_o;  // origin.xyz, tmax
+  Rec<float4, 4> ray_d;  // direction.xyz, -
+  Rec<float4, 4> thr;    // throughput.xyz, -
+  Rec<float4, 4> hit;    // t, u, v, face id bits (0xffffffff = miss)
+  float4* rad;           // radiance.xyz, -   (its own array: k_accumulate streams it)
+  // 8-byte identity record
+  Rec<uint32_t, 2> pixel;
+  Rec<uint32_t, 2> nspp;
   uint32_t* flags;  // bit0: first-hit AOVs valid, bit1: path ended before its first ray (Russian roulette draw of 1.0)
-  // first-hit AOV staging (pt.cu:745-751)
-  float4* aov_position;
-  float4* aov_normal;
-  float4* aov_albedo;
-  float4* aov_texdepth;  // texcoord.xy, depth, -
-  // secondary rays, [slot * capacity + p]
-  float4* sec_o;  // origin.xyz, tmax
-  float4* sec_d;  // direction.xyz, active (1.0f) / inactive (0.0f)
-  float4* sec_c;  // contribution rgb if unoccluded
-  // BSDF-sampled light ray when the scene has emitters (needs the hit to finish the MIS weight)
-  float4* lp_a;   // throughput.xyz, |cos|
-  float4* lp_b;   // f.xyz, pdf
+  // first-hit AOV staging (pt.cu:745-751), one 64-byte record
+  Rec<float4, 4> aov_position;
+  Rec<float4, 4> aov_normal;
+  Rec<float4, 4> aov_albedo;
+  Rec<float4, 4> aov_texdepth;  // texcoord.xy, depth, -
+  // secondary rays: SEC_COUNT x 3 float4 per path -- origin.xyz + tmax, direction.xyz + active (1.0f) / inactive (0.0f), contribution rgb if unoccluded
+  float4* sec;
+  FH_HD size_t sec_at(uint32_t slot, uint32_t p) const { return ((size_t)p * SEC_COUNT + slot) * 3u; }
+  // BSDF-sampled light ray when the scene has emitters (needs the hit to finish the MIS weight), one 32-byte record
+  Rec<float4, 2> lp_a;   // throughput.xyz, |cos|
+  Rec<float4, 2> lp_b;   // f.xyz, pdf
   // queues
   uint32_t* q_rad[2];            // radiance-ray queue, ping-pong per bounce
   uint32_t* q_cls;               // kNumQueues x capacity: hits routed by shading class

@@ -186,11 +186,11 @@ FH_HD f2 concentric_disk(f2 u)
 FH_HD f3 cosine_hemisphere(f2 u)
 {
   const f2 d = concentric_disk(u);
-  return mk3(d.x, sqrtf(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y)), d.y);
+  return mk3(d.x, sqrt_cr(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y)), d.y);
 }
 FH_HD f2 triangle_barycentric(f2 u)
 {
-  const float su0 = sqrtf(u.x);
+  const float su0 = sqrt_cr(u.x);
   return mk2(1.0f - su0, u.y * su0);
 }
 // Heitz 2018 visible-normal sampling; phi is formed in double and rounded (the reference mixes M_PI in)
@@ -198,17 +198,17 @@ FH_HD f3 sample_vndf(f3 wo, float ax, float ay, f2 u)
 {
   const f3 Vh = normalize(mk3(ax * wo.x, wo.y, ay * wo.z));
   const float lensq = Vh.x * Vh.x + Vh.z * Vh.z;
-  const f3 T1 = lensq > 0 ? mk3(Vh.z, 0, -Vh.x) / sqrtf(lensq) : mk3(0, 0, 1);
+  const f3 T1 = lensq > 0 ? mk3(Vh.z, 0, -Vh.x) / sqrt_cr(lensq) : mk3(0, 0, 1);
   const f3 T2 = cross(Vh, T1);
-  const float r = sqrtf(u.x);
+  const float r = sqrt_cr(u.x);
   const float phi = (float)(2.0f * 3.14159265358979323846 * u.y);
   float sp, cp;
   fhe_sincos(phi, &sp, &cp);
   const float t1 = r * cp;
   float t2 = r * sp;
   const float s = 0.5f * (1.0f + Vh.y);
-  t2 = (1.0f - s) * sqrtf(fmaxf(1.0f - t1 * t1, 0.0f)) + s * t2;
-  const f3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(1.0f - t1 * t1 - t2 * t2, 0.0f)) * Vh;
+  t2 = (1.0f - s) * sqrt_cr(fmaxf(1.0f - t1 * t1, 0.0f)) + s * t2;
+  const f3 Nh = t1 * T1 + t2 * T2 + sqrt_cr(fmaxf(1.0f - t1 * t1 - t2 * t2, 0.0f)) * Vh;
   return normalize(mk3(ax * Nh.x, fmaxf(0.0f, Nh.y), ay * Nh.z));
 }
 

@@ -55,7 +55,7 @@ FH_HD f3 hosek_radiance(const HosekSky& st, f3 sun_dir, float intensity, f3 v)
   const float gamma = fhe_acos(dot(sun_dir, v));
   const float cg = fhe_cos(gamma), ct = fhe_cos(theta);
   const float rayM = cg * cg;
-  const float zenith = sqrtf(ct);
+  const float zenith = sqrt_cr(ct);
   float out[3];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {

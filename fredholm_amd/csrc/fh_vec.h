@@ -10,6 +10,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "../../include/fh_elementary.h"
+
 #define FH_HD __host__ __device__ __forceinline__
 #define FH_D __device__ __forceinline__
 
@@ -43,15 +45,18 @@ FH_HD f3 operator/(f3 a, float s) { const float inv = 1.0f / s; return a * inv; 
 FH_HD f3& operator+=(f3& a, f3 b) { a = a + b; return a; }
 FH_HD f3& operator*=(f3& a, f3 b) { a = a * b; return a; }
 
+// correctly rounded square root (include/fh_elementary.h: the short device sequence, bit-identical to sqrtf)
+FH_HD float sqrt_cr(float x) { return fhe_sqrt(x); }
+
 FH_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 FH_HD f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-FH_HD float length(f3 a) { return sqrtf(dot(a, a)); }
-FH_HD f3 normalize(f3 a) { const float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+FH_HD float length(f3 a) { return sqrt_cr(dot(a, a)); }
+FH_HD f3 normalize(f3 a) { const float inv = 1.0f / sqrt_cr(dot(a, a)); return a * inv; }
 FH_HD float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
 FH_HD int clampi(int f, int a, int b) { return f < a ? a : (f > b ? b : f); }
 FH_HD f3 clamp01(f3 v) { return {clampf(v.x, 0.0f, 1.0f), clampf(v.y, 0.0f, 1.0f), clampf(v.z, 0.0f, 1.0f)}; }
 FH_HD f3 max3(f3 a, f3 b) { return {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }
-FH_HD f3 sqrt3(f3 a) { return {sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
+FH_HD f3 sqrt3(f3 a) { return {sqrt_cr(a.x), sqrt_cr(a.y), sqrt_cr(a.z)}; }
 FH_HD bool bad1(float v) { return isnan(v) || isinf(v); }
 FH_HD bool bad3(f3 v) { return bad1(v.x) || bad1(v.y) || bad1(v.z); }
 FH_HD float lum(f3 c) { return dot(c, mk3(0.2126729f, 0.7151522f, 0.0721750f)); }

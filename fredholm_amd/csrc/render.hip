@@ -374,10 +374,10 @@ FH_D f3 emission_of(const SceneDev& sc, const MaterialDev& m, float tu, float tv
 
 FH_D void store_secondary(const PoolDev& pool, uint32_t slot, uint32_t p, f3 o, float tmax, f3 d, bool active, f3 c)
 {
-  const size_t k = (size_t)slot * pool.capacity + p;
-  pool.sec_o[k] = mk4(o, tmax);
-  pool.sec_d[k] = mk4(d, active ? 1.0f : 0.0f);
-  pool.sec_c[k] = mk4(c, 0.0f);
+  const size_t k = pool.sec_at(slot, p);
+  pool.sec[k] = mk4(o, tmax);
+  pool.sec[k + 1] = mk4(d, active ? 1.0f : 0.0f);
+  pool.sec[k + 2] = mk4(c, 0.0f);
 }
 
 // Sobol' dimensions and CMJ slots of one bounce
@@ -790,10 +790,10 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
     for (uint32_t slot = SEC_DIR; slot <= SEC_LIGHT; ++slot) {
       if (slot == SEC_DIR && !fr.has_dir) continue;
       if (slot == SEC_AREA && !has_lights) continue;
-      const size_t k = (size_t)slot * pool.capacity + p;
-      const float4 d = pool.sec_d[k];
+      const size_t k = pool.sec_at(slot, p);
+      const float4 d = pool.sec[k + 1];
       if (d.w == 0.0f) continue;
-      const float4 o = pool.sec_o[k];
+      const float4 o = pool.sec[k];
       HitRec h;
       if (COUNT) nr++;
       if (slot == SEC_LIGHT && has_lights) {
@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
         const bool occluded = WIDE ? traverse_bvh8<true, COUNT, true, ALPHA>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack + threadIdx.x, kBlock, &sc)
                                    : traverse_bvh2<true, COUNT, ALPHA>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt, &sc);
         if (COUNT) { const uint32_t kk = nn - nn0; int b = 0; while (b < 7 && kk > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
-        if (!occluded) L += mk3(pool.sec_c[k]);
+        if (!occluded) L += mk3(pool.sec[k + 2]);
       }
     }
     pool.rad[p] = mk4(L, 0.0f);
@@ -841,11 +841,11 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_coop(SceneDev sc, Fr
     for (uint32_t slot = SEC_DIR; slot <= SEC_LIGHT; ++slot) {
       if (slot == SEC_DIR && !fr.has_dir) continue;
       if (slot == SEC_AREA && !has_lights) continue;
-      const size_t k = (size_t)slot * pool.capacity + p;
-      const float4 d = in_range ? pool.sec_d[k] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+      const size_t k = pool.sec_at(slot, p);
+      const float4 d = in_range ? pool.sec[k + 1] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
       const bool valid = in_range && d.w != 0.0f;
       if (__ballot(valid) == 0ull) continue;
-      const float4 o = valid ? pool.sec_o[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      const float4 o = valid ? pool.sec[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       HitRec h;
       if (COUNT && valid) nr++;
       if (slot == SEC_LIGHT && has_lights) {
@@ -858,7 +858,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_coop(SceneDev sc, Fr
         const uint32_t nn0 = nn;
         const bool occluded = traverse_bvh8_coop<true, COUNT, true, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, lds_stack + threadIdx.x, kBlock, &sc);
         if (COUNT && valid) { const uint32_t kk = nn - nn0; int b = 0; while (b < 7 && kk > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
-        if (valid && !occluded) L += mk3(pool.sec_c[k]);
+        if (valid && !occluded) L += mk3(pool.sec[k + 2]);
       }
     }
     if (in_range) pool.rad[p] = mk4(L, 0.0f);
@@ -893,10 +893,10 @@ struct SecondaryStream {
     for (uint32_t s = from; s <= SEC_LIGHT; ++s) {
       if (s == SEC_DIR && !fr.has_dir) continue;
       if (s == SEC_AREA && !LIGHTS) continue;
-      const size_t k = (size_t)s * pool.capacity + p;
-      const float4 d4 = pool.sec_d[k];
+      const size_t k = pool.sec_at(s, p);
+      const float4 d4 = pool.sec[k + 1];
       if (d4.w == 0.0f) continue;
-      const float4 o4 = pool.sec_o[k];
+      const float4 o4 = pool.sec[k];
       o = mk3(o4); d = mk3(d4); tmax = o4.w;
       any = !(s == SEC_LIGHT && LIGHTS);
       slot = s;
@@ -925,14 +925,14 @@ struct SecondaryStream {
   }
   FH_D void commit(bool hit, const HitRec& h, uint32_t nodes)
   {
-    const size_t k = (size_t)slot * pool.capacity + p;
+    const size_t k = pool.sec_at(slot, p);
     if (slot == SEC_LIGHT && LIGHTS) {
-      const float4 o = pool.sec_o[k], d = pool.sec_d[k];
+      const float4 o = pool.sec[k], d = pool.sec[k + 1];
       const float4 la = pool.lp_a[p], lb = pool.lp_b[p];
       L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, mk3(o), mk3(d), hit, h);
     } else {
       if (COUNT) hp.add(nodes);
-      if (!hit) L += mk3(pool.sec_c[k]);
+      if (!hit) L += mk3(pool.sec[k + 2]);
     }
   }
   FH_D bool drained() const { return feed.drained(); }
@@ -1241,11 +1241,14 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
   auto all = [&]() -> hipError_t {
     hipError_t e;
 #define FH_POOL(ptr, count) if ((e = alloc(ptr, count)) != hipSuccess) return e
-    FH_POOL(P.ray_o, n); FH_POOL(P.ray_d, n); FH_POOL(P.thr, n); FH_POOL(P.rad, n); FH_POOL(P.hit, n);
-    FH_POOL(P.pixel, n); FH_POOL(P.nspp, n); FH_POOL(P.flags, n);
-    FH_POOL(P.aov_position, n); FH_POOL(P.aov_normal, n); FH_POOL(P.aov_albedo, n); FH_POOL(P.aov_texdepth, n);
-    FH_POOL(P.sec_o, n * SEC_COUNT); FH_POOL(P.sec_d, n * SEC_COUNT); FH_POOL(P.sec_c, n * SEC_COUNT);
-    FH_POOL(P.lp_a, n); FH_POOL(P.lp_b, n);
+    float4 *state = nullptr, *aov = nullptr, *lp = nullptr;
+    uint32_t* ident = nullptr;
+    FH_POOL(state, n * 4); FH_POOL(P.rad, n); FH_POOL(ident, n * 2); FH_POOL(P.flags, n);
+    FH_POOL(aov, n * 4); FH_POOL(P.sec, n * SEC_COUNT * 3); FH_POOL(lp, n * 2);
+    P.ray_o.base = state; P.ray_d.base = state + 1; P.thr.base = state + 2; P.hit.base = state + 3;
+    P.pixel.base = ident; P.nspp.base = ident + 1;
+    P.aov_position.base = aov; P.aov_normal.base = aov + 1; P.aov_albedo.base = aov + 2; P.aov_texdepth.base = aov + 3;
+    P.lp_a.base = lp; P.lp_b.base = lp + 1;
     FH_POOL(P.q_rad[0], n); FH_POOL(P.q_rad[1], n); FH_POOL(P.q_cls, n * kNumQueues); FH_POOL(P.q_sec, n);
     FH_POOL(P.counters, (size_t)kCounterStride * 66);  // up to 65 bounces per pass
     FH_POOL(P.key_sec, n); FH_POOL(P.key_rad, n); FH_POOL(P.q_tmp, n); FH_POOL(P.q_sec_sorted, n);
