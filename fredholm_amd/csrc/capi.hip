@@ -387,7 +387,8 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_STREAM_GRID", 8, 8192, t.stream_grid);
     t.stream_grid &= ~7u;
     env_uint("FH_STREAM_REFILL", 1, 64, t.stream_refill);
-    env_uint("FH_STREAM_CHUNK", 16, 65536, t.stream_chunk);
+    env_uint("FH_STREAM_CHUNK", 16, 65535, t.stream_chunk);
+    t.stream_chunk_fixed = getenv("FH_STREAM_CHUNK") != nullptr;
     env_uint("FH_TAIL_DEPTH", 0, 64, t.tail_depth);
     env_uint("FH_TAIL_PATHS", 64, 1 << 30, t.tail_paths);
     env_off("FH_SORT", t.sort_queues);

@@ -125,7 +125,8 @@ struct fh_ctx {
     uint32_t stream_wgs_per_cu = 0; // FH_STREAM_WGS: workgroups per CU of the streaming kernels (0 = the kernels' LDS budget decides)
     uint32_t stream_grid = 0;       // FH_STREAM_GRID: blocks (0 = n_cus * workgroups per CU)
     uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill
-    uint32_t stream_chunk = 64;     // FH_STREAM_CHUNK: queue entries a wave takes per global atomic
+    uint32_t stream_chunk = 64;     // FH_STREAM_CHUNK: queue entries a wave takes per global atomic (setting it also switches the adaptive maximum off)
+    bool stream_chunk_fixed = false;
     uint32_t tail_depth = 0;        // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail
     uint32_t tail_paths = 65536;    // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order

@@ -228,6 +228,20 @@ struct HistPack {
   }
 };
 
+// Queue entries a wave takes per global atomic.  `chunk` packs the range the launcher allows: low 16 bits the default, high 16 bits the maximum.  The cursor
+// is ONE address and serves ~55 M returning atomics/s: at 64 rays per atomic that caps a launch at ~3.5 G rays/s, which rays through a tiny BVH exceed
+// (Cornell box: 4.2 -> 13 G closest-hit rays/s with 256).  Large chunks cost elsewhere -- a queue shorter than waves x chunk leaves waves without work, and on a
+// big BVH consecutive chunks traced by different waves at the same time share the caches -- so the launcher raises the maximum only for small trees and the
+// kernel stays below a quarter of a wave's even share of the queue.
+FH_D uint32_t stream_chunk_for(uint32_t count, uint32_t chunk)
+{
+  const uint32_t lo = chunk & 0xffffu, hi = chunk >> 16;
+  if (hi <= lo) return lo;
+  const uint32_t share = count / (gridDim.x * (kBlock / 64u) * 4u);
+  const uint32_t c = share & ~63u;
+  return c < lo ? lo : (c > hi ? hi : c);
+}
+
 template <bool COUNT>
 struct ClosestStream {
   const PoolDev& pool;
@@ -265,7 +279,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, Po
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_RAD];
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
-  ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, chunk), tc.hist);
+  ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, stream_chunk_for(count, chunk)), tc.hist);
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // the traversal stack of every lane: [entry][thread], as many entries as the BVH has levels
   traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
   if (COUNT) {
@@ -948,7 +962,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, 
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
-  SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, chunk), tc.hist);
+  SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)), tc.hist);
   traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
   pol.finish();
   if (COUNT) {
@@ -1384,7 +1398,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   wgs_per_cu = wgs_per_cu > 6u ? 6u : (wgs_per_cu < 1u ? 1u : wgs_per_cu);
   if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < wgs_per_cu) wgs_per_cu = tun.stream_wgs_per_cu;
   const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_per_cu;
-  const uint32_t stream_refill = tun.stream_refill, stream_chunk = tun.stream_chunk;
+  // (rays through a small tree are cheap enough to run into the atomic rate of the work cursor: allow larger chunks there, stream_chunk_for)
+  const uint32_t chunk_max = tun.stream_chunk_fixed ? tun.stream_chunk : (ctx->bvh8_n_nodes < 512u ? 256u : (ctx->bvh8_n_nodes < 4096u ? 128u : tun.stream_chunk));
+  const uint32_t stream_refill = tun.stream_refill, stream_chunk = (tun.stream_chunk & 0xffffu) | ((chunk_max > tun.stream_chunk ? chunk_max : 0u) << 16);
   const uint32_t env_tail_depth = tun.tail_depth;
   const bool sort_queues = tun.sort_queues;
 
