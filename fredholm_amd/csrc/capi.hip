@@ -383,6 +383,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_COOP_T", 1, 64, t.coop_flush);
     env_off("FH_COOP", t.coop);
     env_off("FH_STREAM", t.stream);
+    t.stream_forced = t.stream && getenv("FH_STREAM") != nullptr;
     env_uint("FH_STREAM_WGS", 1, 8, t.stream_wgs_per_cu);
     env_uint("FH_STREAM_GRID", 8, 8192, t.stream_grid);
     t.stream_grid &= ~7u;

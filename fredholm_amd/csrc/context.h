@@ -121,7 +121,8 @@ struct fh_ctx {
     uint32_t n_cus = 256;
     uint32_t coop_flush = 32;       // FH_COOP_T: queued candidate triangles that trigger a cooperative test round
     bool coop = true;               // FH_COOP=0: per-lane triangle loop
-    bool stream = true;             // FH_STREAM=0: one fixed batch per wave
+    bool stream = true;             // FH_STREAM=0: one fixed batch per wave; FH_STREAM=1: streaming whatever the size of the tree
+    bool stream_forced = false;
     uint32_t stream_wgs_per_cu = 0; // FH_STREAM_WGS: workgroups per CU of the streaming kernels (0 = the kernels' LDS budget decides)
     uint32_t stream_grid = 0;       // FH_STREAM_GRID: blocks (0 = n_cus * workgroups per CU)
     uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill

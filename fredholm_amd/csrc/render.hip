@@ -1385,7 +1385,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const fh_ctx::Tunables& tun = ctx->tun;
   const uint32_t coop_flush = tun.coop_flush;  // wave-cooperative triangle tests (default for the wide BVH): queued candidates that trigger a round
   const bool coop = sc.use_bvh8 != 0 && sc.bvh8.n_tris < kCoopMaxTris && tun.coop;
-  const bool stream = coop && tun.stream;      // streaming form; FH_STREAM=0 falls back to one fixed batch per wave
+  // streaming form (FH_STREAM=0: one fixed batch per wave).  Through a small tree every ray takes the same few steps: nothing to rebalance, and the fixed
+  // batches run without the refill machinery (1000-triangle soup: closest 7.4 -> 4.6 ms, secondary 2.6 -> 1.0 ms per 256 spp; even at ~2 K nodes; behind at 20 K)
+  const bool stream = coop && tun.stream && (tun.stream_forced || ctx->bvh8_n_nodes >= 4096u);
   // the traversal stack of every lane lives in LDS, one entry per level of the BVH (bvh_build.hip records the depth): no overflow path
   const uint32_t stack_bytes = lds_stack_bytes(ctx->bvh8_depth < 2u ? 2u : ctx->bvh8_depth);
   if (sc.use_bvh8 && stack_bytes + kCoopLdsBytesPerBlock > 160u * 1024u) return fail(ctx, FH_E_UNSUPPORTED, "fh_render: BVH too deep for the LDS traversal stack");

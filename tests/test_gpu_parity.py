@@ -25,6 +25,19 @@ pytestmark = pytest.mark.gpu
 L_COAT, L_METAL, L_SPEC, L_TRANS, L_SHEEN, L_DT, L_DIFF, L_ALL = 1, 2, 4, 8, 16, 32, 64, 127
 
 
+@pytest.fixture(autouse=True, params=["auto", "stream"])
+def traversal_kernels(request, monkeypatch):
+    """Every test of this file runs twice: with the library's own choice of traversal kernels (fixed 64-ray batches for trees under 4096 nodes, which is
+    what these small scenes build) and with the streaming kernels forced (FH_STREAM=1, read when a context is created) -- the kernels every big scene uses."""
+    if request.param == "stream":
+        if "big_scene" in request.fixturenames:
+            pytest.skip("the full-size scene streams by itself")
+        monkeypatch.setenv("FH_STREAM", "1")
+    else:
+        monkeypatch.delenv("FH_STREAM", raising=False)
+    yield
+
+
 def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
