@@ -753,6 +753,37 @@ def test_textured_scene_matches_checker(oracle):
     r.close()
 
 
+def test_wild_texture_coordinates_on_opaque_textures_still_take_the_any_hit_test(oracle):
+    """Faces whose textures cannot cut (every texel opaque) skip the any-hit test -- unless a texture coordinate is NaN, infinite or about to overflow: the
+    texture unit fetches 0 there and the reference's any-hit program discards the hit (pt.cu:545-678).  Same hits and same images as the checker."""
+    sc = scenes.textured_cornell_box()
+    tc = np.array(sc["texcoords"], dtype=np.float32, copy=True)
+    rng = np.random.default_rng(9)
+    wild = rng.choice(tc.shape[0], size=max(6, tc.shape[0] // 6), replace=False)
+    tc[wild[0::3], 0] = np.nan
+    tc[wild[1::3], 1] = np.inf
+    tc[wild[2::3], 0] = -3.0e38
+    sc = dict(sc, texcoords=tc)
+    r = F.Renderer(0)
+    r.load_scene(sc)
+    r.build_ias()
+    S = oracle.Scene(sc)
+    rays = _rays(np.random.default_rng(6), 30000, -0.9, 0.9)
+    rays[:, 1] += 1.0
+    tuv_g, prim_g = r.trace_rays(rays)
+    tuv_o, prim_o = S.trace(rays)
+    assert np.array_equal(prim_g, prim_o) and np.array_equal(_bits(tuv_g), _bits(tuv_o))
+    occ = r.trace_rays(rays, any_hit=True)[1] != 0xFFFFFFFF
+    assert np.array_equal(occ, prim_o != 0xFFFFFFFF)
+    r.close()
+    clean = oracle.Scene(scenes.textured_cornell_box()).trace(rays)[1]
+    assert (clean != prim_o).mean() > 0.01  # the wild coordinates do open holes: the test is about something
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    gpu, ref = _render_pair(oracle, sc, cam, 64, 48, launches=2, spp_per_launch=1, depth=4)
+    for name in F.RenderLayer.NAMES:
+        _assert_image_parity(gpu[name], ref[name])
+
+
 def test_image_based_lighting_matches_checker(oracle):
     sc = scenes.triangle_soup(4000, 0.15)
     cam = F.Camera(**scenes.SOUP_CAMERA)
