@@ -252,6 +252,25 @@ __global__ void __launch_bounds__(256) k_trace_batch_coop(SceneDev sc, uint32_t 
   prim[i] = ok ? h.prim : 0xffffffffu;
 }
 
+// fhe_sqrt (the short device sequence, include/fh_elementary.h) against the compiler's IEEE sqrtf over EVERY float bit pattern; optionally the results
+// of `n_sample` given inputs are returned for a comparison with the host's sqrtf
+__global__ void k_sqrt_all(unsigned long long* bad)
+{
+  const uint32_t stride = gridDim.x * blockDim.x;  // 2^22: 1024 iterations cover the 2^32 patterns
+  unsigned long long n = 0;
+  uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t it = 0; it < 1024u; ++it, u += stride) {
+    const float x = __uint_as_float(u), a = fhe_sqrt(x), b = sqrtf(x);
+    if (!(__float_as_uint(a) == __float_as_uint(b) || (a != a && b != b))) n++;
+  }
+  if (n) atomicAdd(bad, n);
+}
+__global__ void k_sqrt_some(uint32_t n, const float* in, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fhe_sqrt(in[i]);
+}
+
 uint32_t blocks(uint32_t n) { return (n + 255) / 256; }
 
 }  // namespace
@@ -401,6 +420,24 @@ int fh_kat_offset_origin(fh_ctx* ctx, uint32_t n, const float* p3, const float* 
   hipLaunchKernelGGL(k_offset, dim3(blocks(n)), dim3(256), 0, ctx->stream, n, a.p, b.p, o.p);
   FH_HIP(hipStreamSynchronize(ctx->stream));
   FH_HIP(o.down(out3));
+  return FH_OK;
+}
+int fh_kat_sqrt(fh_ctx* ctx, unsigned long long* mismatches_over_all_inputs, uint32_t n_sample, const float* sample_in, float* sample_out)
+{
+  KCTX(ctx);
+  if (!mismatches_over_all_inputs || (n_sample && (!sample_in || !sample_out))) return fail(ctx, FH_E_INVALID, "fh_kat_sqrt: null argument");
+  Tmp<unsigned long long> bad;
+  const unsigned long long zero = 0;
+  FH_HIP(bad.up(&zero, 1));
+  hipLaunchKernelGGL(k_sqrt_all, dim3(1u << 14), dim3(256), 0, ctx->stream, bad.p);
+  Tmp<float> a, o;
+  if (n_sample) {
+    FH_HIP(a.up(sample_in, n_sample)); FH_HIP(o.up(nullptr, n_sample));
+    hipLaunchKernelGGL(k_sqrt_some, dim3(blocks(n_sample)), dim3(256), 0, ctx->stream, n_sample, a.p, o.p);
+  }
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  FH_HIP(bad.down(mismatches_over_all_inputs));
+  if (n_sample) FH_HIP(o.down(sample_out));
   return FH_OK;
 }
 int fh_kat_math(fh_ctx* ctx, int kind, uint32_t n, const float* in, float* out)

@@ -241,6 +241,9 @@ enum { FH_MATH_ALBEDO_REFLECTION = 0, FH_MATH_ALBEDO_SHEEN, FH_MATH_ONB, FH_MATH
 int fh_kat_math(fh_ctx* ctx, int kind, uint32_t n, const float* in, float* out);
 /* tex2D<float4>() of the software texture unit (include/fh_texture_unit.h: cwl/texture.h:35-47 semantics) evaluated on the device for n (u, v)
    pairs on an RGBA8 texture (rgba8, optionally sRGB) or a float4 texture (rgba32f); exactly one of the two texel pointers is non-NULL */
+/* the device's short correctly rounded square root (include/fh_elementary.h: fhe_sqrt) against the compiler's IEEE sqrtf over all 2^32 float bit patterns
+ * (number of disagreeing inputs; 0 expected), plus its results on `n_sample` given inputs for a comparison with the host's sqrtf */
+int fh_kat_sqrt(fh_ctx* ctx, unsigned long long* mismatches_over_all_inputs, uint32_t n_sample, const float* sample_in, float* sample_out);
 int fh_kat_tex2d(fh_ctx* ctx, const uint8_t* rgba8, const float* rgba32f, uint32_t width, uint32_t height, int srgb, uint32_t n, const float* uv2, float* out4);
 /* measured HBM bandwidth of this GPU (GB/s): a streaming float4 read and a float4 copy (read + written bytes) over `bytes`-sized buffers,
    `iters` launches each.  The "measured HBM roofline" SURVEY.md 8(d) asks for; use buffers well beyond the 256 MiB Infinity Cache. */

@@ -124,6 +124,22 @@ def test_elementary_functions_identical_on_device(renderer, oracle):
         assert _same(out, oracle.elementary(name, x, y)), name
 
 
+def test_short_square_root_equals_ieee_sqrt_for_every_input(renderer):
+    """fhe_sqrt on the device (x * rsq(x) + one FMA-Newton step, 9 instructions) against the compiler's correctly rounded sqrtf over all 2^32 bit
+    patterns, and against the host's sqrtf (numpy) on a sample that includes the range limits of the short path, denormals, zeros, infinities and NaN"""
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 2**32, size=1 << 20, dtype=np.uint32).view(np.float32).copy()
+    edge = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -1.0, 1.0, 4.0, 2.0, 1e-45, 1.1754942e-38, 1.17549435e-38, 7.888609e-31, 7.8886091e-31, 7.88860905e-31,
+                     3.4028235e38, 1.0000001, 0.99999994, 0.25, 1e-37, 1e-30, 1e30], dtype=np.float32)
+    x[:edge.size] = edge
+    got = np.zeros_like(x)
+    bad = C.c_ulonglong(123)
+    _kat(renderer, "fh_kat_sqrt", C.byref(bad), x.size, N.ptr(x), N.ptr(got))
+    assert bad.value == 0
+    with np.errstate(invalid="ignore"):
+        assert _same(got, np.sqrt(x))
+
+
 def test_warps_identical(renderer, oracle):
     rng = np.random.default_rng(5)
     n = 20000
