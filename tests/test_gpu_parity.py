@@ -796,8 +796,9 @@ def test_wild_texture_coordinates_on_opaque_textures_still_take_the_any_hit_test
     assert (clean != prim_o).mean() > 0.01  # the wild coordinates do open holes: the test is about something
     cam = F.Camera(**scenes.CORNELL_CAMERA)
     gpu, ref = _render_pair(oracle, sc, cam, 64, 48, launches=2, spp_per_launch=1, depth=4)
-    for name in F.RenderLayer.NAMES:
-        _assert_image_parity(gpu[name], ref[name])
+    with np.errstate(all="ignore"):  # texcoord AOVs carry the wild values
+        for name in F.RenderLayer.NAMES:
+            _assert_image_parity(gpu[name], ref[name])
 
 
 def test_image_based_lighting_matches_checker(oracle):
