@@ -379,8 +379,66 @@ __device__ __forceinline__ uint32_t quant_exponent(float extent)
   return e;
 }
 
+// ---- which descendants of a binary node become the children of its wide node: the cut of least cost (Ylitie, Karras, Laine 2017, section 3).
+// With one triangle per leaf child the triangles' share of the SAH cost is the same for every cut, so what is minimised is the summed surface area of the
+// wide nodes, i.e. the expected number of 8-wide node tests per ray.  C(n, i) = least cost of the subtree of n when it may occupy at most i child slots
+// of the wide node above it:
+//   C(n, 1) = area(n) + D(n, 8)                n becomes a wide node itself and deals its eight slots to its two children
+//   D(n, j) = min over k of C(left, k) + C(right, j - k)
+//   C(n, i) = min(D(n, i), C(n, i - 1))        i = 2..7; a triangle costs nothing and takes one slot
+// Tables are filled bottom up (arrival counters, like the box refit); per node 7 costs and the decisions: the k of D(n, j) for j = 2..8 (3 bits each in x)
+// and the number of slots C(n, i) really uses for i = 1..7 (3 bits each in y).
+__global__ void k_tree_parents(int n_inner, const int2* children, int* node_parent, int* leaf_parent)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_inner) return;
+  const int2 ch = children[i];
+  if (ch.x >= 0) node_parent[ch.x] = i; else leaf_parent[~ch.x] = i;
+  if (ch.y >= 0) node_parent[ch.y] = i; else leaf_parent[~ch.y] = i;
+}
+
+__device__ __forceinline__ float cut_cost(int ref, int k, const float* cost) { return ref < 0 ? 0.0f : cost[7 * (size_t)ref + (k - 1)]; }
+
+__global__ void k_cut_tables(int n_leaves, const int2* children, const int* node_parent, const int* leaf_parent, const float4* node_lo, const float4* node_hi, unsigned int* arrive,
+                             float* cost, uint2* decision)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_leaves) return;
+  int cur = leaf_parent[i];
+  while (cur >= 0) {
+    __threadfence();  // publish this subtree's table before signalling
+    const unsigned int prev = atomicAdd(&arrive[cur], 1u);
+    if (prev == 0u) return;
+    __threadfence();  // see the sibling's table
+    const int2 ch = children[cur];
+    float D[9];
+    uint32_t split = 0, use = 1u;
+    for (int j = 2; j <= 8; ++j) {
+      float best = 3e38f;
+      int bk = 1;
+      for (int k = (j - 7 > 1 ? j - 7 : 1); k <= (j - 1 < 7 ? j - 1 : 7); ++k) {
+        const float c = cut_cost(ch.x, k, cost) + cut_cost(ch.y, j - k, cost);
+        if (c < best) { best = c; bk = k; }
+      }
+      D[j] = best;
+      split |= (uint32_t)bk << (3 * (j - 2));
+    }
+    float C = box_area(node_lo[cur], node_hi[cur]) + D[8];
+    uint32_t u = 1u;
+    cost[7 * (size_t)cur] = C;
+    for (int k = 2; k <= 7; ++k) {
+      if (D[k] < C) { C = D[k]; u = (uint32_t)k; }
+      cost[7 * (size_t)cur + (k - 1)] = C;
+      use |= u << (3 * (k - 1));
+    }
+    decision[cur] = make_uint2(split, use);
+    cur = node_parent[cur];
+  }
+}
+
 __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* children, const int2* ranges, const float4* node_lo, const float4* node_hi, const float4* leaf_lo,
-                            const float4* leaf_hi, float pad, uint32_t leaf_max, uint32_t absorb, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_map, Work8* next_items, uint32_t* next_count)
+                            const float4* leaf_hi, float pad, uint32_t leaf_max, uint32_t absorb, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_map, Work8* next_items, uint32_t* next_count,
+                            const uint2* decision)
 {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_items) return;
@@ -398,8 +456,29 @@ __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* ch
   // with at most 8 leaves is opened only when ALL of its leaves fit into the free slots, and is then opened completely before
   // anything else, so it ends up either as direct leaf children of this node or as ONE full inner child below it, never as a few
   // 2-3 leaf fragments that each cost a node fetch (the plain rule left 4.5 of 8 slots used on average).
+  if (decision) {  // the cut chosen by k_cut_tables: deal the eight slots down the binary tree
+    int st_ref[8], st_slots[8], sp = 0;
+    const int2 ch0 = children[it.bnode];
+    const int k0 = (int)((decision[it.bnode].x >> 18) & 7u);
+    st_ref[sp] = ch0.y; st_slots[sp++] = 8 - k0;
+    st_ref[sp] = ch0.x; st_slots[sp++] = k0;
+    n = 0;
+    while (sp > 0) {
+      --sp;
+      const int m = st_ref[sp], j = st_slots[sp];
+      if (m < 0) { ref[n++] = m; continue; }
+      const uint2 d = decision[m];
+      const int jj = (int)((d.y >> (3 * (j - 1))) & 7u);  // slots the subtree really uses of the j it was given
+      if (jj <= 1) { ref[n++] = m; continue; }            // one slot: it becomes a wide node of its own
+      const int k = (int)((d.x >> (3 * (jj - 2))) & 7u);
+      const int2 ch = children[m];
+      st_ref[sp] = ch.y; st_slots[sp++] = jj - k;
+      st_ref[sp] = ch.x; st_slots[sp++] = k;
+    }
+    for (int i = 0; i < n; ++i) child_box(ref[i], node_lo, node_hi, leaf_lo, leaf_hi, lo[i], hi[i]);
+  }
   uint32_t absorbing = 0;  // slots that belong to a subtree being absorbed
-  while (n < 8) {
+  while (!decision && n < 8) {
     int best = -1;
     float best_area = -1.0f;
     if (absorb) {
@@ -980,6 +1059,22 @@ int bvh_build_device(fh_ctx* ctx)
     if (const char* e = getenv("FH_ABSORB")) absorb8 = e[0] != '0' ? 1u : 0u;
     if (const char* e = getenv("FH_LEAF8")) { const int v = atoi(e); if (v >= 1 && v <= (int)kLeafMax8) leaf_max8 = (uint32_t)v; }
     if (ploc) leaf_max8 = 1;  // PLOC subtrees are not contiguous leaf ranges: one triangle per leaf child
+    // the cut of least summed wide-node area (k_cut_tables); FH_COLLAPSE=greedy: the largest-child-first rule above
+    bool optimal_cut = leaf_max8 == 1;
+    if (const char* e = getenv("FH_COLLAPSE")) optimal_cut = optimal_cut && std::strcmp(e, "greedy") != 0;
+    DevBuf<float> cut_cost_tab;
+    DevBuf<uint2> cut_decision;
+    if (optimal_cut) {
+      DevBuf<int> c_node_parent, c_leaf_parent;
+      FH_HIP(c_node_parent.alloc(n_inner)); FH_HIP(c_leaf_parent.alloc(nr)); FH_HIP(cut_cost_tab.alloc(7ull * n_inner)); FH_HIP(cut_decision.alloc(n_inner));
+      FH_HIP(hipMemsetAsync(c_node_parent.p, 0xff, 4ull * n_inner, st));  // the root keeps -1
+      FH_HIP(hipMemsetAsync(arrive.p, 0, 4ull * n_inner, st));
+      hipLaunchKernelGGL(k_tree_parents, dim3(iblocks), dim3(256), 0, st, (int)n_inner, c_children, c_node_parent.p, c_leaf_parent.p);
+      hipLaunchKernelGGL(k_cut_tables, dim3(rblocks), dim3(256), 0, st, (int)nr, c_children, c_node_parent.p, c_leaf_parent.p, c_node_lo, c_node_hi, arrive.p, cut_cost_tab.p,
+                         cut_decision.p);
+      FH_HIP(hipGetLastError());
+      FH_HIP(hipStreamSynchronize(st));  // (the parent arrays go out of scope here)
+    }
     const Work8 root{root_node, 0u};
     const uint32_t init_counters[3] = {1u, 0u, 0u};
     FH_HIP(hipMemcpyAsync(work_a.p, &root, sizeof root, hipMemcpyHostToDevice, st));
@@ -994,7 +1089,7 @@ int bvh_build_device(fh_ctx* ctx)
       level_start.push_back(level_start.back() + level_count);
       FH_HIP(hipMemsetAsync(counters.p + 2, 0, 4, st));
       hipLaunchKernelGGL(k_collapse8, dim3((level_count + 63) / 64), dim3(64), 0, st, cur, level_count, c_children, c_ranges, c_node_lo, c_node_hi, leaf_lo.p, leaf_hi.p, pad,
-                         leaf_max8, absorb8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2);
+                         leaf_max8, absorb8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2, optimal_cut ? cut_decision.p : (const uint2*)nullptr);
       FH_HIP(hipMemcpyAsync(&level_count, counters.p + 2, 4, hipMemcpyDeviceToHost, st));
       FH_HIP(hipStreamSynchronize(st));
       Work8* t = cur; cur = nxt; nxt = t;
@@ -1004,6 +1099,7 @@ int bvh_build_device(fh_ctx* ctx)
     FH_HIP(hipStreamSynchronize(st));
     if (final_counters[1] != nr) return fail(ctx, FH_E_INVALID, "BVH8 collapse lost triangles");
     if (levels > (uint32_t)kBvh8Stack) return fail(ctx, FH_E_UNSUPPORTED, "BVH8 deeper than the traversal stack (48 levels)");
+    if (final_counters[0] >= (1u << 24)) return fail(ctx, FH_E_UNSUPPORTED, "BVH8 with 2^24 or more nodes (the traversal stack keeps node indices in 24 bits)");
     ctx->bvh8_depth = levels;
     hipLaunchKernelGGL(k_emit_tris8, dim3(rblocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_map.p, nr, ctx->d_bvh8_tris, ref_face);
     FH_HIP(hipGetLastError());

@@ -74,6 +74,7 @@ struct fh_ctx {
   double bvh8_area_built = 0.0;             // sum of the node areas right after the full build (quality reference for refits)
   uint32_t n_refits = 0;
   uint32_t bvh8_depth = 0;            // levels of the wide tree = most entries a traversal stack can hold
+  uint32_t occupancy_key = 0xffffffffu, occupancy_blocks = 0, occupancy_blocks_secondary = 0;  // resident workgroups per CU of the streaming kernels, as the runtime reports them (render.hip)
   uint32_t lds_configured_bytes = 0;  // dynamic-LDS size the traversal kernels were last configured for (render.hip)
   bool use_bvh8 = false;
   int builder_choice = 0;  // 0 = not decided for this scene, 1 = radix tree (LBVH), 2 = PLOC; decided at the first build after an upload

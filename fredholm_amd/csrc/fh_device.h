@@ -46,6 +46,7 @@ struct Bvh8Dev {
   const float4* tris;   // 3 x float4 per leaf triangle, grouped per node
   uint32_t n_nodes;
   uint32_t n_tris;
+  uint32_t depth;       // levels of the tree (>= 2): entries of the LDS traversal stack
 };
 
 struct SceneDev {

@@ -254,7 +254,7 @@ FH_D bool first_active_lane() { return __lane_id() == (uint32_t)__ffsll((long lo
 
 // Traversal stack of node groups.  A group is pushed only while descending into one of its children, so the stack never holds
 // more entries than the tree has levels; the builder records that number (fh_ctx::bvh8_depth) and refuses trees deeper than kBvh8Stack.
-//   GroupStack<true>   every entry in LDS, column layout [entry][thread] (conflict-free); the launcher sizes the dynamic LDS for the
+//   GroupStack<true>   every entry in LDS, column layout [entry][thread] (conflict-free; constructed from the block's LDS and the tree depth); the launcher sizes the dynamic LDS for the
 //                      tree's depth, so there is no overflow path and no private array: `sp` lives in a register.  (The first build kept
 //                      6 entries in LDS and the rest in a private array; the compiler then kept the whole object, `sp` included, in scratch:
 //                      every push and pop started with a scratch load on the dependent path -- 408 B of scratch, ~1 GB of writes per launch.)
@@ -271,19 +271,22 @@ struct GroupStack<false> {
 };
 template <>
 struct GroupStack<true> {
-  uint2* lds;
-  int stride;
+  // 5 bytes per entry: a word (first-child node index << 8 | pending hit bits) and a byte (the group's inner-child mask), each in its own
+  // column array [entry][thread] -- 1.25 KB per tree level and workgroup instead of 2 KB, which is a workgroup more per CU on every tree
+  // deeper than eight levels (node indices stay below 2^24: the builder refuses larger trees)
+  uint32_t* word;
+  uint8_t* mask;
   int sp = 0;
-  FH_D GroupStack(uint2* lds_column, int lds_stride) : lds(lds_column), stride(lds_stride) {}
-  FH_D void push(uint2 g) { lds[sp * stride] = g; ++sp; }
-  FH_D uint2 pop() { --sp; return lds[sp * stride]; }
+  FH_D GroupStack(uint2* block_lds, int depth) : word((uint32_t*)block_lds + threadIdx.x), mask((uint8_t*)((uint32_t*)block_lds + depth * 256) + threadIdx.x) {}
+  FH_D void push(uint2 g) { word[sp * 256] = (g.x << 8) | (g.y >> 24); mask[sp * 256] = (uint8_t)g.y; ++sp; }
+  FH_D uint2 pop() { --sp; const uint32_t w = word[sp * 256]; return make_uint2(w >> 8, (w << 24) | mask[sp * 256]); }
 };
 // dynamic LDS of one 256-thread workgroup whose lanes keep `depth` stack entries there
-FH_HD uint32_t lds_stack_bytes(uint32_t depth) { return depth * 256u * (uint32_t)sizeof(uint2); }
+FH_HD uint32_t lds_stack_bytes(uint32_t depth) { return (depth * 256u * 5u + 15u) & ~15u; }
 
 template <bool ANY_HIT, bool COUNT, bool LDS = false, bool ALPHA = false>
 FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr, uint2* lds_column = nullptr,
-                        int lds_stride = 0, const SceneDev* sc = nullptr)
+                        int lds_stride = 0, const SceneDev* sc = nullptr)  // (LDS: lds_column = the block's stack area, lds_stride = tree depth)
 {
   best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu;
   if (bvh.n_nodes == 0) return false;

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, Po
   WaveSteps ws;
   ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, stream_chunk_for(count, chunk)), tc.hist);
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // the traversal stack of every lane: [entry][thread], as many entries as the BVH has levels
-  traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
+  traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc);
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
@@ -811,13 +811,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
       HitRec h;
       if (COUNT) nr++;
       if (slot == SEC_LIGHT && has_lights) {
-        const bool hit = WIDE ? traverse_bvh8<false, COUNT, true, ALPHA>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack + threadIdx.x, kBlock, &sc)
+        const bool hit = WIDE ? traverse_bvh8<false, COUNT, true, ALPHA>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack, (int)sc.bvh8.depth, &sc)
                               : traverse_bvh2<false, COUNT, ALPHA>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt, &sc);
         const float4 la = pool.lp_a[p], lb = pool.lp_b[p];
         L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, mk3(o), mk3(d), hit, h);
       } else {
         const uint32_t nn0 = nn;
-        const bool occluded = WIDE ? traverse_bvh8<true, COUNT, true, ALPHA>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack + threadIdx.x, kBlock, &sc)
+        const bool occluded = WIDE ? traverse_bvh8<true, COUNT, true, ALPHA>(sc.bvh8, mk3(o), mk3(d), o.w, h, nn, nt, &ws, lds_stack, (int)sc.bvh8.depth, &sc)
                                    : traverse_bvh2<true, COUNT, ALPHA>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt, &sc);
         if (COUNT) { const uint32_t kk = nn - nn0; int b = 0; while (b < 7 && kk > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
         if (!occluded) L += mk3(pool.sec[k + 2]);
@@ -863,14 +863,14 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_coop(SceneDev sc, Fr
       HitRec h;
       if (COUNT && valid) nr++;
       if (slot == SEC_LIGHT && has_lights) {
-        const bool hit = traverse_bvh8_coop<false, COUNT, true, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, lds_stack + threadIdx.x, kBlock, &sc);
+        const bool hit = traverse_bvh8_coop<false, COUNT, true, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, lds_stack, (int)sc.bvh8.depth, &sc);
         if (valid) {
           const float4 la = pool.lp_a[p], lb = pool.lp_b[p];
           L += resolve_light_ray(sc, fr, mk3(la), la.w, mk3(lb), lb.w, mk3(o), mk3(d), hit, h);
         }
       } else {
         const uint32_t nn0 = nn;
-        const bool occluded = traverse_bvh8_coop<true, COUNT, true, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, lds_stack + threadIdx.x, kBlock, &sc);
+        const bool occluded = traverse_bvh8_coop<true, COUNT, true, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, lds_stack, (int)sc.bvh8.depth, &sc);
         if (COUNT && valid) { const uint32_t kk = nn - nn0; int b = 0; while (b < 7 && kk > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
         if (valid && !occluded) L += mk3(pool.sec[k + 2]);
       }
@@ -954,7 +954,7 @@ struct SecondaryStream {
 };
 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk)
+__global__ void __launch_bounds__(kBlock, (COUNT || LIGHTS || ALPHA) ? 1 : 6) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
@@ -963,7 +963,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_stream(SceneDev sc, 
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)), tc.hist);
-  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack + threadIdx.x, kBlock, &sc);
+  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc);
   pol.finish();
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
@@ -1217,6 +1217,7 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.bvh8.tris = ctx->d_bvh8_tris;
   s.bvh8.n_nodes = ctx->bvh8_n_nodes;
   s.bvh8.n_tris = ctx->bvh8_n_tris;
+  s.bvh8.depth = ctx->bvh8_depth < 2u ? 2u : ctx->bvh8_depth;
   s.use_bvh8 = ctx->use_bvh8 ? 1u : 0u;
   return s;
 }
@@ -1398,8 +1399,29 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   // all workgroups of a streaming launch are resident: as many per CU as its 160 KB of LDS hold (at most 6: the kernels' register budget)
   uint32_t wgs_per_cu = (160u * 1024u) / (stack_bytes + kCoopLdsBytesPerBlock);
   wgs_per_cu = wgs_per_cu > 6u ? 6u : (wgs_per_cu < 1u ? 1u : wgs_per_cu);
-  if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < wgs_per_cu) wgs_per_cu = tun.stream_wgs_per_cu;
-  const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_per_cu;
+  if (stream) {  // what the runtime says really fits (LDS granularity, registers of the variant in use): a grid above it would leave blocks queued behind the resident ones
+    const uint32_t key = stack_bytes | (count ? 1u : 0u) | (sc.has_alpha ? 2u : 0u) | (sc.n_lights > 0 ? 4u : 0u);
+    if (ctx->occupancy_key != key) {
+      int a = 0, b = 0;
+      with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest_stream<decltype(C)::value, decltype(A)::value>, kBlock, stack_bytes);
+        with_bool(sc.n_lights > 0, [&](auto Li) {
+          (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>, kBlock, stack_bytes);
+        });
+      }); });
+      ctx->occupancy_key = key;
+      ctx->occupancy_blocks = a > 0 ? (uint32_t)a : 0u;
+      ctx->occupancy_blocks_secondary = b > 0 ? (uint32_t)b : 0u;
+      if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[trace] stack %u B + %u B per workgroup: %d / %d resident workgroups per CU (closest / secondary)\n", stack_bytes, kCoopLdsBytesPerBlock, a, b);
+    }
+  }
+  uint32_t wgs_closest = wgs_per_cu, wgs_secondary = wgs_per_cu;
+  if (stream && ctx->occupancy_blocks && ctx->occupancy_blocks < wgs_closest) wgs_closest = ctx->occupancy_blocks;
+  if (stream && ctx->occupancy_blocks_secondary && ctx->occupancy_blocks_secondary < wgs_secondary) wgs_secondary = ctx->occupancy_blocks_secondary;
+  if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < wgs_closest) wgs_closest = tun.stream_wgs_per_cu;
+  if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < wgs_secondary) wgs_secondary = tun.stream_wgs_per_cu;
+  const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_closest;
+  const uint32_t stream_grid_secondary = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_secondary;
   // (rays through a small tree are cheap enough to run into the atomic rate of the work cursor: allow larger chunks there, stream_chunk_for)
   const uint32_t chunk_max = tun.stream_chunk_fixed ? tun.stream_chunk : (ctx->bvh8_n_nodes < 512u ? 256u : (ctx->bvh8_n_nodes < 4096u ? 128u : tun.stream_chunk));
   const uint32_t stream_refill = tun.stream_refill, stream_chunk = (tun.stream_chunk & 0xffffu) | ((chunk_max > tun.stream_chunk ? chunk_max : 0u) << 16);
@@ -1518,7 +1540,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         Span sp(ctx, st, 1);
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), stack_bytes, st, sc,
+            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stack_bytes, st, sc,
                                fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk);
           }); }); });
         } else if (coop) {
