@@ -970,8 +970,9 @@ int bvh_build_device(fh_ctx* ctx)
     // ---- optional: replace the radix tree by a PLOC tree as the input of the collapse (the binary fallback above keeps the radix tree)
     int root_node = 0;
     // FH_BVH_BUILDER = lbvh | ploc | auto (default).  auto: the first build after an upload makes both trees and keeps PLOC when the
-    // sum of its inner-node areas is at least 15 % below the radix tree's (non-uniform scenes: -29 % on tools' `city`, 9 % faster
-    // frames); on a uniform soup the two are within 3 % and the radix tree traverses faster, so it stays.  Later builds of the same
+    // sum of its inner-node areas is at least 7 % below the radix tree's (non-uniform scenes: -29 % on tools' `city`, 9 % faster
+    // frames; -9 % on the Sponza-class glTF, 5 % faster frames); on a uniform soup the two are within 3 % and the radix tree traverses
+    // faster (closest-hit rays need the well separated children of a Morton split for the octant order to work), so it stays.  Later builds of the same
     // scene (animation) reuse the choice.
     int mode = ctx->builder_choice;
     if (const char* e = getenv("FH_BVH_BUILDER")) { if (std::strcmp(e, "ploc") == 0) mode = 2; else if (std::strcmp(e, "lbvh") == 0) mode = 1; }
@@ -1037,7 +1038,7 @@ int bvh_build_device(fh_ctx* ctx)
       FH_HIP(hipMemcpyAsync(h, sums.p, 16, hipMemcpyDeviceToHost, st));
       FH_HIP(hipStreamSynchronize(st));
       if (deciding && !ploc_failed) {
-        ploc = h[1] < 0.85 * h[0];
+        ploc = h[1] < 0.93 * h[0];
         ctx->builder_choice = ploc ? 2 : 1;
       }
       if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[bvh] sum of inner-node areas: radix tree %.4f, PLOC %.4f -> %s\n", h[0], h[1], ploc ? "PLOC" : "radix tree");
