@@ -43,6 +43,9 @@ namespace {
 constexpr int kBlock = 256;
 constexpr uint32_t kLutReflFloats = 16 * 16 * 2, kLutSheenFloats = 16 * 16;  // lut.cu:5-93, :917-955
 constexpr uint32_t kMatLds = 32;  // material records staged in LDS by the shade kernels when the scene has at most this many
+#ifndef FH_SECONDARY_BLOCKS_HEAVY
+#define FH_SECONDARY_BLOCKS_HEAVY 5  // resident workgroups per CU the secondary streaming kernel is compiled for when it carries the emitter / any-hit code
+#endif
 #ifndef FH_SHADE_BLOCKS
 #define FH_SHADE_BLOCKS 2  // resident workgroups per CU the specialised shade kernels are compiled for (register budget = 512 / that per lane): they need 208-230 registers
 #endif                     // since their products go to memory as they are made (PoolSink); the generic seven-lobe kernel keeps one wave per SIMD (391 registers, no spills)
@@ -954,7 +957,7 @@ struct SecondaryStream {
 };
 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
-__global__ void __launch_bounds__(kBlock, (COUNT || LIGHTS || ALPHA) ? 1 : 6) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk)
+__global__ void __launch_bounds__(kBlock, COUNT ? 1 : ((LIGHTS || ALPHA) ? FH_SECONDARY_BLOCKS_HEAVY : 6)) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
