@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, Po
 template <bool COUNT, bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_closest_coop(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush)
 {
+  extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
   const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   const uint32_t* cnt = pool.counters + depth * kCounterStride;
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_coop(SceneDev sc, Pool
     const float4 o = valid ? pool.ray_o[p] : make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = valid ? pool.ray_d[p] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
     HitRec h;
     const uint32_t nn0 = nn;
-    traverse_bvh8_coop<false, COUNT, false, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, nullptr, 0, &sc);
+    traverse_bvh8_coop<false, COUNT, true, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, lds_stack, (int)sc.bvh8.depth, &sc);
     if (COUNT && valid) { const uint32_t k = nn - nn0; int b = 0; while (b < 7 && k > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
     if (valid) pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
   }
@@ -840,7 +841,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
 // secondary rays over the 8-wide BVH with wave-cooperative triangle tests: a lane owns one shaded path and walks its
 // secondary-ray slots in the reference's order; a slot is traversed by the whole wave when any lane has a ray in it
 template <bool COUNT, bool LIGHTS, bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_secondary_coop(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush)
+__global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? 5 : 6)) k_trace_secondary_coop(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
@@ -1300,6 +1301,7 @@ int configure_traversal_lds(fh_ctx* ctx, uint32_t stack_bytes)
             with_bool(l != 0, [&](auto Li) {
               set((const void*)k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
               set((const void*)k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
+              set((const void*)k_trace_closest_coop<decltype(C)::value, decltype(A)::value>);
               set((const void*)k_trace_secondary_static<decltype(C)::value, true, decltype(Li)::value, decltype(A)::value>);
               set((const void*)k_trace_secondary_static<decltype(C)::value, false, decltype(Li)::value, decltype(A)::value>);
             });
@@ -1503,7 +1505,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
           }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_closest_coop<decltype(C)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), 0, st, sc, pd, depth, tc_closest, coop_flush);
+            hipLaunchKernelGGL((k_trace_closest_coop<decltype(C)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), stack_bytes, st, sc, pd, depth, tc_closest, coop_flush);
           }); });
         } else {
           with_bool(count, [&](auto C) { with_bool(sc.use_bvh8 != 0, [&](auto W) { with_bool(sc.has_alpha != 0, [&](auto A) {
