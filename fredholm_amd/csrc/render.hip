@@ -988,6 +988,15 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : ((LIGHTS || ALPHA) ? FH_SE
 // kernels, hence the same bits.
 __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth)
 {
+  extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // traversal stack of every lane ([entry][thread], as in the streaming kernels): a private array lands in scratch
+  // one ray through the scene, per lane (the wide tree with its stack in LDS; tiny scenes: the binary tree)
+  auto trace = [&](auto any_hit, f3 o, f3 d, float tmax, HitRec& h) -> bool {
+    constexpr bool ANY = decltype(any_hit)::value;
+    uint32_t a = 0, b = 0;
+    if (!sc.use_bvh8) return traverse<ANY, false>(sc, o, d, tmax, h, a, b);
+    if (sc.has_alpha) return traverse_bvh8<ANY, false, true, true>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc);
+    return traverse_bvh8<ANY, false, true, false>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc);
+  };
   __shared__ SobolRows<4> rows;
   __shared__ float s_lut[kLutReflFloats + kLutSheenFloats];  // as in k_shade: small tables every hit reads live in LDS
   __shared__ MaterialDev s_mat[kMatLds];
@@ -1024,8 +1033,7 @@ __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolD
       bs.load_rows(rows, fr.sobol_bytes);
       if (alive) {
         HitRec h;
-        uint32_t a = 0, b = 0;
-        const bool hit = traverse<false, false>(sc, ro, rd, 1e9f, h, a, b);
+        const bool hit = trace(std::false_type{}, ro, rd, 1e9f, h);
         if (!hit) {
           alive = false;  // pt.cu:504-523 with firsthit == false: nothing added
         } else {
@@ -1039,10 +1047,10 @@ __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolD
             if (!o.sec[slot].active) continue;
             HitRec sh;
             if (slot == SEC_LIGHT && has_lights) {
-              const bool lhit = traverse<false, false>(sc, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh, a, b);
+              const bool lhit = trace(std::false_type{}, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh);
               L += resolve_light_ray(sc, fr, o.lp_T, o.lp_cos, o.lp_f, o.lp_pdf, o.sec[slot].o, o.sec[slot].d, lhit, sh);
             } else {
-              const bool occluded = traverse<true, false>(sc, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh, a, b);
+              const bool occluded = trace(std::true_type{}, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh);
               if (!occluded) L += o.sec[slot].c;
             }
           }
@@ -1302,6 +1310,7 @@ int configure_traversal_lds(fh_ctx* ctx, uint32_t stack_bytes)
               set((const void*)k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
               set((const void*)k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
               set((const void*)k_trace_closest_coop<decltype(C)::value, decltype(A)::value>);
+              set((const void*)k_tail);
               set((const void*)k_trace_secondary_static<decltype(C)::value, true, decltype(Li)::value, decltype(A)::value>);
               set((const void*)k_trace_secondary_static<decltype(C)::value, false, decltype(Li)::value, decltype(A)::value>);
             });
@@ -1564,7 +1573,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     }
     if (wave_depth < max_depth) {
       Span sp(ctx, st, 3);
-      hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), 0, st, sc, fr, pd, wave_depth);
+      hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), sc.use_bvh8 ? stack_bytes : 0u, st, sc, fr, pd, wave_depth);
       ctx->stats.n_tail_launches++;
     }
     if (prev != slot && ctx->acc_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[prev], 0));
