@@ -373,7 +373,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     (void)hipEventCreateWithFlags(&ctx->ev_acc[k], hipEventDisableTiming);
   }
   (void)hipEventCreateWithFlags(&ctx->ev_enter, hipEventDisableTiming);
-  if (const char* e = getenv("FH_PIPELINE")) ctx->n_slots = e[0] == '0' ? 1 : (e[0] == '3' ? 3 : 2);
+  if (const char* e = getenv("FH_PIPELINE")) ctx->n_slots = e[0] == '0' ? 1 : (e[0] == '2' ? 2 : 3);
   {
     fh_ctx::Tunables& t = ctx->tun;
     hipDeviceProp_t prop;

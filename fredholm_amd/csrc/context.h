@@ -110,7 +110,7 @@ struct fh_ctx {
   unsigned long long pass_seq = 0;           // passes submitted so far
   hipEvent_t ev_gen[3] = {nullptr, nullptr, nullptr}, ev_acc[3] = {nullptr, nullptr, nullptr}, ev_enter = nullptr;
   bool gen_valid[3] = {false, false, false}, acc_valid[3] = {false, false, false};
-  int n_slots = 2;  // passes in flight (FH_PIPELINE=0: 1, every pass on the main stream; =3: three)
+  int n_slots = 3;  // passes in flight (FH_PIPELINE=0: 1, every pass on the main stream; =2: two).  Three against two: +2.3 % on configs[2], +0.3-0.9 % on the others, one more path pool
   int last_slot_used = 0;  // slot of the pass submitted last (what the next pass orders itself after)
   // FH_FLAG_REFERENCE_FIRSTHIT (render.hip: k_firsthit_scan): per-pixel "a sample of this launch has hit something" + the AOVs of that hit
   uint32_t* d_quirk_seen = nullptr;
