@@ -229,7 +229,7 @@ FH_D uint32_t node8_test(const Ray8& r, const uint4 n0, const uint4 n1, const ui
       const float t0y = fmaf((float)byte_of(neary, j), sy, oy), t1y = fmaf((float)byte_of(fary, j), sy, oy);
       const float t0z = fmaf((float)byte_of(nearz, j), sz, oz), t1z = fmaf((float)byte_of(farz, j), sz, oz);
       const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
-      const float tf = fminf(fminf(t1x, t1y), t1z) * 1.000001f;
+      const float tf = fminf(fminf(t1x, t1y), t1z);  // no inflation: the child boxes carry the build's absolute padding (2^-16 of the scene's largest coordinate), ~100 x the rounding error of these distances
       if (tn <= tf && tn <= tmax) hitmask |= byte_of(child_bits4, j) << byte_of(bit_index4, j);
     }
   }
