@@ -747,7 +747,8 @@ __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : FH_SHADE_BLOCKS)
       const float4 hit = pool.hit[p];
       PoolSink o(pool, p, hit.x);
       const bool first = depth != 0 || (pool.flags[p] & 4u) == 0u;
-      shade_hit<LOBES>(sc, fr, rows, bs, depth, hit, mk3(pool.ray_d[p]), mk3(pool.thr[p]), mk3(pool.rad[p]), pool.pixel[p], pool.nspp[p], o, first);
+      const f3 L = depth == 0u ? mk3(pool.rad[p]) : mk3(0.0f);  // the radiance so far only enters at a directly visible emitter (first hit): later bounces skip the load
+      shade_hit<LOBES>(sc, fr, rows, bs, depth, hit, mk3(pool.ray_d[p]), mk3(pool.thr[p]), L, pool.pixel[p], pool.nspp[p], o, first);
       shaded = o.shaded;
       cont = o.cont;
       if (shaded || cont) cell = cell_of(fr, o.origin);
