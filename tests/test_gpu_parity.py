@@ -10,6 +10,7 @@ tests use size-independent properties: determinism, tile-shard invariance, batch
 any-hit/closest-hit consistency, and checker parity on a crop of rows.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1190,7 +1191,8 @@ def test_non_uniform_scene_matches_checker_with_either_builder(oracle, builder, 
     r.load_scene(sc)
     r.build_ias()
     st = r.stats()
-    assert st["bvh_tri_bytes"] > 48 * sc["indices"].shape[0]  # the ground triangles and the cables were split into several references
+    if os.environ.get("FH_SPLIT", "1") != "0":  # (tools/gpu_variants.sh also runs this file with split clipping switched off)
+        assert st["bvh_tri_bytes"] > 48 * sc["indices"].shape[0]  # the ground triangles and the cables were split into several references
     rays = _rays(np.random.default_rng(8), 20000, -1.0, 1.0)
     rays[:, 1] = np.abs(rays[:, 1]) * 0.8 + 0.01
     tuv_g, prim_g = r.trace_rays(rays)
