@@ -727,6 +727,11 @@ __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : FH_SHADE_BLOCKS)
     for (uint32_t i = threadIdx.x; i < sc.n_materials * (uint32_t)(sizeof(MaterialDev) / 4); i += blockDim.x) dst[i] = src[i];
     sc.materials = s_mat;
   }
+  __shared__ float s_srgb[256];  // the sRGB decode table: twelve lookups per fetch of a colour texture
+  if (sc.n_textures) {
+    s_srgb[threadIdx.x] = sc.srgb_lut[threadIdx.x];
+    sc.srgb_lut = s_srgb;
+  }
   BounceSlots bs;
   bs.set(fr, sc.n_lights, depth);
   bs.load_rows(rows, fr.sobol_bytes);  // (ends with the workgroup barrier that also publishes the tables above)
