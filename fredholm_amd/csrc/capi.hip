@@ -451,6 +451,19 @@ int fh_set_path_pool(fh_ctx* ctx, uint32_t target)
   return FH_OK;
 }
 
+int fh_path_pool_bytes(fh_ctx* ctx, uint64_t* bytes_per_path, uint32_t* pools)
+{
+  CTX_CHECK(ctx);
+  if (!bytes_per_path || !pools) return fail(ctx, FH_E_INVALID, "fh_path_pool_bytes: null argument");
+  // render.hip: pool_ensure -- path record 64, radiance 16, identity 8, flags 4, first-hit AOVs 64, a 48-byte place per kind of secondary ray, the pending
+  // light ray 32 (emitters only); queues: two radiance + one spare + secondary + its sorted copy 5 x 4, two 16-bit keys, one entry per shading class
+  const uint32_t sec = 2u + (ctx->has_dir ? 1u : 0u) + (ctx->n_lights > 0 ? 1u : 0u);
+  const uint32_t classes = ctx->n_classes < 1u ? 1u : ctx->n_classes;
+  *bytes_per_path = 64u + 16u + 8u + 4u + 64u + 48u * sec + (ctx->n_lights > 0 ? 32u : 0u) + 20u + 4u + 4u * classes;
+  *pools = (uint32_t)ctx->n_slots;
+  return FH_OK;
+}
+
 int fh_set_tail_depth(fh_ctx* ctx, uint32_t depth)
 {
   CTX_CHECK(ctx);

@@ -99,6 +99,8 @@ struct fh_ctx {
 
   // path pools: one per pass in flight (pass j uses slot j % n_slots and the stream of that slot); allocated on first use
   fh::PoolDev pool[3] = {};
+  struct PoolShape { bool dir = false, lights = false; uint32_t classes = 0; };  // what the records of a pool have room for (render.hip: pool_ensure)
+  PoolShape pool_shape[3];
   std::vector<void*> pool_allocs[3];
   uint32_t pool_target = 1u << 25;  // 32 Mi path slots (12.5 GB): 16 samples per pixel per pass at 1080p
   uint32_t tail_depth = 0;          // bounces run as wavefront kernels before k_tail finishes the survivors; 0 = adaptive

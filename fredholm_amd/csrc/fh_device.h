@@ -120,13 +120,16 @@ struct PoolDev {
   Rec<float4, 4> aov_texdepth;  // texcoord.xy, depth, -
   // secondary rays: SEC_COUNT x 3 float4 per path -- origin.xyz + tmax, direction.xyz + active (1.0f) / inactive (0.0f), contribution rgb if unoccluded
   float4* sec;
-  FH_HD size_t sec_at(uint32_t slot, uint32_t p) const { return ((size_t)p * SEC_COUNT + slot) * 3u; }
+  // only the ray kinds the scene can emit have a place in the record (no directional light, no emitters: sky ray + light ray = 96 bytes instead of 192)
+  uint32_t sec_count;       // places per path
+  uint32_t sec_index;       // place of slot s: byte s of this word
+  FH_HD size_t sec_at(uint32_t slot, uint32_t p) const { return ((size_t)p * sec_count + ((sec_index >> (8u * slot)) & 0xffu)) * 3u; }
   // BSDF-sampled light ray when the scene has emitters (needs the hit to finish the MIS weight), one 32-byte record
   Rec<float4, 2> lp_a;   // throughput.xyz, |cos|
   Rec<float4, 2> lp_b;   // f.xyz, pdf
   // queues
   uint32_t* q_rad[2];            // radiance-ray queue, ping-pong per bounce
-  uint32_t* q_cls;               // kNumQueues x capacity: hits routed by shading class
+  uint32_t* q_cls;               // (shading classes of the scene) x capacity: hits routed by shading class
   uint32_t* q_sec;               // shaded paths with secondary rays
   uint32_t* counters;            // kCounterStride words per bounce, zeroed once per pass
   // spatial ordering of the bounce queues (render.hip: sort_queue_by_cell): the shade kernel stores the cell of the hit point next

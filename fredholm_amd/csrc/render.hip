@@ -1248,19 +1248,30 @@ void pool_release(fh_ctx* ctx)
     for (void* p : ctx->pool_allocs[k]) (void)hipFree(p);
     ctx->pool_allocs[k].clear();
     ctx->pool[k] = PoolDev{};
+    ctx->pool_shape[k] = fh_ctx::PoolShape{};
     ctx->counters_in_flight[k] = false;
   }
 }
 
 int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
 {
-  if (ctx->pool[slot].capacity >= capacity) return FH_OK;
+  // what a path record has to hold depends on the scene and the lights: a place per kind of secondary ray, the pending light-ray record (emitters
+  // only), one queue per shading class.  A pool only grows: in paths, or when a later frame needs a kind of ray / a class it has no place for.
+  fh_ctx::PoolShape need;
+  need.dir = ctx->has_dir;
+  need.lights = ctx->n_lights > 0;
+  need.classes = ctx->n_classes < 1u ? 1u : ctx->n_classes;
+  fh_ctx::PoolShape& have = ctx->pool_shape[slot];
+  if (ctx->pool[slot].capacity >= capacity && (have.dir || !need.dir) && (have.lights || !need.lights) && have.classes >= need.classes) return FH_OK;
   if (ctx->pool[slot].capacity) {  // growing: nothing may still be running out of the old buffers
     FH_HIP(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 2; ++k) FH_HIP(hipStreamSynchronize(ctx->aux_stream[k]));
     for (void* p : ctx->pool_allocs[slot]) (void)hipFree(p);
     ctx->pool_allocs[slot].clear();
+    if (ctx->pool[slot].capacity > capacity) capacity = ctx->pool[slot].capacity;
+    need.dir = need.dir || have.dir; need.lights = need.lights || have.lights; need.classes = need.classes > have.classes ? need.classes : have.classes;
     ctx->pool[slot] = PoolDev{};
+    have = fh_ctx::PoolShape{};
     ctx->counters_in_flight[slot] = false;
   }
   PoolDev& P = ctx->pool[slot];
@@ -1271,18 +1282,23 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
     return e;
   };
   const size_t n = capacity;
+  const uint32_t i_dir = 0u, i_sky = need.dir ? 1u : 0u, i_area = i_sky + 1u, i_light = i_sky + 1u + (need.lights ? 1u : 0u);
+  const uint32_t sec_count = i_light + 1u;
   auto all = [&]() -> hipError_t {
     hipError_t e;
 #define FH_POOL(ptr, count) if ((e = alloc(ptr, count)) != hipSuccess) return e
     float4 *state = nullptr, *aov = nullptr, *lp = nullptr;
     uint32_t* ident = nullptr;
     FH_POOL(state, n * 4); FH_POOL(P.rad, n); FH_POOL(ident, n * 2); FH_POOL(P.flags, n);
-    FH_POOL(aov, n * 4); FH_POOL(P.sec, n * SEC_COUNT * 3); FH_POOL(lp, n * 2);
+    FH_POOL(aov, n * 4); FH_POOL(P.sec, n * sec_count * 3);
+    if (need.lights) FH_POOL(lp, n * 2);
+    P.sec_count = sec_count;
+    P.sec_index = i_dir | (i_sky << 8) | (i_area << 16) | (i_light << 24);
     P.ray_o.base = state; P.ray_d.base = state + 1; P.thr.base = state + 2; P.hit.base = state + 3;
     P.pixel.base = ident; P.nspp.base = ident + 1;
     P.aov_position.base = aov; P.aov_normal.base = aov + 1; P.aov_albedo.base = aov + 2; P.aov_texdepth.base = aov + 3;
-    P.lp_a.base = lp; P.lp_b.base = lp + 1;
-    FH_POOL(P.q_rad[0], n); FH_POOL(P.q_rad[1], n); FH_POOL(P.q_cls, n * kNumQueues); FH_POOL(P.q_sec, n);
+    P.lp_a.base = lp; P.lp_b.base = lp ? lp + 1 : nullptr;
+    FH_POOL(P.q_rad[0], n); FH_POOL(P.q_rad[1], n); FH_POOL(P.q_cls, n * need.classes); FH_POOL(P.q_sec, n);
     FH_POOL(P.counters, (size_t)kCounterStride * 66);  // up to 65 bounces per pass
     FH_POOL(P.key_sec, n); FH_POOL(P.key_rad, n); FH_POOL(P.q_tmp, n); FH_POOL(P.q_sec_sorted, n);
     FH_POOL(P.bins, (size_t)2 * kCells);
@@ -1297,6 +1313,7 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
     return fail(ctx, FH_E_HIP, std::string("path pool allocation: ") + hipGetErrorString(e));
   }
   P.capacity = capacity;
+  have = need;
   return FH_OK;
 }
 

@@ -189,6 +189,12 @@ class Renderer:
     def set_path_pool(self, target_paths):
         self._ck(N.lib().fh_set_path_pool(self._ctx, C.c_uint32(target_paths)), "fh_set_path_pool")
 
+    def path_pool_bytes(self):
+        """(bytes per path slot, pools) with the scene and lights as they are now: the pools take pools x target_paths x bytes of device memory"""
+        b, n = C.c_uint64(0), C.c_uint32(0)
+        self._ck(N.lib().fh_path_pool_bytes(self._ctx, C.byref(b), C.byref(n)), "fh_path_pool_bytes")
+        return int(b.value), int(n.value)
+
     def set_tail_depth(self, depth):
         self._ck(N.lib().fh_set_tail_depth(self._ctx, C.c_uint32(depth)), "fh_set_tail_depth")
 

@@ -140,6 +140,9 @@ int fh_set_flags(fh_ctx* ctx, uint32_t flags);
 /* target number of camera paths in flight per pass (path-pool slots); a pass starts floor(target / owned pixels) >= 1
  * samples per pixel.  Results do not depend on it.  Default 32 Mi paths (12.5 GB of pool). */
 int fh_set_path_pool(fh_ctx* ctx, uint32_t target_paths);
+/* device memory of the path pools with the scene and lights as they are now: bytes per path slot and the number of pools (one per pass in flight);
+ * a caller that sizes the pools for a frame (bench.py) multiplies: pools x target_paths x bytes_per_path */
+int fh_path_pool_bytes(fh_ctx* ctx, uint64_t* bytes_per_path, uint32_t* pools);
 /* number of bounces run as bounce-synchronous wavefront kernels before the surviving paths are finished by one
  * fused launch (k_tail).  Results do not depend on it.  0 (default) = adaptive: the depth at which fewer than 64 Ki
  * paths survived in earlier passes; a value >= max_depth disables the fused tail. */
