@@ -11,7 +11,7 @@ g = lambda n: float(re.search(n + r"\s+mean\s+([\d.]+)", blk).group(1))
 disp = int(re.search(r"dispatches=(\d+)", blk).group(1))
 fetch, write = g("FETCH_SIZE"), g("WRITE_SIZE")
 d = {"kernel": name, "config": 2,
-     "source": f"profiles/{tag}_pmc_summary.txt (tools/profile_round2.sh {tag}: separate rocprofv3 --pmc passes -- SQ group a, SQ group b, FETCH_SIZE, WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- of bench.py --steps 1 --warmup 1 --spp 256 --no-cpu-baseline; mean over the {disp} dispatches of the kernel; same launch size as the timed runs: 64 spp of the 1080p frame per pass)",
+     "source": f"profiles/{tag}_pmc_summary.txt (tools/profile_round2.sh {tag}: separate rocprofv3 --pmc passes -- SQ group a, SQ group b, FETCH_SIZE, WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- of bench.py --steps 1 --warmup 1 --spp 384 --no-cpu-baseline; mean over the {disp} dispatches of the kernel; same launch size as the timed runs: 128 spp of the 1080p frame per pass)",
      "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
      "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; KB = 1024 B.  The guide calibrates the doubling on wide streaming reads only; for the scattered 16-B node/triangle loads of this kernel it is an upper bound.",
      "traffic_bytes_per_launch": int((2 * fetch + write) * 1024),

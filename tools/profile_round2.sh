@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_ser
 find $R/gpurun_out/${tag}_serial_stats -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${tag}_serial_kernel_stats.csv \;
 find $R/gpurun_out/${tag}_stats $R/gpurun_out/${tag}_serial_stats -name "*kernel_trace.csv" -delete
 run() { name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_$name -- $B --steps 1 --warmup 1 --spp 256 --no-cpu-baseline > $R/gpurun_out/${tag}_$name.log 2>&1; echo "pmc $name rc=$?"
+  rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_$name -- $B --steps 1 --warmup 1 --spp 384 --no-cpu-baseline > $R/gpurun_out/${tag}_$name.log 2>&1; echo "pmc $name rc=$?"
 }
 run sqa SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD
 run sqb SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE
