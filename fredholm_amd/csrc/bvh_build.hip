@@ -351,7 +351,7 @@ __global__ void k_emit_tris(const float4* face_rec, const uint8_t* face_cls, con
 // children to the next level.  Levels are processed breadth first; node and triangle blocks are
 // allocated with atomics (the traversal result does not depend on their order, fh_trace.h).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kLeafMax8 = 3;  // upper bound (3 bits of unary count per leaf child)
+constexpr uint32_t kLeafMax8 = 3;  // scenes with at most this many faces get a single root node (k_collapse8_tiny)
 
 struct Work8 { int bnode; uint32_t wnode; };
 
@@ -377,6 +377,33 @@ __device__ __forceinline__ uint32_t quant_exponent(float extent)
   // guard against rounding in the division above
   while (e < 254u && __uint_as_float(e << 23) * 255.0f < extent) e += 1u;
   return e;
+}
+
+// Origin and scale of one axis of a wide node share a word (fh_trace.h): the low mantissa byte of the origin holds the biased exponent of the
+// scale, and the origin IS the float the word spells.  Returns the word for lower bound `lo` and upper bound `hi`: the largest such float that
+// is <= lo, with the smallest exponent whose 255 steps still reach hi from there.
+__device__ __forceinline__ uint32_t origin_word(float lo, uint32_t e)
+{
+  const uint32_t b = __float_as_uint(lo);
+  if (!(b >> 31)) {                       // lo >= +0: clearing mantissa bits rounds down, the exponent byte may round up again
+    uint32_t w = (b & ~0xffu) | e;
+    if (w > b) w = w >= 0x100u ? w - 0x100u : (0x80000000u | e);  // (nothing below on the positive side: the negative number closest to zero)
+    return w;
+  }
+  const uint32_t m = b & 0x7fffffffu;     // lo <= -0: the magnitude has to reach |lo|
+  uint32_t wm = (m & ~0xffu) | e;
+  if (wm < m) wm += 0x100u;
+  return 0x80000000u | wm;
+}
+__device__ __forceinline__ uint32_t quant_axis(float lo, float hi, float& origin)
+{
+  uint32_t e = quant_exponent(hi - lo);
+  for (;;) {
+    const uint32_t w = origin_word(lo, e);
+    origin = __uint_as_float(w);
+    if (e >= 254u || __uint_as_float(e << 23) * 255.0f >= hi - origin) return w;
+    e += 1u;
+  }
 }
 
 // ---- which descendants of a binary node become the children of its wide node: the cut of least cost (Ylitie, Karras, Laine 2017, section 3).
@@ -437,7 +464,7 @@ __global__ void k_cut_tables(int n_leaves, const int2* children, const int* node
 }
 
 __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* children, const int2* ranges, const float4* node_lo, const float4* node_hi, const float4* leaf_lo,
-                            const float4* leaf_hi, float pad, uint32_t leaf_max, uint32_t absorb, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_map, Work8* next_items, uint32_t* next_count,
+                            const float4* leaf_hi, float pad, uint32_t leaf_max, uint32_t absorb, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_slot, Work8* next_items, uint32_t* next_count,
                             const uint2* decision)
 {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -543,7 +570,7 @@ __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* ch
     slot_of[bc] = bs;
     child_in[bs] = bc;
   }
-  // count inner children / triangles, allocate blocks
+  // count inner children / triangles, allocate the block of inner children (triangles live in the node's own eight slots)
   uint32_t n_inner = 0, n_tris = 0;
   for (int sl = 0; sl < 8; ++sl) {
     const int c = child_in[sl];
@@ -552,72 +579,78 @@ __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* ch
     if (ref[c] >= 0 && cnt > leaf_max) n_inner++; else n_tris += cnt;
   }
   const uint32_t child_base = n_inner ? atomicAdd(node_counter, n_inner) : 0u;
-  const uint32_t tri_base = n_tris ? atomicAdd(tri_counter, n_tris) : 0u;
-  const uint32_t ex = quant_exponent(nhi[0] - nlo[0]), ey = quant_exponent(nhi[1] - nlo[1]), ez = quant_exponent(nhi[2] - nlo[2]);
-  const float isx = 1.0f / __uint_as_float(ex << 23), isy = 1.0f / __uint_as_float(ey << 23), isz = 1.0f / __uint_as_float(ez << 23);
-  uint32_t imask = 0, meta[2] = {0, 0}, q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
-  uint32_t inner_seen = 0, tri_off = 0;
+  if (n_tris) atomicAdd(tri_counter, n_tris);
+  float org[3];
+  const uint32_t wx = quant_axis(nlo[0], nhi[0], org[0]), wy = quant_axis(nlo[1], nhi[1], org[1]), wz = quant_axis(nlo[2], nhi[2], org[2]);
+  const float isx = 1.0f / __uint_as_float((wx & 0xffu) << 23), isy = 1.0f / __uint_as_float((wy & 0xffu) << 23), isz = 1.0f / __uint_as_float((wz & 0xffu) << 23);
+  uint32_t imask = 0, q[6][2] = {{~0u, ~0u}, {~0u, ~0u}, {~0u, ~0u}, {0, 0}, {0, 0}, {0, 0}};  // empty slots keep the inverted box (lo 255, hi 0)
+  uint32_t inner_seen = 0;
   uint32_t next_base = 0;
   if (n_inner) next_base = atomicAdd(next_count, n_inner);
   for (int sl = 0; sl < 8; ++sl) {
     const int c = child_in[sl];
     if (c < 0) continue;
     const uint32_t cnt = ref_count(ref[c], ranges);
-    uint32_t m;
     if (ref[c] >= 0 && cnt > leaf_max) {
       imask |= 1u << sl;
-      m = 0x20u | (24u + (uint32_t)sl);
       next_items[next_base + inner_seen] = Work8{ref[c], child_base + inner_seen};
       inner_seen++;
     } else {
-      const uint32_t first = ref_first(ref[c], ranges);
-      for (uint32_t k = 0; k < cnt; ++k) tri_map[tri_base + tri_off + k] = first + k;
-      m = (((1u << cnt) - 1u) << 5) | tri_off;
-      tri_off += cnt;
+      tri_slot[ref_first(ref[c], ranges)] = 8u * it.wnode + (uint32_t)sl;  // (leaf_max is 1: one triangle per leaf child)
     }
-    meta[sl >> 2] |= m << (8 * (sl & 3));
-    const float v[6] = {floorf((lo[c].x - nlo[0]) * isx), floorf((lo[c].y - nlo[1]) * isy), floorf((lo[c].z - nlo[2]) * isz),
-                        ceilf((hi[c].x - nlo[0]) * isx), ceilf((hi[c].y - nlo[1]) * isy), ceilf((hi[c].z - nlo[2]) * isz)};
+    const float v[6] = {floorf((lo[c].x - org[0]) * isx), floorf((lo[c].y - org[1]) * isy), floorf((lo[c].z - org[2]) * isz),
+                        ceilf((hi[c].x - org[0]) * isx), ceilf((hi[c].y - org[1]) * isy), ceilf((hi[c].z - org[2]) * isz)};
     for (int k = 0; k < 6; ++k) {
       const float cl = fminf(fmaxf(v[k], 0.0f), 255.0f);
-      q[k][sl >> 2] |= ((uint32_t)cl) << (8 * (sl & 3));
+      q[k][sl >> 2] = (q[k][sl >> 2] & ~(0xffu << (8 * (sl & 3)))) | (((uint32_t)cl) << (8 * (sl & 3)));
     }
   }
-  uint4* out = nodes + 5 * (size_t)it.wnode;
-  out[0] = make_uint4(__float_as_uint(nlo[0]), __float_as_uint(nlo[1]), __float_as_uint(nlo[2]), ex | (ey << 8) | (ez << 16) | (imask << 24));
-  out[1] = make_uint4(child_base, tri_base, meta[0], meta[1]);
-  out[2] = make_uint4(q[0][0], q[0][1], q[1][0], q[1][1]);
-  out[3] = make_uint4(q[2][0], q[2][1], q[3][0], q[3][1]);
-  out[4] = make_uint4(q[4][0], q[4][1], q[5][0], q[5][1]);
+  uint4* out = nodes + kBvh8NodeVec * (size_t)it.wnode;
+  out[0] = make_uint4(wx, wy, wz, (child_base << 8) | imask);
+  out[1] = make_uint4(q[0][0], q[0][1], q[1][0], q[1][1]);
+  out[2] = make_uint4(q[2][0], q[2][1], q[3][0], q[3][1]);
+  out[3] = make_uint4(q[4][0], q[4][1], q[5][0], q[5][1]);
 }
 
-// scenes with <= kLeafMax8 faces: a root whose slot 0 is the only leaf
-__global__ void k_collapse8_tiny(int n, const float4* face_lo, const float4* face_hi, float pad, uint4* nodes, uint32_t* tri_map)
+// scenes with <= kLeafMax8 faces: a root with one leaf child per face
+__global__ void k_collapse8_tiny(int n, const float4* face_lo, const float4* face_hi, float pad, uint4* nodes, uint32_t* tri_slot)
 {
   float l[3] = {3e38f, 3e38f, 3e38f}, h[3] = {-3e38f, -3e38f, -3e38f};
   for (int f = 0; f < n; ++f) {
     l[0] = fminf(l[0], face_lo[f].x - pad); l[1] = fminf(l[1], face_lo[f].y - pad); l[2] = fminf(l[2], face_lo[f].z - pad);
     h[0] = fmaxf(h[0], face_hi[f].x + pad); h[1] = fmaxf(h[1], face_hi[f].y + pad); h[2] = fmaxf(h[2], face_hi[f].z + pad);
-    tri_map[f] = (uint32_t)f;
+    tri_slot[f] = (uint32_t)f;
   }
-  const uint32_t ex = quant_exponent(h[0] - l[0]), ey = quant_exponent(h[1] - l[1]), ez = quant_exponent(h[2] - l[2]);
-  nodes[0] = make_uint4(__float_as_uint(l[0]), __float_as_uint(l[1]), __float_as_uint(l[2]), ex | (ey << 8) | (ez << 16));
-  nodes[1] = make_uint4(0u, 0u, (((1u << n) - 1u) << 5), 0u);
-  nodes[2] = make_uint4(0u, 0u, 0u, 0u);
-  nodes[3] = make_uint4(0u, 0u, 0xffu, 0u);
-  nodes[4] = make_uint4(0xffu, 0u, 0xffu, 0u);
+  float org[3];
+  const uint32_t wx = quant_axis(l[0], h[0], org[0]), wy = quant_axis(l[1], h[1], org[1]), wz = quant_axis(l[2], h[2], org[2]);
+  // every face gets the whole node box (0 .. 255 on every axis): with <= 3 triangles nothing is gained by tighter ones
+  const uint32_t lo4 = n >= 4 ? 0u : (~0u << (8 * n)), hi4 = ~lo4;
+  nodes[0] = make_uint4(wx, wy, wz, 0u);
+  nodes[1] = make_uint4(lo4, ~0u, lo4, ~0u);
+  nodes[2] = make_uint4(lo4, ~0u, hi4, 0u);
+  nodes[3] = make_uint4(hi4, 0u, hi4, 0u);
 }
 
-__global__ void k_emit_tris8(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, const uint32_t* tri_map, uint32_t n, float4* tris, const uint32_t* ref_face)
+// triangle slots of the wide tree: 8 per node, slot 8 * node + child slot; slots without a triangle hold a degenerate one (all zero, face id 0xffffffff)
+__global__ void k_emit_tris8(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, const uint32_t* tri_slot, uint32_t n, float4* tris, const uint32_t* ref_face)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t f = sorted_face[tri_map[i]];
+  uint32_t f = sorted_face[i];
   if (ref_face) f = ref_face[f];
+  const size_t t = 3 * (size_t)tri_slot[i];
   const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
-  tris[3 * (size_t)i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
-  tris[3 * (size_t)i + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);
-  tris[3 * (size_t)i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+  tris[t] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
+  tris[t + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);
+  tris[t + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+__global__ void k_clear_tris8(float4* tris, uint32_t n_slots)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  tris[3 * (size_t)i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
+  tris[3 * (size_t)i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  tris[3 * (size_t)i + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -712,11 +745,12 @@ __global__ void k_sah_sum(int n_inner, const float4* node_lo, const float4* node
 // face records and the boxes are recomputed bottom up, level by level (levels are contiguous node ranges because the collapse is
 // breadth first), with the build's own padding and quantisation rules.  Hits do not depend on the shape of the tree (fh_trace.h), so a
 // refitted tree returns the same bits as a rebuilt one; what degrades is its quality, which bvh_build_device watches.
-__global__ void k_refresh_tris8(const float4* face_rec, uint32_t n, float4* tris)
+__global__ void k_refresh_tris8(const float4* face_rec, uint32_t n_slots, float4* tris)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n_slots) return;
   const uint32_t f = __float_as_uint(tris[3 * (size_t)i].w);
+  if (f == 0xffffffffu) return;  // a slot without a triangle
   const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
   tris[3 * (size_t)i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
   tris[3 * (size_t)i + 1].x = b.x; tris[3 * (size_t)i + 1].y = b.y; tris[3 * (size_t)i + 1].z = b.z;  // .w keeps the alpha flag
@@ -728,51 +762,47 @@ __global__ void k_refit8_level(uint4* nodes, const float4* tris, float4* box, ui
 {
   const uint32_t ni = begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (ni >= end) return;
-  uint4* nd = nodes + 5 * (size_t)ni;
-  const uint4 n0 = nd[0], n1 = nd[1];
-  const uint32_t imask = n0.w >> 24, child_base = n1.x, tri_base = n1.y;
+  uint4* nd = nodes + kBvh8NodeVec * (size_t)ni;
+  const uint4 n0 = nd[0];
+  const uint32_t imask = n0.w & 0xffu, child_base = n0.w >> 8;
   float lo[8][3], hi[8][3];
   bool used[8];
   float nlo[3] = {3e38f, 3e38f, 3e38f}, nhi[3] = {-3e38f, -3e38f, -3e38f};
   for (int sl = 0; sl < 8; ++sl) {
-    const uint32_t m = ((sl < 4 ? n1.z : n1.w) >> (8 * (sl & 3))) & 0xffu;
-    used[sl] = m != 0u;
-    if (!used[sl]) continue;
-    if ((m >> 5) == 1u && (m & 0x1fu) >= 24u) {  // inner child: its own box, computed when its level was done (one padding already in it)
+    used[sl] = false;
+    if ((imask >> sl) & 1u) {  // inner child: its own box, computed when its level was done (one padding already in it)
       const uint32_t c = child_base + (uint32_t)__popc(imask & ((1u << sl) - 1u));
       const float4 l = box[2 * (size_t)c], h = box[2 * (size_t)c + 1];
       lo[sl][0] = l.x; lo[sl][1] = l.y; lo[sl][2] = l.z; hi[sl][0] = h.x; hi[sl][1] = h.y; hi[sl][2] = h.z;
-    } else {  // leaf child: bounds of its triangles, padded like the builder pads leaf boxes
-      const uint32_t cnt = (uint32_t)__popc(m >> 5), off = m & 0x1fu;
-      float l[3] = {3e38f, 3e38f, 3e38f}, h[3] = {-3e38f, -3e38f, -3e38f};
-      for (uint32_t k = 0; k < cnt; ++k) {
-        const size_t t = 3 * (size_t)(tri_base + off + k);
-        const float4 a = tris[t], b = tris[t + 1], c = tris[t + 2];
-        l[0] = fminf(l[0], fminf(a.x, fminf(b.x, c.x))); l[1] = fminf(l[1], fminf(a.y, fminf(b.y, c.y))); l[2] = fminf(l[2], fminf(a.z, fminf(b.z, c.z)));
-        h[0] = fmaxf(h[0], fmaxf(a.x, fmaxf(b.x, c.x))); h[1] = fmaxf(h[1], fmaxf(a.y, fmaxf(b.y, c.y))); h[2] = fmaxf(h[2], fmaxf(a.z, fmaxf(b.z, c.z)));
-      }
-      for (int k = 0; k < 3; ++k) { lo[sl][k] = l[k] - pad; hi[sl][k] = h[k] + pad; }
+    } else {  // leaf child: bounds of its triangle, padded like the builder pads leaf boxes
+      const size_t t = 3 * (size_t)(8u * ni + (uint32_t)sl);
+      const float4 a = tris[t], b = tris[t + 1], c = tris[t + 2];
+      if (__float_as_uint(a.w) == 0xffffffffu) continue;  // empty slot
+      lo[sl][0] = fminf(a.x, fminf(b.x, c.x)) - pad; lo[sl][1] = fminf(a.y, fminf(b.y, c.y)) - pad; lo[sl][2] = fminf(a.z, fminf(b.z, c.z)) - pad;
+      hi[sl][0] = fmaxf(a.x, fmaxf(b.x, c.x)) + pad; hi[sl][1] = fmaxf(a.y, fmaxf(b.y, c.y)) + pad; hi[sl][2] = fmaxf(a.z, fmaxf(b.z, c.z)) + pad;
     }
+    used[sl] = true;
     for (int k = 0; k < 3; ++k) { nlo[k] = fminf(nlo[k], lo[sl][k]); nhi[k] = fmaxf(nhi[k], hi[sl][k]); }
   }
   box[2 * (size_t)ni] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);
   box[2 * (size_t)ni + 1] = make_float4(nhi[0], nhi[1], nhi[2], 0.0f);
   if (!requantise) return;
-  const uint32_t ex = quant_exponent(nhi[0] - nlo[0]), ey = quant_exponent(nhi[1] - nlo[1]), ez = quant_exponent(nhi[2] - nlo[2]);
-  const float is[3] = {1.0f / __uint_as_float(ex << 23), 1.0f / __uint_as_float(ey << 23), 1.0f / __uint_as_float(ez << 23)};
-  uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  float org[3];
+  const uint32_t w[3] = {quant_axis(nlo[0], nhi[0], org[0]), quant_axis(nlo[1], nhi[1], org[1]), quant_axis(nlo[2], nhi[2], org[2])};
+  const float is[3] = {1.0f / __uint_as_float((w[0] & 0xffu) << 23), 1.0f / __uint_as_float((w[1] & 0xffu) << 23), 1.0f / __uint_as_float((w[2] & 0xffu) << 23)};
+  uint32_t q[6][2] = {{~0u, ~0u}, {~0u, ~0u}, {~0u, ~0u}, {0, 0}, {0, 0}, {0, 0}};
   for (int sl = 0; sl < 8; ++sl) {
     if (!used[sl]) continue;
     for (int k = 0; k < 3; ++k) {
-      const float vl = fminf(fmaxf(floorf((lo[sl][k] - nlo[k]) * is[k]), 0.0f), 255.0f), vh = fminf(fmaxf(ceilf((hi[sl][k] - nlo[k]) * is[k]), 0.0f), 255.0f);
-      q[k][sl >> 2] |= ((uint32_t)vl) << (8 * (sl & 3));
+      const float vl = fminf(fmaxf(floorf((lo[sl][k] - org[k]) * is[k]), 0.0f), 255.0f), vh = fminf(fmaxf(ceilf((hi[sl][k] - org[k]) * is[k]), 0.0f), 255.0f);
+      q[k][sl >> 2] = (q[k][sl >> 2] & ~(0xffu << (8 * (sl & 3)))) | (((uint32_t)vl) << (8 * (sl & 3)));
       q[3 + k][sl >> 2] |= ((uint32_t)vh) << (8 * (sl & 3));
     }
   }
-  nd[0] = make_uint4(__float_as_uint(nlo[0]), __float_as_uint(nlo[1]), __float_as_uint(nlo[2]), ex | (ey << 8) | (ez << 16) | (imask << 24));
-  nd[2] = make_uint4(q[0][0], q[0][1], q[1][0], q[1][1]);
-  nd[3] = make_uint4(q[2][0], q[2][1], q[3][0], q[3][1]);
-  nd[4] = make_uint4(q[4][0], q[4][1], q[5][0], q[5][1]);
+  nd[0] = make_uint4(w[0], w[1], w[2], n0.w);
+  nd[1] = make_uint4(q[0][0], q[0][1], q[1][0], q[1][1]);
+  nd[2] = make_uint4(q[2][0], q[2][1], q[3][0], q[3][1]);
+  nd[3] = make_uint4(q[4][0], q[4][1], q[5][0], q[5][1]);
 }
 
 __global__ void k_box_area_sum(uint32_t n, const float4* box, double* sum)
@@ -826,7 +856,7 @@ int bvh_build_device(fh_ctx* ctx)
     const int init_bounds[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
     FH_HIP(hipMemcpyAsync(bounds.p, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_face_bounds, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_face_rec, n, face_lo.p, face_hi.p, bounds.p);
-    hipLaunchKernelGGL(k_refresh_tris8, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_face_rec, n, ctx->d_bvh8_tris);
+    hipLaunchKernelGGL(k_refresh_tris8, dim3((8u * ctx->bvh8_n_nodes + 255) / 256), dim3(256), 0, st, ctx->d_face_rec, 8u * ctx->bvh8_n_nodes, ctx->d_bvh8_tris);
     int hb[6];
     FH_HIP(hipMemcpyAsync(hb, bounds.p, sizeof hb, hipMemcpyDeviceToHost, st));
     FH_HIP(hipStreamSynchronize(st));
@@ -891,12 +921,13 @@ int bvh_build_device(fh_ctx* ctx)
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh2_n_nodes = 1;
     if (n <= kLeafMax8) {
-      DevBuf<uint32_t> tri_map;
-      FH_HIP(tri_map.alloc(n));
-      FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * 5));
-      FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n));
-      hipLaunchKernelGGL(k_collapse8_tiny, dim3(1), dim3(1), 0, st, (int)n, face_lo.p, face_hi.p, pad, ctx->d_bvh8_nodes, tri_map.p);
-      hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, tri_map.p, n, ctx->d_bvh8_tris, (const uint32_t*)nullptr);
+      DevBuf<uint32_t> tri_slot;
+      FH_HIP(tri_slot.alloc(n));
+      FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * kBvh8NodeVec));
+      FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * 8ull));
+      hipLaunchKernelGGL(k_clear_tris8, dim3(1), dim3(64), 0, st, ctx->d_bvh8_tris, 8u);
+      hipLaunchKernelGGL(k_collapse8_tiny, dim3(1), dim3(1), 0, st, (int)n, face_lo.p, face_hi.p, pad, ctx->d_bvh8_nodes, tri_slot.p);
+      hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, tri_slot.p, n, ctx->d_bvh8_tris, (const uint32_t*)nullptr);
       FH_HIP(hipStreamSynchronize(st));
       ctx->bvh8_n_nodes = 1;
       ctx->bvh8_n_tris = n;
@@ -1051,15 +1082,12 @@ int bvh_build_device(fh_ctx* ctx)
 
     // ---- collapse to BVH8, breadth first
     DevBuf<Work8> work_a, work_b;
-    DevBuf<uint32_t> counters, tri_map;  // [0] node counter, [1] triangle counter, [2] next-level item count
-    FH_HIP(work_a.alloc(n_inner)); FH_HIP(work_b.alloc(n_inner)); FH_HIP(counters.alloc(3)); FH_HIP(tri_map.alloc(nr));
-    FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * 5ull * n_inner));
-    FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * nr));
-    uint32_t leaf_max8 = 1;  // one triangle per leaf child: box tests are ~4x cheaper than triangle tests (profiles/README.md)
+    DevBuf<uint32_t> counters, tri_slot;  // [0] node counter, [1] triangle counter, [2] next-level item count; triangle slot of every sorted leaf
+    FH_HIP(work_a.alloc(n_inner)); FH_HIP(work_b.alloc(n_inner)); FH_HIP(counters.alloc(3)); FH_HIP(tri_slot.alloc(nr));
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * (size_t)kBvh8NodeVec * n_inner));
+    const uint32_t leaf_max8 = 1;  // one triangle per leaf child (the node layout has one triangle slot per child slot): box tests are ~4x cheaper than triangle tests (profiles/README.md)
     uint32_t absorb8 = 1u;  // FH_ABSORB=0: plain largest-child-first collapse
     if (const char* e = getenv("FH_ABSORB")) absorb8 = e[0] != '0' ? 1u : 0u;
-    if (const char* e = getenv("FH_LEAF8")) { const int v = atoi(e); if (v >= 1 && v <= (int)kLeafMax8) leaf_max8 = (uint32_t)v; }
-    if (ploc) leaf_max8 = 1;  // PLOC subtrees are not contiguous leaf ranges: one triangle per leaf child
     // the cut of least summed wide-node area (k_cut_tables); FH_COLLAPSE=greedy: the largest-child-first rule above
     bool optimal_cut = leaf_max8 == 1;
     if (const char* e = getenv("FH_COLLAPSE")) optimal_cut = optimal_cut && std::strcmp(e, "greedy") != 0;
@@ -1090,7 +1118,7 @@ int bvh_build_device(fh_ctx* ctx)
       level_start.push_back(level_start.back() + level_count);
       FH_HIP(hipMemsetAsync(counters.p + 2, 0, 4, st));
       hipLaunchKernelGGL(k_collapse8, dim3((level_count + 63) / 64), dim3(64), 0, st, cur, level_count, c_children, c_ranges, c_node_lo, c_node_hi, leaf_lo.p, leaf_hi.p, pad,
-                         leaf_max8, absorb8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_map.p, nxt, counters.p + 2, optimal_cut ? cut_decision.p : (const uint2*)nullptr);
+                         leaf_max8, absorb8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_slot.p, nxt, counters.p + 2, optimal_cut ? cut_decision.p : (const uint2*)nullptr);
       FH_HIP(hipMemcpyAsync(&level_count, counters.p + 2, 4, hipMemcpyDeviceToHost, st));
       FH_HIP(hipStreamSynchronize(st));
       Work8* t = cur; cur = nxt; nxt = t;
@@ -1101,8 +1129,12 @@ int bvh_build_device(fh_ctx* ctx)
     if (final_counters[1] != nr) return fail(ctx, FH_E_INVALID, "BVH8 collapse lost triangles");
     if (levels > (uint32_t)kBvh8Stack) return fail(ctx, FH_E_UNSUPPORTED, "BVH8 deeper than the traversal stack (48 levels)");
     if (final_counters[0] >= (1u << 24)) return fail(ctx, FH_E_UNSUPPORTED, "BVH8 with 2^24 or more nodes (the traversal stack keeps node indices in 24 bits)");
+    if (final_counters[0] >= kCoopMaxTris / 8u) return fail(ctx, FH_E_UNSUPPORTED, "BVH8 with 2^23 or more nodes (the cooperative triangle queue keeps triangle slots in 26 bits)");
     ctx->bvh8_depth = levels;
-    hipLaunchKernelGGL(k_emit_tris8, dim3(rblocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_map.p, nr, ctx->d_bvh8_tris, ref_face);
+    const uint32_t n_slots = 8u * final_counters[0];  // one triangle slot per child slot
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n_slots));
+    hipLaunchKernelGGL(k_clear_tris8, dim3((n_slots + 255) / 256), dim3(256), 0, st, ctx->d_bvh8_tris, n_slots);
+    hipLaunchKernelGGL(k_emit_tris8, dim3(rblocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_slot.p, nr, ctx->d_bvh8_tris, ref_face);
     FH_HIP(hipGetLastError());
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh8_n_nodes = final_counters[0];
@@ -1124,7 +1156,7 @@ int bvh_build_device(fh_ctx* ctx)
   ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
   if (getenv("FH_BVH2")) ctx->use_bvh8 = false;  // developer switch: traverse the binary layout instead of the wide one
   ctx->stats.bvh_nodes = ctx->use_bvh8 ? ctx->bvh8_n_nodes : ctx->bvh2_n_nodes;
-  ctx->stats.bvh_node_bytes = ctx->use_bvh8 ? 80ull * ctx->bvh8_n_nodes : 64ull * ctx->bvh2_n_nodes;
+  ctx->stats.bvh_node_bytes = ctx->use_bvh8 ? 16ull * kBvh8NodeVec * ctx->bvh8_n_nodes : 64ull * ctx->bvh2_n_nodes;
   ctx->stats.bvh_tri_bytes = 48ull * (ctx->use_bvh8 ? ctx->bvh8_n_tris : ctx->bvh2_n_tris);
   ctx->stats.bvh_depth = ctx->use_bvh8 ? ctx->bvh8_depth : 0;
   return FH_OK;

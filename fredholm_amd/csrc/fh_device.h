@@ -42,8 +42,8 @@ struct Bvh2Dev {
 
 // wide BVH (8 children, quantised boxes), see fh_trace.h
 struct Bvh8Dev {
-  const uint4* nodes;   // 5 x uint4 (80 bytes) per node
-  const float4* tris;   // 3 x float4 per leaf triangle, grouped per node
+  const uint4* nodes;   // 4 x uint4 (64 bytes) per node
+  const float4* tris;   // 3 x float4 per triangle slot, eight slots per node (slot 8 * node + child slot)
   uint32_t n_nodes;
   uint32_t n_tris;
   uint32_t depth;       // levels of the tree (>= 2): entries of the LDS traversal stack

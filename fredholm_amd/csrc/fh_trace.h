@@ -182,58 +182,108 @@ FH_D bool traverse_bvh2(const Bvh2Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
 
 
 // ---------------------------------------------------------------------------------------------
-// BVH8: 80-byte nodes with eight children whose boxes are quantised to 8 bits per plane relative
-// to the node's origin and per-axis power-of-two scale (layout after Ylitie, Karras, Laine,
-// "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017):
-//   n0 = origin.xyz (float bits), ex | ey<<8 | ez<<16 | imask<<24     (e* = biased exponent of the scale)
-//   n1 = first inner-child node index, first triangle index, meta[0..3], meta[4..7]
-//   n2 = qlo_x[0..7], qlo_y[0..7]    n3 = qlo_z[0..7], qhi_x[0..7]    n4 = qhi_y[0..7], qhi_z[0..7]
-// meta byte of child slot i: 0 = empty; inner child: 0x20 | (24 + i); leaf of k <= 3 triangles:
-// (unary k: 1,3,7) << 5 | offset of its first triangle in the node's triangle block (0..23).
-// A node test yields a 32-bit mask: bits 24..31 inner children ordered by the ray octant, bits 0..23
-// one bit per leaf triangle.  One node = five 16-byte loads and replaces ~3 levels of a binary tree.
+// BVH8: 64-byte nodes with eight children whose boxes are quantised to 8 bits per plane relative
+// to the node's origin and per-axis power-of-two scale (after Ylitie, Karras, Laine, "Efficient
+// Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017, with everything that is
+// not a plane squeezed into the first 16 bytes so that a node is FOUR 16-byte loads and never straddles a 128-byte line):
+//   n0 = origin.x | ex, origin.y | ey, origin.z | ez, first inner-child node index << 8 | imask
+//        The biased exponent of an axis' scale sits in the low mantissa byte of that axis' origin; the origin is the float
+//        the word spells WITH that byte (the builder picks it at or below the node's lower corner and quantises against it).
+//   n1 = qlo_x[0..7], qlo_y[0..7]    n2 = qlo_z[0..7], qhi_x[0..7]    n3 = qhi_y[0..7], qhi_z[0..7]
+// Child slot i is an inner node when bit i of imask is set (the inner children of a node are consecutive nodes, in slot
+// order), else a leaf holding the ONE triangle in slot 8 * node + i of the triangle array, else empty: an empty slot has the
+// inverted box (lo 255, hi 0) no ray enters, and its triangle slot holds a degenerate triangle no ray hits.
+// A node test yields one bit per child slot.  Inner hits are then permuted by the ray's octant (bit i -> bit i ^ oct) so that
+// "highest bit first" visits the children front to back.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBvh8Stack = 48;
+constexpr uint32_t kBvh8NodeVec = 4;  // uint4 per node
 
 struct Ray8 {
   f3 o, inv;       // origin, safe reciprocal direction
-  uint32_t oct4;   // octant inversion mask replicated in 4 bytes
+  uint32_t oct;    // octant: bit 2 / 1 / 0 set when the x / y / z direction is positive
   bool nx, ny, nz; // direction signs
 };
 
-FH_D uint32_t byte_of(uint32_t w, int j) { return (w >> (8 * j)) & 0xffu; }
+// bit i of an 8-bit mask -> bit i ^ oct
+FH_D uint32_t octant_permute(uint32_t m, uint32_t oct)
+{
+  const uint32_t s4 = oct & 4u, s2 = oct & 2u, s1 = oct & 1u;
+  m = ((m * 0x0101u) >> s4) & 0xffu;                          // oct & 4: swap the nibbles
+  m = ((m << s2) & 0xccu) | ((m >> s2) & 0x33u);              // oct & 2: swap the bit pairs (a shift of 0 leaves m as it is)
+  m = ((m << s1) & 0xaau) | ((m >> s1) & 0x55u);              // oct & 1: swap neighbours
+  return m;
+}
 
-FH_D uint32_t node8_test(const Ray8& r, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, const uint4 n4, float tmax)
+// EXPERIMENT, not used by the kernels (node8_test<true>; tools/micro/issue_peak.hip measures it): byte k of w as a float, scaled by 2^-23 -- the byte,
+// read as the bit pattern of a (denormal) float, is k * 2^-149; times 2^126 that is exact.  On gfx950 v_fma / v_mul / v_add_f32 issue in ~2.2 cycles per
+// wave and run BESIDE the 4-cycle instructions of everything else (a 1:1 mix of v_fma_f32 and v_max3_f32 issues at 2.3 cycles per instruction,
+// profiles/r03_issue_peak.txt), so a node test costs 4 cycles x its ~140 non-FMA instructions and the 48 v_cvt_f32_ubyte are a third of them.  Moving the
+// conversion to an FMA-class instruction through the SDWA byte select does NOT move it to the fast pipe: v_mul_f32_sdwa issues at 4.3 cycles and the
+// node test gets 18 % slower (0.0035 against 0.0042 G tests/s per SIMD), so the plain conversion stays.  v_fma_mix_f32 (f16 planes) is a 4-cycle form too.
+template <int K>
+FH_D float byte_scaled(uint32_t w, float two126)
+{
+  float f;
+  if (K == 0) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(f) : "v"(w), "v"(two126));
+  if (K == 1) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(f) : "v"(w), "v"(two126));
+  if (K == 2) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(f) : "v"(w), "v"(two126));
+  if (K == 3) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(f) : "v"(w), "v"(two126));
+  return f;
+}
+
+template <int J, bool SDWA>
+FH_D void node8_child(uint32_t& hits, uint32_t nearx, uint32_t farx, uint32_t neary, uint32_t fary, uint32_t nearz, uint32_t farz, float sx, float sy, float sz, float ox, float oy, float oz,
+                      float tmax, float two126)
+{
+  float b0x, b1x, b0y, b1y, b0z, b1z;
+  if (SDWA) {
+    b0x = byte_scaled<J>(nearx, two126); b1x = byte_scaled<J>(farx, two126); b0y = byte_scaled<J>(neary, two126); b1y = byte_scaled<J>(fary, two126);
+    b0z = byte_scaled<J>(nearz, two126); b1z = byte_scaled<J>(farz, two126);
+  } else {
+    b0x = (float)((nearx >> (8 * J)) & 0xffu); b1x = (float)((farx >> (8 * J)) & 0xffu); b0y = (float)((neary >> (8 * J)) & 0xffu); b1y = (float)((fary >> (8 * J)) & 0xffu);
+    b0z = (float)((nearz >> (8 * J)) & 0xffu); b1z = (float)((farz >> (8 * J)) & 0xffu);
+  }
+  const float t0x = fmaf(b0x, sx, ox), t1x = fmaf(b1x, sx, ox);
+  const float t0y = fmaf(b0y, sy, oy), t1y = fmaf(b1y, sy, oy);
+  const float t0z = fmaf(b0z, sz, oz), t1z = fmaf(b1z, sz, oz);
+  const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
+  const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));  // no inflation: the child boxes carry the build's absolute padding (2^-16 of the scene's largest coordinate), ~100 x the rounding error of these distances
+  // hits = 2 * hits + (tn <= tf): the compare leaves its result in the carry, the add-with-carry shifts it in (one VALU instruction per child
+  // instead of a select, a shift and an or)
+  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(tn), "v"(tf) : "vcc");
+}
+
+#ifndef FH_NODE_SDWA
+#define FH_NODE_SDWA 0
+#endif
+// one bit per child slot whose (conservative) box the ray enters before tmax
+template <bool SDWA = (FH_NODE_SDWA != 0)>
+FH_D uint32_t node8_test(const Ray8& r, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, float tmax)
 {
   const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
-  const float sx = __uint_as_float((n0.w & 0xffu) << 23) * r.inv.x;
-  const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * r.inv.y;
-  const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * r.inv.z;
+  // scale of an axis = 2^(e - 127) with e the low byte of the origin word (<< 23 shifts everything else out; bit 8 lands in the sign, hence the fabsf, a free
+  // source modifier); the SDWA form of the byte conversion delivers byte * 2^-23, so its scale carries 2^23 (the builder keeps e + 23 below 255)
+  const float kx = fabsf(__uint_as_float((n0.x + (SDWA ? 23u : 0u)) << 23)), ky = fabsf(__uint_as_float((n0.y + (SDWA ? 23u : 0u)) << 23)), kz = fabsf(__uint_as_float((n0.z + (SDWA ? 23u : 0u)) << 23));
+  const float sx = kx * r.inv.x, sy = ky * r.inv.y, sz = kz * r.inv.z;
   const float ox = (px - r.o.x) * r.inv.x, oy = (py - r.o.y) * r.inv.y, oz = (pz - r.o.z) * r.inv.z;
-  uint32_t hitmask = 0;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const uint32_t meta4 = half ? n1.w : n1.z;
-    const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-    const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
-    const uint32_t bit_index4 = (meta4 ^ (r.oct4 & inner_mask4)) & 0x1f1f1f1fu;
-    const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
-    const uint32_t qlx = half ? n2.y : n2.x, qly = half ? n2.w : n2.z, qlz = half ? n3.y : n3.x;
-    const uint32_t qhx = half ? n3.w : n3.z, qhy = half ? n4.y : n4.x, qhz = half ? n4.w : n4.z;
-    const uint32_t nearx = r.nx ? qhx : qlx, farx = r.nx ? qlx : qhx;
-    const uint32_t neary = r.ny ? qhy : qly, fary = r.ny ? qly : qhy;
-    const uint32_t nearz = r.nz ? qhz : qlz, farz = r.nz ? qlz : qhz;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float t0x = fmaf((float)byte_of(nearx, j), sx, ox), t1x = fmaf((float)byte_of(farx, j), sx, ox);
-      const float t0y = fmaf((float)byte_of(neary, j), sy, oy), t1y = fmaf((float)byte_of(fary, j), sy, oy);
-      const float t0z = fmaf((float)byte_of(nearz, j), sz, oz), t1z = fmaf((float)byte_of(farz, j), sz, oz);
-      const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
-      const float tf = fminf(fminf(t1x, t1y), t1z);  // no inflation: the child boxes carry the build's absolute padding (2^-16 of the scene's largest coordinate), ~100 x the rounding error of these distances
-      if (tn <= tf && tn <= tmax) hitmask |= byte_of(child_bits4, j) << byte_of(bit_index4, j);
-    }
+  const float two126 = 8.507059173023462e37f;
+  uint32_t hits = 0;
+  {  // slots 7 .. 4, then 3 .. 0: every test shifts the mask left and moves its result in at the bottom
+    const uint32_t nearx = r.nx ? n2.w : n1.y, farx = r.nx ? n1.y : n2.w, neary = r.ny ? n3.y : n1.w, fary = r.ny ? n1.w : n3.y, nearz = r.nz ? n3.w : n2.y, farz = r.nz ? n2.y : n3.w;
+    node8_child<3, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
+    node8_child<2, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
+    node8_child<1, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
+    node8_child<0, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
   }
-  return hitmask;
+  {
+    const uint32_t nearx = r.nx ? n2.z : n1.x, farx = r.nx ? n1.x : n2.z, neary = r.ny ? n3.x : n1.z, fary = r.ny ? n1.z : n3.x, nearz = r.nz ? n3.z : n2.x, farz = r.nz ? n2.x : n3.z;
+    node8_child<3, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
+    node8_child<2, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
+    node8_child<1, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
+    node8_child<0, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
+  }
+  return hits;
 }
 
 FH_D Ray8 ray8_prepare(const RayPre& rp, f3 d)
@@ -243,8 +293,20 @@ FH_D Ray8 ray8_prepare(const RayPre& rp, f3 d)
   r.inv = rp.inv;
   (void)d;
   r.nx = r.inv.x < 0.0f; r.ny = r.inv.y < 0.0f; r.nz = r.inv.z < 0.0f;  // sign of the reciprocal actually used (-0.0 components count as negative)
-  r.oct4 = ((r.nx ? 0u : 4u) | (r.ny ? 0u : 2u) | (r.nz ? 0u : 1u)) * 0x01010101u;
+  r.oct = (r.nx ? 0u : 4u) | (r.ny ? 0u : 2u) | (r.nz ? 0u : 1u);
   return r;
+}
+
+// one visited node: the group of its inner children the ray enters (first-child node index, octant-ordered hit bits << 24 | imask)
+// and the group of its candidate triangles (first triangle slot, one bit per slot)
+FH_D void node8_visit(const Bvh8Dev& bvh, const Ray8& r, uint32_t ni, float tmax, uint2& group, uint2& tg)
+{
+  const uint4* nd = bvh.nodes + kBvh8NodeVec * (size_t)ni;
+  const uint4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+  const uint32_t hm = node8_test<>(r, n0, n1, n2, n3, tmax);
+  const uint32_t imask = n0.w & 0xffu;
+  group = make_uint2(n0.w >> 8, (octant_permute(hm & imask, r.oct) << 24) | imask);
+  tg = make_uint2(8u * ni, hm & ~imask);
 }
 
 // wave-level step counters of the instrumented build: how many times a wave executed the node test /
@@ -302,15 +364,11 @@ FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
       const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
       group.y &= ~(1u << bit);
       if (group.y & 0xff000000u) stack.push(group);
-      const uint32_t slot = (bit - 24u) ^ (r.oct4 & 7u);
+      const uint32_t slot = (bit - 24u) ^ r.oct;
       const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
       const uint32_t ni = group.x + rel;
-      const uint4 n0 = bvh.nodes[5 * (size_t)ni], n1 = bvh.nodes[5 * (size_t)ni + 1], n2 = bvh.nodes[5 * (size_t)ni + 2], n3 = bvh.nodes[5 * (size_t)ni + 3],
-                  n4 = bvh.nodes[5 * (size_t)ni + 4];
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
-      const uint32_t hm = node8_test(r, n0, n1, n2, n3, n4, best.t);
-      group = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
-      tg = make_uint2(n1.y, hm & 0x00ffffffu);
+      node8_visit(bvh, r, ni, best.t, group, tg);
     } else {
       tg = group;
       group = make_uint2(0u, 0u);
@@ -432,15 +490,11 @@ FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float t
       const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
       group.y &= ~(1u << bit);
       if (group.y & 0xff000000u) stack.push(group);
-      const uint32_t slot = (bit - 24u) ^ (r.oct4 & 7u);
+      const uint32_t slot = (bit - 24u) ^ r.oct;
       const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
       const uint32_t ni = group.x + rel;
-      const uint4 n0 = bvh.nodes[5 * (size_t)ni], n1 = bvh.nodes[5 * (size_t)ni + 1], n2 = bvh.nodes[5 * (size_t)ni + 2], n3 = bvh.nodes[5 * (size_t)ni + 3],
-                  n4 = bvh.nodes[5 * (size_t)ni + 4];
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
-      const uint32_t hm = node8_test(r, n0, n1, n2, n3, n4, best_t);
-      group = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
-      tg = make_uint2(n1.y, hm & 0x00ffffffu);
+      node8_visit(bvh, r, ni, best_t, group, tg);
     }
     // hand the candidate triangles to the wave's queue, one per lane and round
     for (;;) {
@@ -527,7 +581,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   const uint32_t lane = __lane_id();
   GroupStack<LDS> stack(lds_column, lds_stride);
   Ray8 r;
-  r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct4 = 0u; r.nx = r.ny = r.nz = false;
+  r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct = 0u; r.nx = r.ny = r.nz = false;
   uint2 group = make_uint2(0u, 0u);
   bool busy = false;  // the lane's ray still has nodes to visit
   bool have = false;  // the lane holds a ray that is not committed yet
@@ -603,14 +657,10 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
       group.y &= ~(1u << bit);
       if (group.y & 0xff000000u) stack.push(group);
-      const uint32_t slot = (bit - 24u) ^ (r.oct4 & 7u);
+      const uint32_t slot = (bit - 24u) ^ r.oct;
       const uint32_t ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
-      const uint4 n0 = bvh.nodes[5 * (size_t)ni], n1 = bvh.nodes[5 * (size_t)ni + 1], n2 = bvh.nodes[5 * (size_t)ni + 2], n3 = bvh.nodes[5 * (size_t)ni + 3],
-                  n4 = bvh.nodes[5 * (size_t)ni + 4];
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
-      const uint32_t hm = node8_test(r, n0, n1, n2, n3, n4, best_t);
-      group = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
-      tg = make_uint2(n1.y, hm & 0x00ffffffu);
+      node8_visit(bvh, r, ni, best_t, group, tg);
     }
     for (;;) {
       const bool has = tg.y != 0u;
