@@ -378,6 +378,10 @@ int fh_ctx_create(int device, fh_ctx** out)
     fh_ctx::Tunables& t = ctx->tun;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) t.n_cus = (uint32_t)prop.multiProcessorCount;
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && v >= 64 * 1024) t.lds_per_cu = (uint32_t)v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && v >= 64 * 1024) t.lds_per_block = (uint32_t)v;
+    if (t.lds_per_block > t.lds_per_cu) t.lds_per_block = t.lds_per_cu;
     auto env_uint = [](const char* name, int lo, int hi, uint32_t& dst) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) dst = (uint32_t)v; } };
     auto env_off = [](const char* name, bool& dst) { if (const char* e = getenv(name)) dst = e[0] != '0'; };
     env_uint("FH_COOP_T", 1, 64, t.coop_flush);
@@ -388,6 +392,8 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_STREAM_GRID", 8, 8192, t.stream_grid);
     t.stream_grid &= ~7u;
     env_uint("FH_STREAM_REFILL", 1, 64, t.stream_refill);
+    env_uint("FH_STREAM_MIN_RAYS", 0, 65535, t.stream_min_rays);
+    env_off("FH_SORT_SMALL", t.sort_small);
     env_uint("FH_STREAM_CHUNK", 16, 65535, t.stream_chunk);
     t.stream_chunk_fixed = getenv("FH_STREAM_CHUNK") != nullptr;
     env_uint("FH_TAIL_DEPTH", 0, 64, t.tail_depth);
@@ -704,6 +710,11 @@ int fh_sync(fh_ctx* ctx)
     ctx->event_pool.push_back(s.b);
   }
   ctx->spans.clear();
+  if (ctx->flags & FH_FLAG_TIME_KERNELS) {  // shader cycles and 100 MHz ticks the waves of the streaming traversal kernels have summed up (fh_device.h: ClockStamp)
+    unsigned long long c[4];
+    FH_HIP(hipMemcpy(c, ctx->d_trace_counters + 27, sizeof c, hipMemcpyDeviceToHost));
+    ctx->stats.clk_cycles_closest = c[0]; ctx->stats.clk_ticks_closest = c[1]; ctx->stats.clk_cycles_shadow = c[2]; ctx->stats.clk_ticks_shadow = c[3];
+  }
   if (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) {
     unsigned long long c[32];
     FH_HIP(hipMemcpy(c, ctx->d_trace_counters, sizeof c, hipMemcpyDeviceToHost));

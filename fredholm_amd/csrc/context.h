@@ -76,6 +76,7 @@ struct fh_ctx {
   uint32_t bvh8_depth = 0;            // levels of the wide tree = most entries a traversal stack can hold
   uint32_t occupancy_key = 0xffffffffu, occupancy_blocks = 0, occupancy_blocks_secondary = 0;  // resident workgroups per CU of the streaming kernels, as the runtime reports them (render.hip)
   uint32_t lds_configured_bytes = 0;  // dynamic-LDS size the traversal kernels were last configured for (render.hip)
+  uint32_t lds_static_max = 0;        // largest static LDS of a kernel that keeps its traversal stack in dynamic LDS (hipFuncGetAttributes; render.hip: configure_traversal_lds)
   bool use_bvh8 = false;
   int builder_choice = 0;  // 0 = not decided for this scene, 1 = radix tree (LBVH), 2 = PLOC; decided at the first build after an upload
   double bvh_build_ms = 0.0;
@@ -122,6 +123,7 @@ struct fh_ctx {
   // device facts and developer switches, read ONCE at fh_ctx_create (fh_render does no getenv / hipGetDeviceProperties)
   struct Tunables {
     uint32_t n_cus = 256;
+    uint32_t lds_per_cu = 160u * 1024u, lds_per_block = 160u * 1024u;  // LDS of a CU / the most one workgroup may take, from the device attributes (gfx950: 160 KB both)
     uint32_t coop_flush = 32;       // FH_COOP_T: queued candidate triangles that trigger a cooperative test round
     bool coop = true;               // FH_COOP=0: per-lane triangle loop
     bool stream = true;             // FH_STREAM=0: one fixed batch per wave; FH_STREAM=1: streaming whatever the size of the tree
@@ -129,10 +131,12 @@ struct fh_ctx {
     uint32_t stream_wgs_per_cu = 0; // FH_STREAM_WGS: workgroups per CU of the streaming kernels (0 = the kernels' LDS budget decides)
     uint32_t stream_grid = 0;       // FH_STREAM_GRID: blocks (0 = n_cus * workgroups per CU)
     uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill
+    uint32_t stream_min_rays = 64;  // FH_STREAM_MIN_RAYS: queue entries per wave below which workgroups of a streaming launch stay out (render.hip: stream_block_idle); 0 = all take part
+    bool sort_small = false;        // FH_SORT_SMALL=1: cell-order the bounce queues of trees the fixed-batch kernels trace as well
     uint32_t stream_chunk = 64;     // FH_STREAM_CHUNK: queue entries a wave takes per global atomic (setting it also switches the adaptive maximum off)
     bool stream_chunk_fixed = false;
     uint32_t tail_depth = 0;        // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail
-    uint32_t tail_paths = 65536;    // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail
+    uint32_t tail_paths = 0;        // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail; 0 = 65536, 131072 for passes of at most 4 Mi paths on trees the streaming kernels trace
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
     bool debug_tail = false;        // FH_DEBUG_TAIL
     bool force_alpha = false;       // FH_FORCE_ALPHA=1 (timing experiments): the kernels with the any-hit path compiled in, whatever the scene

@@ -160,7 +160,20 @@ struct LayersDev {
 };
 
 // traversal statistics (only written by the instrumented kernel variants)
-struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; unsigned long long* rays; unsigned long long* wave_nodes; unsigned long long* wave_tris; unsigned long long* hist; };  // hist: 8 buckets of node steps per ray (<=8, <=16, ... <=512, more)
+struct TraceCounters { unsigned long long* nodes; unsigned long long* tris; unsigned long long* rays; unsigned long long* wave_nodes; unsigned long long* wave_tris; unsigned long long* hist;  // hist: 8 buckets of node steps per ray (<=8, <=16, ... <=512, more)
+                       unsigned long long* clk; };  // FH_FLAG_TIME_KERNELS, streaming kernels: summed shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of their waves, else null
+
+// clock the chip holds while a kernel runs (MI355X_MICROARCH.md, DVFS give-back item 6): every wave stamps both counters at its start and its end
+struct ClockStamp {
+  unsigned long long t0, r0;
+  FH_D ClockStamp() : t0(__builtin_amdgcn_s_memtime()), r0(__builtin_amdgcn_s_memrealtime()) {}
+  FH_D void commit(unsigned long long* clk) const
+  {
+    if (!clk) return;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (__lane_id() == 0u) { atomicAdd(clk, t1 - t0); atomicAdd(clk + 1, r1 - r0); }
+  }
+};
 
 // ---- wave-aggregated queue append: one atomic per wave (ballot + popcount prefix)
 // same append, storing a 16-bit key at the same position of a parallel array

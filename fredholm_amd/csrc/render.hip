@@ -246,6 +246,14 @@ FH_D uint32_t stream_chunk_for(uint32_t count, uint32_t chunk)
   return c < lo ? lo : (c > hi ? hi : c);
 }
 
+// Small launches (the reference's callers render 1 or 16 samples per call, controller.cpp:224, rtcamp8.cpp:183-189).  The grid of a streaming launch is every
+// resident wave slot of the chip; with a short queue every one of those waves draws one chunk and runs it at a fraction of its lanes, six to a SIMD, all
+// competing for the SIMD's issue slots: the launch then takes (steps of its longest ray) x (six mostly empty waves' node tests) -- 0.34 ms for the 330 k
+// camera rays of a 1-spp 1080p frame of the 1 M-triangle scene, which at the kernel's throughput are 0.07 ms of work.  So only as many workgroups take part
+// as the queue can give `min_rays` entries per wave: the others leave at once, the SIMDs hold one or two waves whose steps are as short as memory latency lets them
+// be, and in-wave refill keeps their lanes busy.  Big launches are untouched (every workgroup takes part from 6144 x min_rays entries on).
+FH_D bool stream_block_idle(uint32_t count, uint32_t min_rays) { return blockIdx.x != 0u && (unsigned long long)blockIdx.x * (kBlock / 64u) * min_rays >= count; }
+
 template <bool COUNT>
 struct ClosestStream {
   const PoolDev& pool;
@@ -276,16 +284,19 @@ struct ClosestStream {
 };
 
 template <bool COUNT, bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk)
+__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays)
 {
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
-  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_RAD];
+  if (stream_block_idle(count, min_rays)) return;
+  const ClockStamp stamp;
+  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, stream_chunk_for(count, chunk)), tc.hist);
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // the traversal stack of every lane: [entry][thread], as many entries as the BVH has levels
   traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc);
+  stamp.commit(tc.clk);
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
@@ -712,6 +723,8 @@ __global__ void __launch_bounds__(kSortBlock) k_cell_scatter(const uint32_t* cou
 template <uint32_t LOBES>
 __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : FH_SHADE_BLOCKS)) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
 {
+  // (the grid is sized for every path of the pass; the blocks beyond this class's queue leave before they stage anything)
+  if (blockIdx.x * blockDim.x >= pool.counters[depth * kCounterStride + CNT_CLS + cls]) return;
   __shared__ SobolRows<4> rows;
   // the shade kernels run one wave per SIMD (512 registers per lane), so nothing hides a dependent global load: the small tables every
   // hit reads -- the two albedo LUTs and, when there are few of them, the material records -- are staged in LDS once per workgroup
@@ -964,17 +977,20 @@ struct SecondaryStream {
 };
 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
-__global__ void __launch_bounds__(kBlock, COUNT ? 1 : ((LIGHTS || ALPHA) ? FH_SECONDARY_BLOCKS_HEAVY : 6)) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk)
+__global__ void __launch_bounds__(kBlock, COUNT ? 1 : ((LIGHTS || ALPHA) ? FH_SECONDARY_BLOCKS_HEAVY : 6)) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
-  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
+  if (stream_block_idle(count, min_rays)) return;
+  const ClockStamp stamp;
+  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)), tc.hist);
   traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc);
   pol.finish();
+  stamp.commit(tc.clk);
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
     atomicAdd(tc.tris, (unsigned long long)nt);
@@ -992,13 +1008,23 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : ((LIGHTS || ALPHA) ? FH_SE
 // (trace -> shade -> secondary rays -> Russian roulette), so slow rays of different paths overlap
 // instead of adding up.  Same device functions, same per-path operation order as the wavefront
 // kernels, hence the same bits.
-__global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth)
+__global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth, uint32_t coop_flush)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // traversal stack of every lane ([entry][thread], as in the streaming kernels): a private array lands in scratch
-  // one ray through the scene, per lane (the wide tree with its stack in LDS; tiny scenes: the binary tree)
-  auto trace = [&](auto any_hit, f3 o, f3 d, float tmax, HitRec& h) -> bool {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_coop[(kBlock / 64) * kCoopLdsBytesPerWave];
+  const CoopLds cl = coop_lds(lds_coop, threadIdx.x >> 6);
+  // One ray per lane through the scene, called by all 64 lanes of a wave together (lanes without a ray pass valid = false).  The wide tree is walked with
+  // wave-cooperative triangle tests (coop_flush != 0; fh_trace.h: traverse_bvh8_coop): in a per-lane loop nearly every step of a wave ran one to three triangle tests
+  // for a handful of lanes, and a wave that has its SIMD to itself issues an instruction every five cycles however few lanes want it -- the tail of a 1-spp
+  // 1080p frame of the 1 M-triangle scene took 1.46 of the frame's 3.0 ms.  Tiny scenes (binary tree) and FH_COOP=0 keep the per-lane loops.
+  auto trace = [&](auto any_hit, bool valid, f3 o, f3 d, float tmax, HitRec& h) -> bool {
     constexpr bool ANY = decltype(any_hit)::value;
     uint32_t a = 0, b = 0;
+    if (sc.use_bvh8 && coop_flush) {
+      if (sc.has_alpha) return traverse_bvh8_coop<ANY, false, true, true>(sc.bvh8, valid, o, d, tmax, h, a, b, nullptr, cl, coop_flush, lds_stack, (int)sc.bvh8.depth, &sc);
+      return traverse_bvh8_coop<ANY, false, true, false>(sc.bvh8, valid, o, d, tmax, h, a, b, nullptr, cl, coop_flush, lds_stack, (int)sc.bvh8.depth, &sc);
+    }
+    if (!valid) return false;
     if (!sc.use_bvh8) return traverse<ANY, false>(sc, o, d, tmax, h, a, b);
     if (sc.has_alpha) return traverse_bvh8<ANY, false, true, true>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc);
     return traverse_bvh8<ANY, false, true, false>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc);
@@ -1021,11 +1047,11 @@ __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolD
   const uint32_t* q = pool.q_rad[first_depth & 1u];
   const bool has_lights = sc.n_lights > 0;
   const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // (block-uniform bound: the bounce loop holds workgroup barriers)
     const uint32_t i = base + threadIdx.x;
     bool alive = i < count;
     uint32_t p = 0, image_idx = 0, n_spp = 0;
-    f3 ro = mk3(0.0f), rd = mk3(0.0f), T = mk3(0.0f), L = mk3(0.0f);
+    f3 ro = mk3(0.0f), rd = mk3(0.0f, 0.0f, 1.0f), T = mk3(0.0f), L = mk3(0.0f);
     if (alive) {
       p = q[i];
       const float4 o = pool.ray_o[p];
@@ -1037,32 +1063,37 @@ __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolD
       bs.set(fr, sc.n_lights, depth);
       __syncthreads();  // rows of the previous bounce are no longer read
       bs.load_rows(rows, fr.sobol_bytes);
+      if (__ballot(alive) == 0ull) continue;  // (wave-uniform; the barriers above are still met)
+      HitRec h;
+      const bool hit = trace(std::false_type{}, alive, ro, rd, 1e9f, h);
+      ShadeOut o;
       if (alive) {
-        HitRec h;
-        const bool hit = trace(std::false_type{}, ro, rd, 1e9f, h);
-        if (!hit) {
-          alive = false;  // pt.cu:504-523 with firsthit == false: nothing added
+        if (!hit) alive = false;  // pt.cu:504-523 with firsthit == false: nothing added
+        else shade_hit<L_ALL>(sc, fr, rows, bs, depth, make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)), rd, T, L, image_idx, n_spp, o);
+      }
+      // secondary rays in the reference's order (one call per slot: the slot index has to be a constant for the rays to stay in registers)
+      auto secondary = [&](auto slot_c) {
+        constexpr uint32_t slot = decltype(slot_c)::value;
+        if (slot == SEC_DIR && !fr.has_dir) return;
+        if (slot == SEC_AREA && !has_lights) return;
+        const bool valid = alive && o.sec[slot].active;
+        if (__ballot(valid) == 0ull) return;
+        HitRec sh;
+        if (slot == SEC_LIGHT && has_lights) {
+          const bool lhit = trace(std::false_type{}, valid, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh);
+          if (valid) L += resolve_light_ray(sc, fr, o.lp_T, o.lp_cos, o.lp_f, o.lp_pdf, o.sec[slot].o, o.sec[slot].d, lhit, sh);
         } else {
-          ShadeOut o;
-          shade_hit<L_ALL>(sc, fr, rows, bs, depth, make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)), rd, T, L, image_idx, n_spp, o);
-          // secondary rays in the reference's order
-#pragma unroll
-          for (uint32_t slot = SEC_DIR; slot <= SEC_LIGHT; ++slot) {
-            if (slot == SEC_DIR && !fr.has_dir) continue;
-            if (slot == SEC_AREA && !has_lights) continue;
-            if (!o.sec[slot].active) continue;
-            HitRec sh;
-            if (slot == SEC_LIGHT && has_lights) {
-              const bool lhit = trace(std::false_type{}, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh);
-              L += resolve_light_ray(sc, fr, o.lp_T, o.lp_cos, o.lp_f, o.lp_pdf, o.sec[slot].o, o.sec[slot].d, lhit, sh);
-            } else {
-              const bool occluded = trace(std::true_type{}, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh);
-              if (!occluded) L += o.sec[slot].c;
-            }
-          }
-          if (o.cont) { ro = o.next_o; rd = o.next_d; T = o.T; }
-          else alive = false;
+          const bool occluded = trace(std::true_type{}, valid, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh);
+          if (valid && !occluded) L += o.sec[slot].c;
         }
+      };
+      secondary(std::integral_constant<uint32_t, SEC_DIR>{});
+      secondary(std::integral_constant<uint32_t, SEC_SKY>{});
+      secondary(std::integral_constant<uint32_t, SEC_AREA>{});
+      secondary(std::integral_constant<uint32_t, SEC_LIGHT>{});
+      if (alive) {
+        if (o.cont) { ro = o.next_o; rd = o.next_d; T = o.T; }
+        else alive = false;
       }
     }
     if (i < count) pool.rad[p] = mk4(L, 0.0f);
@@ -1317,30 +1348,38 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
   return FH_OK;
 }
 
-// Dynamic LDS beyond the default limit has to be announced per kernel (hipFuncAttributeMaxDynamicSharedMemorySize).  Only trees
-// deeper than 24 levels get there (24 x 2 KB + 14 KB static = 62 KB); done once per BVH depth, for every kernel that keeps its stack in LDS.
+// Dynamic LDS beyond the default limit has to be announced per kernel (hipFuncAttributeMaxDynamicSharedMemorySize).  Every kernel that keeps its stack in LDS
+// is asked for its own static LDS (the fused tail carries 40 KB of tables next to the 14 KB of cooperative-test records the others have) and told the stack size when
+// static + stack pass the default 64 KB; the largest static size is what fh_render checks against the CU's LDS.  Done once per BVH depth.
 int configure_traversal_lds(fh_ctx* ctx, uint32_t stack_bytes)
 {
-  if (stack_bytes + kCoopLdsBytesPerBlock > 64u * 1024u) {
-    hipError_t err = hipSuccess;
-    auto set = [&](const void* fn) { const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stack_bytes); if (e != hipSuccess) err = e; };
-    for (int c = 0; c < 2; ++c)
-      for (int a = 0; a < 2; ++a)
-        with_bool(c != 0, [&](auto C) { with_bool(a != 0, [&](auto A) {
-          set((const void*)k_trace_closest_stream<decltype(C)::value, decltype(A)::value>);
-          for (int l = 0; l < 2; ++l)
-            with_bool(l != 0, [&](auto Li) {
-              set((const void*)k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
-              set((const void*)k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
-              set((const void*)k_trace_closest_coop<decltype(C)::value, decltype(A)::value>);
-              set((const void*)k_tail);
-              set((const void*)k_trace_secondary_static<decltype(C)::value, true, decltype(Li)::value, decltype(A)::value>);
-              set((const void*)k_trace_secondary_static<decltype(C)::value, false, decltype(Li)::value, decltype(A)::value>);
-            });
-        }); });
-    if (err != hipSuccess) return fail(ctx, FH_E_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(err));
-  }
+  hipError_t err = hipSuccess;
+  uint32_t max_static = kCoopLdsBytesPerBlock;
+  auto set = [&](const void* fn) {
+    hipFuncAttributes at{};
+    if (hipFuncGetAttributes(&at, fn) == hipSuccess && (uint32_t)at.sharedSizeBytes > max_static) max_static = (uint32_t)at.sharedSizeBytes;
+    if ((uint32_t)at.sharedSizeBytes + stack_bytes > 64u * 1024u) {
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stack_bytes);
+      if (e != hipSuccess) err = e;
+    }
+  };
+  for (int c = 0; c < 2; ++c)
+    for (int a = 0; a < 2; ++a)
+      with_bool(c != 0, [&](auto C) { with_bool(a != 0, [&](auto A) {
+        set((const void*)k_trace_closest_stream<decltype(C)::value, decltype(A)::value>);
+        set((const void*)k_trace_closest_coop<decltype(C)::value, decltype(A)::value>);
+        for (int l = 0; l < 2; ++l)
+          with_bool(l != 0, [&](auto Li) {
+            set((const void*)k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
+            set((const void*)k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
+            set((const void*)k_trace_secondary_static<decltype(C)::value, true, decltype(Li)::value, decltype(A)::value>);
+            set((const void*)k_trace_secondary_static<decltype(C)::value, false, decltype(Li)::value, decltype(A)::value>);
+          });
+      }); });
+  set((const void*)k_tail);
+  if (err != hipSuccess) return fail(ctx, FH_E_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(err));
   ctx->lds_configured_bytes = stack_bytes;
+  ctx->lds_static_max = max_static;
   return FH_OK;
 }
 
@@ -1395,8 +1434,11 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
 
   const SceneDev sc = scene_dev(ctx);
   const bool count = (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) != 0;
-  TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2, ctx->d_trace_counters + 6, ctx->d_trace_counters + 7, ctx->d_trace_counters + 10};
-  TraceCounters tc_shadow{ctx->d_trace_counters + 3, ctx->d_trace_counters + 4, ctx->d_trace_counters + 5, ctx->d_trace_counters + 8, ctx->d_trace_counters + 9, ctx->d_trace_counters + 18};
+  const bool clocks = (ctx->flags & FH_FLAG_TIME_KERNELS) != 0;
+  TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2, ctx->d_trace_counters + 6, ctx->d_trace_counters + 7, ctx->d_trace_counters + 10,
+                           clocks ? ctx->d_trace_counters + 27 : nullptr};
+  TraceCounters tc_shadow{ctx->d_trace_counters + 3, ctx->d_trace_counters + 4, ctx->d_trace_counters + 5, ctx->d_trace_counters + 8, ctx->d_trace_counters + 9, ctx->d_trace_counters + 18,
+                          clocks ? ctx->d_trace_counters + 29 : nullptr};
 
   // FH_FLAG_REFERENCE_FIRSTHIT with more than one sample per launch: per-pixel state carried through the launch, passes run one after the other
   const bool quirk = (ctx->flags & FH_FLAG_REFERENCE_FIRSTHIT) != 0 && n_samples > 1;
@@ -1428,13 +1470,13 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const bool stream = coop && tun.stream && (tun.stream_forced || ctx->bvh8_n_nodes >= 4096u);
   // the traversal stack of every lane lives in LDS, one entry per level of the BVH (bvh_build.hip records the depth): no overflow path
   const uint32_t stack_bytes = lds_stack_bytes(ctx->bvh8_depth < 2u ? 2u : ctx->bvh8_depth);
-  if (sc.use_bvh8 && stack_bytes + kCoopLdsBytesPerBlock > 160u * 1024u) return fail(ctx, FH_E_UNSUPPORTED, "fh_render: BVH too deep for the LDS traversal stack");
   if (sc.use_bvh8 && ctx->lds_configured_bytes != stack_bytes) {  // kernels that may need more than the default 64 KB of LDS are told so once per BVH depth
     const int rc = configure_traversal_lds(ctx, stack_bytes);
     if (rc) return rc;
   }
-  // all workgroups of a streaming launch are resident: as many per CU as its 160 KB of LDS hold (at most 6: the kernels' register budget)
-  uint32_t wgs_per_cu = (160u * 1024u) / (stack_bytes + kCoopLdsBytesPerBlock);
+  if (sc.use_bvh8 && stack_bytes + ctx->lds_static_max > tun.lds_per_block) return fail(ctx, FH_E_UNSUPPORTED, "fh_render: BVH too deep for the LDS traversal stack");
+  // all workgroups of a streaming launch are resident: as many per CU as its LDS (160 KB on gfx950) holds (at most 6: the kernels' register budget)
+  uint32_t wgs_per_cu = tun.lds_per_cu / (stack_bytes + kCoopLdsBytesPerBlock);
   wgs_per_cu = wgs_per_cu > 6u ? 6u : (wgs_per_cu < 1u ? 1u : wgs_per_cu);
   if (stream) {  // what the runtime says really fits (LDS granularity, registers of the variant in use): a grid above it would leave blocks queued behind the resident ones
     const uint32_t key = stack_bytes | (count ? 1u : 0u) | (sc.has_alpha ? 2u : 0u) | (sc.n_lights > 0 ? 4u : 0u);
@@ -1463,7 +1505,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const uint32_t chunk_max = tun.stream_chunk_fixed ? tun.stream_chunk : (ctx->bvh8_n_nodes < 512u ? 256u : (ctx->bvh8_n_nodes < 4096u ? 128u : tun.stream_chunk));
   const uint32_t stream_refill = tun.stream_refill, stream_chunk = (tun.stream_chunk & 0xffffu) | ((chunk_max > tun.stream_chunk ? chunk_max : 0u) << 16);
   const uint32_t env_tail_depth = tun.tail_depth;
-  const bool sort_queues = tun.sort_queues;
+  // cell-ordered queues pay where rays of one cell share the nodes they fetch; a tree the fixed-batch kernels trace (under 4096 nodes) sits in the caches whatever
+  // the order, and there the six sort launches per bounce are what a small frame waits for (Cornell box, 1 spp: 0.33 of 2.15 ms)
+  const bool sort_queues = tun.sort_queues && (stream || tun.sort_small);
 
   for (uint32_t done = 0; done < n_samples; done += batch) {
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
@@ -1497,7 +1541,10 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     // bounces run as bounce-synchronous wavefront kernels; the survivors are finished by k_tail.  Adaptive mode picks the
     // first depth at which an earlier pass had at most kTailPaths survivors (counts come from an asynchronous snapshot of
     // the device counters: no host/device synchronisation)
-    const uint32_t kTailPaths = tun.tail_paths;
+    // (a wavefront bounce of a big tree costs two streaming launches, each as long as its longest ray whatever the number of rays: 0.5 ms on the 1 M-triangle scene
+    // against 0.25 ms for a bounce inside the fused tail, so in a small pass the tail takes over earlier there -- 1-spp 1080p frame 3.02 -> 2.73 ms; in a big pass the
+    // tail runs next to the streaming launches of the passes in flight, one wave per SIMD against their six, and twice the paths cost configs[2] 1.3 %)
+    const uint32_t kTailPaths = tun.tail_paths ? tun.tail_paths : ((stream && n_paths <= (1u << 22)) ? 131072u : 65536u);
     for (int k = 0; k < 3; ++k) {
       if (!(ctx->counters_in_flight[k] && hipEventQuery(ctx->ev_counters[k]) == hipSuccess)) continue;
       ctx->counters_in_flight[k] = false;
@@ -1533,7 +1580,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), stack_bytes, st, sc, pd, depth, tc_closest,
-                               coop_flush, stream_refill, stream_chunk);
+                               coop_flush, stream_refill, stream_chunk, tun.stream_min_rays);
           }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
@@ -1578,7 +1625,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stack_bytes, st, sc,
-                               fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk);
+                               fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk, tun.stream_min_rays);
           }); }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
@@ -1596,7 +1643,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     }
     if (wave_depth < max_depth) {
       Span sp(ctx, st, 3);
-      hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), sc.use_bvh8 ? stack_bytes : 0u, st, sc, fr, pd, wave_depth);
+      hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), sc.use_bvh8 ? stack_bytes : 0u, st, sc, fr, pd, wave_depth, coop ? coop_flush : 0u);
       ctx->stats.n_tail_launches++;
     }
     if (prev != slot && ctx->acc_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[prev], 0));

@@ -52,3 +52,52 @@ def assemble(width, height, shards, tile_w=32, tile_h=32):
         own = tile_ownership(width, height, r, world, tile_w, tile_h)
         img[own] = np.asarray(shards[r])[: own.size]
     return img.reshape(height, width, -1)
+
+
+def preflight(dist, device, packed_rows, fpp=4):
+    """Fail loudly, before any frame is rendered, on what would otherwise hang or corrupt the RCCL gather of bench.py: a rendezvous the environment
+    does not describe, a process group bound to another device than the renderer's, ranks that disagree on the shard size, a collective that does
+    not move the bytes it should.  `dist` is an initialised torch.distributed, `device` this rank's torch device, `packed_rows` the rows of the
+    padded packed shard.  Returns the seconds one gather of that size took."""
+    import os
+    import time
+
+    import torch
+
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in os.environ:
+            raise RuntimeError(f"distributed launch without {k} in the environment (start with python -m torch.distributed.run --master-addr 127.0.0.1 --master-port P ...)")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if world != int(os.environ["WORLD_SIZE"]) or rank != int(os.environ["RANK"]):
+        raise RuntimeError(f"process group says rank {rank} of {world}, environment says {os.environ['RANK']} of {os.environ['WORLD_SIZE']}")
+    on_gpu = dist.get_backend() == "nccl"
+    if on_gpu:
+        if device.type != "cuda" or torch.cuda.current_device() != device.index:
+            raise RuntimeError(f"rank {rank}: RCCL needs the current device to be the renderer's ({device}), it is cuda:{torch.cuda.current_device()}")
+        if torch.cuda.device_count() < world and os.environ.get("FH_ALLOW_SHARED_GPU") != "1":
+            raise RuntimeError(f"{world} RCCL ranks on {torch.cuda.device_count()} visible GPU(s): one process per GPU (FH_BENCH_BACKEND=gloo shares a GPU for functional tests)")
+    dev = device if on_gpu else torch.device("cpu")
+    # every rank must bring the same shard shape: a gather of unequal tensors hangs or truncates
+    mine = torch.tensor([int(packed_rows), int(fpp)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    got = [tuple(int(v) for v in t.tolist()) for t in sizes]
+    if len(set(got)) != 1:
+        raise RuntimeError(f"packed shard shapes differ across ranks: {got} (every rank pads to distributed.max_owned)")
+    # one gather of the real size with a pattern only the right rank can have produced
+    payload = torch.full((int(packed_rows), int(fpp)), float(rank + 1), dtype=torch.float32, device=dev)
+    outs = [torch.zeros_like(payload) for _ in range(world)] if rank == 0 else None
+    if on_gpu:
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.gather(payload, outs, dst=0)
+    if on_gpu:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        for k in range(world):
+            if not bool((outs[k] == float(k + 1)).all().item()):
+                raise RuntimeError(f"gather returned wrong data for rank {k}")
+    dist.barrier()
+    return dt

@@ -119,6 +119,9 @@ typedef struct fh_stats {
   uint64_t bvh_depth;   /* levels of the wide BVH = entries of the LDS traversal stack */
   double post_ms;       /* summed HIP-event time of the fh_post_process chains (threshold + blur + tone map) */
   uint64_t n_post_launches;
+  /* FH_FLAG_TIME_KERNELS, streaming traversal kernels: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) summed over their waves;
+   * the clock the chip held while they ran = cycles / ticks x 100 MHz */
+  uint64_t clk_cycles_closest, clk_ticks_closest, clk_cycles_shadow, clk_ticks_shadow;
 } fh_stats;
 
 #define FH_FLAG_TIME_KERNELS 1u    /* bracket traversal/shade launches with HIP events (fh_stats *_ms) */

@@ -158,6 +158,63 @@ def test_world_size_2_gather_over_gloo(tmp_path):
     assert "GLOO_OK" in outs[0]
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_gather_probe_runs_as_two_ranks_over_gloo():
+    """tools/rccl_gather_probe.py -- the collective leg of bench.py --gpus N on its own (process group, distributed.preflight, timed gathers of the packed shard) --
+    started by torch.distributed.run as the driver starts bench.py, with gloo standing in for RCCL"""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tools", "rccl_gather_probe.py"), "--backend", "gloo", "--width", "200", "--height", "72"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert run.returncode == 0, run.stderr[-2000:]
+    out = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["world"] == 2 and out["data_ok"] and out["bytes_per_rank"] == 16 * D.max_owned(200, 72, 2)
+
+
+_PREFLIGHT_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from fredholm_amd import distributed as D
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+try:
+    D.preflight(dist, torch.device("cpu"), 100 + (rank if sys.argv[2] == "unequal" else 0))
+    print("PREFLIGHT_PASSED")
+except RuntimeError as e:
+    print("PREFLIGHT_REFUSED:", e)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("mode", ["equal", "unequal"])
+def test_preflight_refuses_unequal_shards(tmp_path, mode):
+    """distributed.preflight (called by bench.py before the first frame when N > 1): ranks that would bring shards of different shapes to the gather are told so
+    instead of hanging in the collective"""
+    script = tmp_path / "worker.py"
+    script.write_text(_PREFLIGHT_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script), ROOT, mode]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert run.returncode == 0, run.stderr[-2000:]
+    if mode == "equal":
+        assert run.stdout.count("PREFLIGHT_PASSED") == 2
+    else:
+        assert run.stdout.count("PREFLIGHT_REFUSED") == 2 and "shapes differ" in run.stdout
+
+
+def test_preflight_names_a_missing_rendezvous_variable(monkeypatch):
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "1"); monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        D.preflight(None, None, 1)
+
+
 # ---------------------------------------------------------------- wire formats and the C++ facade
 def test_obj_mtl_round_trip(tmp_path):
     c = scenes.cornell_box()

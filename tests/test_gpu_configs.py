@@ -225,6 +225,39 @@ def test_two_rank_bench_step_gathers_the_unsharded_frame(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and "gather" in out["config"]["gather"]
 
 
+def test_rccl_leg_on_two_gpus(tmp_path):
+    """The RCCL leg itself -- dist.init_process_group("nccl", device_id=...) and dist.gather of device tensors, bench.py's N > 1 path as the driver's multi-GPU run
+    takes it -- needs one GPU per rank: runs wherever two or more are visible (the one-GPU boxes of the development pool skip it; the two-rank test above covers
+    everything but the transport there).  First the collective alone (tools/rccl_gather_probe.py), then the whole bench step with --check-frame."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL leg needs two visible GPUs (one process per GPU)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("FH_BENCH_BACKEND", None)
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    run = subprocess.run(launch + ["--master-port", str(port()), os.path.join(root, "tools", "rccl_gather_probe.py")], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-3000:]
+    probe = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert probe["backend"] == "nccl" and probe["world"] == 2 and probe["data_ok"]
+    run = subprocess.run(launch + ["--master-port", str(port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "4", "--check-frame", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert "frame gathered from 2 ranks bit-identical to the unsharded render: True" in run.stderr
+    out = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["gather"].startswith("RCCL")
+
+
 def test_gl_interop_entry_points_fail_cleanly_without_an_opengl_context():
     """fh_gl_register_buffer (cwl::CUDAGLBuffer's backend) needs a current OpenGL context; on a headless box it must return an error, not take the
     process down.  Probed in a child process so that a misbehaving GL stack cannot end the test run."""

@@ -1,0 +1,42 @@
+"""after tools/profile_round3.sh <tag> <config> [pmc spp]: copy the summaries into profiles/ and write profiles/<tag>_traffic_config<N>.json from the PMC summary -- the
+counters of the configuration's dominant kernel (what bench.py quotes as roofline.traffic / roofline.valu) and the fabric-side bytes of a whole frame per sample per pixel-frame
+(whole_frame.fabric_*).  python tools/collect_profile3.py <tag> <config> [pmc spp]"""
+import json, re, shutil, sys
+tag, cfg = sys.argv[1], int(sys.argv[2])
+pspp = int(sys.argv[3]) if len(sys.argv) > 3 else 384
+for f in ("bench.json", "kernel_stats.csv", "serial_kernel_stats.csv", "pmc_summary.txt"):
+    shutil.copy(f"gpurun_out/{tag}_{f}", f"profiles/{tag}_{f}")
+b = json.load(open(f"profiles/{tag}_bench.json"))
+dom = b["roofline"]["kernel"]
+s = open(f"gpurun_out/{tag}_pmc_summary.txt").read()
+blocks = re.split(r"\n(?=k_)", s)
+def parse(blk):
+    head = blk.splitlines()[0]
+    d = {"name": head.split("  dispatches=")[0], "dispatches": int(re.search(r"dispatches=(\d+)", head).group(1))}
+    for m in re.finditer(r"^\s+(\w+)\s+mean\s+([\d.]+)\s+total\s+(\d+)", blk, re.M):
+        d[m.group(1)] = (float(m.group(2)), float(m.group(3)))
+    return d
+ks = [parse(x) for x in blocks if x.startswith("k_")]
+# the dominant kernel's un-instrumented instantiation with the most dispatches
+cand = [k for k in ks if k["name"].startswith(dom) and not k["name"].startswith(dom + "<true")]
+k = max(cand, key=lambda k: k["dispatches"] * k.get("SQ_INSTS_VALU", (0, 0))[0])
+g = lambda n: k[n][0]
+renders = 4  # --warmup 1 --steps 1 + the serial step + the counting replay
+frame = sum((2 * x.get("FETCH_SIZE", (0, 0))[1] + x.get("WRITE_SIZE", (0, 0))[1]) * 1024 for x in ks)
+d = {"kernel": k["name"], "config": cfg,
+     "source": f"profiles/{tag}_pmc_summary.txt (tools/profile_round3.sh {tag} {cfg} {pspp}: separate rocprofv3 --pmc passes -- SQ group a, SQ group b, FETCH_SIZE, WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- of "
+               f"bench.py --config {cfg} --steps 1 --warmup 1 --spp {pspp} --no-cpu-baseline --no-extras; mean over the {k['dispatches']} dispatches of the kernel)",
+     "FETCH_SIZE_KB_per_launch": g("FETCH_SIZE"), "WRITE_SIZE_KB_per_launch": g("WRITE_SIZE"),
+     "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; KB = 1024 B.  The guide calibrates the doubling on wide streaming reads only; for scattered 16-B loads it is an upper bound.",
+     "traffic_bytes_per_launch": int((2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024),
+     "tcc_hit_rate": round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4),
+     "valu_insts_per_launch": int(g("SQ_INSTS_VALU")), "vmem_rd_insts_per_launch": int(g("SQ_INSTS_VMEM_RD")), "vmem_wr_insts_per_launch": int(g("SQ_INSTS_VMEM_WR")),
+     "lds_insts_per_launch": int(g("SQ_INSTS_LDS")), "valu_lane_utilisation": round(g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_INSTS_VALU")), 4),
+     "wait_any_frac_of_wave_cycles": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4), "waves_per_launch": int(g("SQ_WAVES")),
+     "grbm_gui_active_per_launch": g("GRBM_GUI_ACTIVE"),
+     "frame_traffic_bytes_per_spp": frame / (renders * pspp),
+     "frame_note": f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every kernel of the run / ({renders} renders x {pspp} spp): fabric-side bytes one sample per pixel of the whole frame costs",
+     "note": "fabric-side bytes (L2 misses; Infinity-Cache hits are counted)."}
+json.dump(d, open(f"profiles/{tag}_traffic_config{cfg}.json", "w"), indent=1)
+print(b["value"], b["step_ms"], {x: b["roofline"][x] for x in ("bound", "kernel", "achieved", "peak", "frac") if x in b["roofline"]}, b["kernel_ms_per_step_alone"], b["rates"], b.get("cpu_baseline", {}).get("value"))
+print({x: d[x] for x in ("kernel", "traffic_bytes_per_launch", "tcc_hit_rate", "valu_insts_per_launch", "valu_lane_utilisation", "wait_any_frac_of_wave_cycles", "waves_per_launch", "frame_traffic_bytes_per_spp")})

@@ -151,7 +151,7 @@ static void verify_sdwa()
   CHECK(hipFree(d));
 }
 
-struct Result { double ms, clock_ghz, instr_per_cycle_simd, ginstr_s_simd, cycles_per_instr_wave; };
+struct Result { double ms, clock_ghz, per_cycle_simd, g_per_s_simd, cycles_one_wave; };
 
 template <int KIND>
 Result run_point(int n_cus, int wps, double target_ms, double instr_per_iter, float* sink, Stamp* stamps)
@@ -181,9 +181,12 @@ Result run_point(int n_cus, int wps, double target_ms, double instr_per_iter, fl
   Result r;
   r.ms = ms;
   r.clock_ghz = clk[clk.size() / 2];
-  r.cycles_per_instr_wave = cyc[cyc.size() / 2] / instr;
-  r.instr_per_cycle_simd = wps * instr / cyc[cyc.size() / 2];
-  r.ginstr_s_simd = wps * instr / (ms * 1e-3) / 1e9;
+  // The SIMD serves its oldest wave first, so the waves of a SIMD do not share its issue slots evenly and finish one after the other: a wave's own elapsed
+  // cycles say little about the SIMD's rate (their median is about half the launch at eight waves).  The rate is what the whole launch delivered: all waves'
+  // instructions over the launch's wall time, and per cycle with the clock the waves measured.
+  r.g_per_s_simd = wps * instr / (ms * 1e-3) / 1e9;
+  r.per_cycle_simd = r.g_per_s_simd / r.clock_ghz;
+  r.cycles_one_wave = cyc[cyc.size() / 2] / instr;
   CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
   return r;
 }
@@ -193,8 +196,10 @@ void run_kind(int n_cus, double target_ms, float* sink, Stamp* stamps, const std
 {
   for (int wps : occ) {
     const Result r = run_point<KIND>(n_cus, wps, target_ms, instr_per_iter, sink, stamps);
-    printf("%-30s waves/SIMD %d: launch %7.1f ms  clock %.3f GHz  %6.2f cycles per %s (one wave's view)  %.4f %s/cycle/SIMD  %.4f G%s/s/SIMD\n", kNames[KIND], wps, r.ms, r.clock_ghz,
-           r.cycles_per_instr_wave, unit, r.instr_per_cycle_simd, unit, r.ginstr_s_simd, unit);
+    printf("%-34s waves/SIMD %d: launch %6.1f ms  clock %.3f GHz  %.4f G%s/s/SIMD = %.4f %s/cycle/SIMD = %7.2f SIMD cycles per %s", kNames[KIND], wps, r.ms, r.clock_ghz, r.g_per_s_simd, unit,
+           r.per_cycle_simd, unit, 1.0 / r.per_cycle_simd, unit);
+    if (wps == 1) printf("  (one wave alone: %.2f cycles per %s)", r.cycles_one_wave, unit);
+    printf("\n");
     fflush(stdout);
   }
 }
