@@ -328,6 +328,17 @@ using namespace fh;
   if (!(ctx)) return FH_E_INVALID;          \
   if (hipSetDevice((ctx)->device) != hipSuccess) return fh::fail(ctx, FH_E_HIP, "hipSetDevice failed")
 
+namespace fh {
+// render.hip: pool_ensure -- path record 64, radiance 16, identity 8, flags 4, first-hit AOVs 64, a 48-byte place per kind of secondary ray, the pending
+// light ray 32 (emitters only); queues: two radiance + one spare + secondary + its sorted copy 5 x 4, two 16-bit keys, one entry per shading class
+uint64_t pool_bytes_per_path(const fh_ctx* ctx)
+{
+  const uint32_t sec = 2u + (ctx->has_dir ? 1u : 0u) + (ctx->n_lights > 0 ? 1u : 0u);
+  const uint32_t classes = ctx->n_classes < 1u ? 1u : ctx->n_classes;
+  return 64u + 16u + 8u + 4u + 64u + 48u * sec + (ctx->n_lights > 0 ? 32u : 0u) + 20u + 4u + 4u * classes;
+}
+}  // namespace fh
+
 extern "C" {
 
 int fh_ctx_create(int device, fh_ctx** out)
@@ -446,6 +457,13 @@ int fh_set_flags(fh_ctx* ctx, uint32_t flags)
   ctx->flags = flags;
   return FH_OK;
 }
+int fh_get_flags(fh_ctx* ctx, uint32_t* flags)
+{
+  CTX_CHECK(ctx);
+  if (!flags) return fail(ctx, FH_E_INVALID, "fh_get_flags: null argument");
+  *flags = ctx->flags;
+  return FH_OK;
+}
 
 int fh_set_path_pool(fh_ctx* ctx, uint32_t target)
 {
@@ -454,6 +472,7 @@ int fh_set_path_pool(fh_ctx* ctx, uint32_t target)
   (void)hipStreamSynchronize(ctx->stream);
   pool_release(ctx);
   ctx->pool_target = target;
+  ctx->pool_target_by_caller = true;
   return FH_OK;
 }
 
@@ -461,11 +480,7 @@ int fh_path_pool_bytes(fh_ctx* ctx, uint64_t* bytes_per_path, uint32_t* pools)
 {
   CTX_CHECK(ctx);
   if (!bytes_per_path || !pools) return fail(ctx, FH_E_INVALID, "fh_path_pool_bytes: null argument");
-  // render.hip: pool_ensure -- path record 64, radiance 16, identity 8, flags 4, first-hit AOVs 64, a 48-byte place per kind of secondary ray, the pending
-  // light ray 32 (emitters only); queues: two radiance + one spare + secondary + its sorted copy 5 x 4, two 16-bit keys, one entry per shading class
-  const uint32_t sec = 2u + (ctx->has_dir ? 1u : 0u) + (ctx->n_lights > 0 ? 1u : 0u);
-  const uint32_t classes = ctx->n_classes < 1u ? 1u : ctx->n_classes;
-  *bytes_per_path = 64u + 16u + 8u + 4u + 64u + 48u * sec + (ctx->n_lights > 0 ? 32u : 0u) + 20u + 4u + 4u * classes;
+  *bytes_per_path = pool_bytes_per_path(ctx);
   *pools = (uint32_t)ctx->n_slots;
   return FH_OK;
 }

@@ -103,7 +103,10 @@ struct fh_ctx {
   struct PoolShape { bool dir = false, lights = false; uint32_t classes = 0; };  // what the records of a pool have room for (render.hip: pool_ensure)
   PoolShape pool_shape[3];
   std::vector<void*> pool_allocs[3];
-  uint32_t pool_target = 1u << 25;  // 32 Mi path slots (12.5 GB): 16 samples per pixel per pass at 1080p
+  // 32 Mi path slots per pool: 16 samples per pixel per pass at 1080p.  Three pools (one per pass in flight) of 284-436 bytes per path are 27-42 GB when a call brings enough
+  // samples to fill them; unless the caller chose the size (fh_set_path_pool), fh_render keeps all pools together within half of the device memory that is free when the first one is made
+  uint32_t pool_target = 1u << 25;
+  bool pool_target_by_caller = false, pool_target_capped = false;
   uint32_t tail_depth = 0;          // bounces run as wavefront kernels before k_tail finishes the survivors; 0 = adaptive
   uint32_t auto_wave_depth = 2;     // adaptive choice, updated from the per-bounce survivor counts of earlier passes
   uint32_t* h_counters[3] = {nullptr, nullptr, nullptr};  // pinned snapshots of the per-bounce counters of a finished pass
@@ -173,6 +176,7 @@ SceneDev scene_dev(const fh_ctx* ctx);
 int bvh_build_device(fh_ctx* ctx);                 // bvh_build.hip
 int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_render_layers* layers, uint32_t n_samples, uint32_t max_depth, uint32_t seed);  // render.hip
 int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity);   // render.hip
+uint64_t pool_bytes_per_path(const fh_ctx* ctx);            // capi.hip
 void pool_release(fh_ctx* ctx);
 int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int w, int h, const fh_post_params* pp, float* out);  // post.hip
 int denoise_submit(fh_ctx* ctx, int w, int h, const float* beauty, const float* normal, const float* albedo, float* out, int upscale);  // post.hip

@@ -234,7 +234,7 @@ FH_D float byte_scaled(uint32_t w, float two126)
 
 template <int J, bool SDWA>
 FH_D void node8_child(uint32_t& hits, uint32_t nearx, uint32_t farx, uint32_t neary, uint32_t fary, uint32_t nearz, uint32_t farz, float sx, float sy, float sz, float ox, float oy, float oz,
-                      float tmax, float two126)
+                      float fx, float fy, float fz, float tmax, float two126)
 {
   float b0x, b1x, b0y, b1y, b0z, b1z;
   if (SDWA) {
@@ -244,11 +244,11 @@ FH_D void node8_child(uint32_t& hits, uint32_t nearx, uint32_t farx, uint32_t ne
     b0x = (float)((nearx >> (8 * J)) & 0xffu); b1x = (float)((farx >> (8 * J)) & 0xffu); b0y = (float)((neary >> (8 * J)) & 0xffu); b1y = (float)((fary >> (8 * J)) & 0xffu);
     b0z = (float)((nearz >> (8 * J)) & 0xffu); b1z = (float)((farz >> (8 * J)) & 0xffu);
   }
-  const float t0x = fmaf(b0x, sx, ox), t1x = fmaf(b1x, sx, ox);
-  const float t0y = fmaf(b0y, sy, oy), t1y = fmaf(b1y, sy, oy);
-  const float t0z = fmaf(b0z, sz, oz), t1z = fmaf(b1z, sz, oz);
+  const float t0x = fmaf(b0x, sx, ox), t1x = fmaf(b1x, sx, fx);
+  const float t0y = fmaf(b0y, sy, oy), t1y = fmaf(b1y, sy, fy);
+  const float t0z = fmaf(b0z, sz, oz), t1z = fmaf(b1z, sz, fz);
   const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
-  const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));  // no inflation: the child boxes carry the build's absolute padding (2^-16 of the scene's largest coordinate), ~100 x the rounding error of these distances
+  const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));
   // hits = 2 * hits + (tn <= tf): the compare leaves its result in the carry, the add-with-carry shifts it in (one VALU instruction per child
   // instead of a select, a shift and an or)
   asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(tn), "v"(tf) : "vcc");
@@ -267,21 +267,29 @@ FH_D uint32_t node8_test(const Ray8& r, const uint4 n0, const uint4 n1, const ui
   const float kx = fabsf(__uint_as_float((n0.x + (SDWA ? 23u : 0u)) << 23)), ky = fabsf(__uint_as_float((n0.y + (SDWA ? 23u : 0u)) << 23)), kz = fabsf(__uint_as_float((n0.z + (SDWA ? 23u : 0u)) << 23));
   const float sx = kx * r.inv.x, sy = ky * r.inv.y, sz = kz * r.inv.z;
   const float ox = (px - r.o.x) * r.inv.x, oy = (py - r.o.y) * r.inv.y, oz = (pz - r.o.z) * r.inv.z;
+  // The child boxes carry the build's absolute padding (2^-16 of the scene's largest coordinate), ~100 x the rounding error of these distances while the ray
+  // starts within a few hundred scene sizes of the node.  The error of (p - o) * inv grows with |p - o| though (2^-24 of it, per axis), and so does what the
+  // triangle test itself makes of a ray from far away; so the near planes of every axis are moved in and the far planes out by 2^-21 of that axis' own offset:
+  // nothing next to the padding for a ray that starts in or near the scene, and what keeps a thin box from being skipped by a camera far outside it.
+  // Six FMA-class instructions per node, which issue beside the others (profiles/r03_issue_peak.txt).
+  const float kSlack = 4.76837158203125e-7f;
+  const float fx = fmaf(fabsf(ox), kSlack, ox), fy = fmaf(fabsf(oy), kSlack, oy), fz = fmaf(fabsf(oz), kSlack, oz);
+  const float nx = fmaf(fabsf(ox), -kSlack, ox), ny = fmaf(fabsf(oy), -kSlack, oy), nz = fmaf(fabsf(oz), -kSlack, oz);
   const float two126 = 8.507059173023462e37f;
   uint32_t hits = 0;
   {  // slots 7 .. 4, then 3 .. 0: every test shifts the mask left and moves its result in at the bottom
     const uint32_t nearx = r.nx ? n2.w : n1.y, farx = r.nx ? n1.y : n2.w, neary = r.ny ? n3.y : n1.w, fary = r.ny ? n1.w : n3.y, nearz = r.nz ? n3.w : n2.y, farz = r.nz ? n2.y : n3.w;
-    node8_child<3, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
-    node8_child<2, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
-    node8_child<1, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
-    node8_child<0, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
+    node8_child<3, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
+    node8_child<2, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
+    node8_child<1, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
+    node8_child<0, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
   }
   {
     const uint32_t nearx = r.nx ? n2.z : n1.x, farx = r.nx ? n1.x : n2.z, neary = r.ny ? n3.x : n1.z, fary = r.ny ? n1.z : n3.x, nearz = r.nz ? n3.z : n2.x, farz = r.nz ? n2.x : n3.z;
-    node8_child<3, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
-    node8_child<2, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
-    node8_child<1, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
-    node8_child<0, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, ox, oy, oz, tmax, two126);
+    node8_child<3, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
+    node8_child<2, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
+    node8_child<1, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
+    node8_child<0, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
   }
   return hits;
 }

@@ -1389,6 +1389,14 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (ctx->width == 0 || ctx->height == 0 || !ctx->d_sample_count) return fail(ctx, FH_E_INVALID, "fh_render: resolution not set");
   if (max_depth > 64) return fail(ctx, FH_E_INVALID, "fh_render: max_depth > 64 is not supported");
   if (ctx->n_owned == 0 || n_samples == 0) return FH_OK;
+  if (!ctx->pool_target_by_caller && !ctx->pool_target_capped) {  // the default pool size is a wish: all pools together stay within half of what the device has free now
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const unsigned long long cap = (unsigned long long)free_b / 2ull / ((unsigned long long)ctx->n_slots * pool_bytes_per_path(ctx));
+      if (cap < ctx->pool_target) ctx->pool_target = cap > ctx->n_owned ? (uint32_t)cap : ctx->n_owned;
+    }
+    ctx->pool_target_capped = true;
+  }
   uint32_t target = ctx->pool_target > ctx->n_owned ? ctx->pool_target : ctx->n_owned;
   uint32_t batch = target / ctx->n_owned;
   if (batch > n_samples) batch = n_samples;

@@ -89,7 +89,12 @@ class Renderer
 
   // not in the reference: render(n_samples = k) as ONE reference launch of k samples, payload.firsthit quirk included (pt.cu:432-433;
   // rtcamp8 renders 16 per launch, rtcamp8.cpp:183-189), instead of k one-sample launches
-  void set_reference_launch_semantics(bool on) { cwl::check(m_ctx, fh_set_flags(m_ctx, on ? FH_FLAG_REFERENCE_FIRSTHIT : 0u), "fh_set_flags"); }
+  void set_reference_launch_semantics(bool on)
+  {
+    uint32_t flags = 0;  // (only this bit changes: timing / counting / serial-pass flags set through the C ABI stay as they are)
+    cwl::check(m_ctx, fh_get_flags(m_ctx, &flags), "fh_get_flags");
+    cwl::check(m_ctx, fh_set_flags(m_ctx, on ? (flags | FH_FLAG_REFERENCE_FIRSTHIT) : (flags & ~FH_FLAG_REFERENCE_FIRSTHIT)), "fh_set_flags");
+  }
 
  private:
   static fh_camera camera_from(const Mat4& m, const Camera& camera)

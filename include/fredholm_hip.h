@@ -140,8 +140,10 @@ int fh_ctx_create(int device, fh_ctx** out);
 int fh_ctx_destroy(fh_ctx* ctx);
 const char* fh_last_error(fh_ctx* ctx); /* ctx may be NULL for creation errors */
 int fh_set_flags(fh_ctx* ctx, uint32_t flags);
+int fh_get_flags(fh_ctx* ctx, uint32_t* flags); /* (a caller that wants to change one flag reads, edits and sets) */
 /* target number of camera paths in flight per pass (path-pool slots); a pass starts floor(target / owned pixels) >= 1
- * samples per pixel.  Results do not depend on it.  Default 32 Mi paths (12.5 GB of pool). */
+ * samples per pixel.  Results do not depend on it.  Default 32 Mi paths per pool, three pools (one per pass in flight), 284-436 bytes per path; the
+ * default is lowered when the pools would take more than half of the free device memory, a size set here is taken as given. */
 int fh_set_path_pool(fh_ctx* ctx, uint32_t target_paths);
 /* device memory of the path pools with the scene and lights as they are now: bytes per path slot and the number of pools (one per pass in flight);
  * a caller that sizes the pools for a frame (bench.py) multiplies: pools x target_paths x bytes_per_path */

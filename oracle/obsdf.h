@@ -241,17 +241,17 @@ struct Sheen {
     const float c = interp(rough, 0.16801, 0.19823);
     const float d = interp(rough, -1.27393, -1.97760);
     const float e = interp(rough, -4.85967, -4.32054);
-    return a / (1.0f + b * fhe_pow(x, c)) + d * x + e;
+    return a / (1.0f + b * oe::pow(x, c)) + d * x + e;
   }
   float lambda(V3 w) const
   {
     const float c = abs_cos(w);
-    return (c < 0.5f) ? fhe_exp(L(c)) : fhe_exp(2.0f * L(0.5f) - L(1.0f - c));
+    return (c < 0.5f) ? oe::exp(L(c)) : oe::exp(2.0f * L(0.5f) - L(1.0f - c));
   }
   float D(V3 wh) const
   {
     const float s = fabsf(sin_t(wh));
-    return (2.0f + 1.0f / rough) * fhe_pow(s, 1.0f / rough) / (2.0f * kPi);
+    return (2.0f + 1.0f / rough) * oe::pow(s, 1.0f / rough) / (2.0f * kPi);
   }
   V3 eval(V3 wo, V3 wi) const
   {

@@ -326,15 +326,15 @@ static bool intersect_brute(const Scene& s, V3 o, V3 d, float tmax, bool any_hit
 static float hosek_bezier(const float* m, int stride, float e)
 {
   const float ie = 1.0f - e;
-  return fhe_pow(ie, 5.0f) * m[0] + 5.0f * fhe_pow(ie, 4.0f) * e * m[stride] + 10.0f * fhe_pow(ie, 3.0f) * fhe_pow(e, 2.0f) * m[2 * stride] +
-         10.0f * fhe_pow(ie, 2.0f) * fhe_pow(e, 3.0f) * m[3 * stride] + 5.0f * ie * fhe_pow(e, 4.0f) * m[4 * stride] + fhe_pow(e, 5.0f) * m[5 * stride];
+  return oe::pow(ie, 5.0f) * m[0] + 5.0f * oe::pow(ie, 4.0f) * e * m[stride] + 10.0f * oe::pow(ie, 3.0f) * oe::pow(e, 2.0f) * m[2 * stride] +
+         10.0f * oe::pow(ie, 2.0f) * oe::pow(e, 3.0f) * m[3 * stride] + 5.0f * ie * oe::pow(e, 4.0f) * m[4 * stride] + oe::pow(e, 5.0f) * m[5 * stride];
 }
 static HosekState hosek_cook(float turbidity, float albedo, float elevation)
 {
   HosekState st{};
   const int it = (int)turbidity;
   const float tr = turbidity - (float)it;
-  const float e = fhe_pow(elevation / (kPi / 2.0f), (1.0f / 3.0f));
+  const float e = oe::pow(elevation / (kPi / 2.0f), (1.0f / 3.0f));
   for (int ch = 0; ch < 3; ++ch) {
     const float* ds = g_hosek + 1080 * ch;
     const float* dr = g_hosek + 3240 + 120 * ch;
@@ -361,18 +361,18 @@ static HosekState hosek_cook(float turbidity, float albedo, float elevation)
 static float hosek_channel(const HosekState& st, int ch, float theta, float gamma)
 {
   const float* c = st.cfg[ch];
-  const float cg = fhe_cos(gamma), ct = fhe_cos(theta);
-  const float expM = fhe_exp(c[4] * gamma);
+  const float cg = oe::cos(gamma), ct = oe::cos(theta);
+  const float expM = oe::exp(c[4] * gamma);
   const float rayM = cg * cg;
-  const float mieM = (1.0f + cg * cg) / fhe_pow1p5(1.0f + c[8] * c[8] - 2.0f * c[8] * cg);  // arhosek.cu:109-110: pow(x, 1.5)
+  const float mieM = (1.0f + cg * cg) / oe::pow1p5(1.0f + c[8] * c[8] - 2.0f * c[8] * cg);  // arhosek.cu:109-110: pow(x, 1.5)
   const float zenith = sqrtf(ct);
-  return (1.0f + c[0] * fhe_exp(c[1] / (ct + 0.01f))) * (c[2] + c[3] * expM + c[5] * rayM + c[6] * mieM + c[7] * zenith) * st.rad[ch];
+  return (1.0f + c[0] * oe::exp(c[1] / (ct + 0.01f))) * (c[2] + c[3] * expM + c[5] * rayM + c[6] * mieM + c[7] * zenith) * st.rad[ch];
 }
 // pt.cu:352-363 (+ math.cu:111-118; the azimuth is computed there but never used)
 static V3 sky_radiance(const Scene& s, V3 v)
 {
-  const float theta = fhe_acos(clampf(v.y, -1.0f, 1.0f));
-  const float gamma = fhe_acos(dot(s.sun_dir, v));
+  const float theta = oe::acos(clampf(v.y, -1.0f, 1.0f));
+  const float gamma = oe::acos(dot(s.sun_dir, v));
   return s.sky_intensity * v3(hosek_channel(s.hosek, 0, theta, gamma), hosek_channel(s.hosek, 1, theta, gamma), hosek_channel(s.hosek, 2, theta, gamma));
 }
 
@@ -495,8 +495,8 @@ static inline bool shadow_visible(const Scene& s, V3 o, V3 d, float tmax)
 static inline V3 env_radiance(const Scene& s, const Frame& fr, V3 d)
 {
   if (s.has_ibl) {  // pt.cu:344-350, math.cu:111-118
-    const float theta = fhe_acos(clampf(d.y, -1.0f, 1.0f));
-    float phi = fhe_atan2(d.z, d.x);
+    const float theta = oe::acos(clampf(d.y, -1.0f, 1.0f));
+    float phi = oe::atan2(d.z, d.x);
     if (phi < 0) phi += 2.0f * kPi;
     float o[4];
     tex2d(s.ibl, phi / (2.0f * kPi), theta / kPi, o);
@@ -736,12 +736,12 @@ static inline float uchimura1(float x)
   const float w0 = 1.0f - smoothstep_f(0.0f, m, x);
   const float w2 = (x < m + l0) ? 0.0f : 1.0f;
   const float w1 = 1.0f - w0 - w2;
-  const float T = m * fhe_pow(x / m, c) + b;
-  const float S = P - (P - S1) * fhe_exp(CP * (x - S0));
+  const float T = m * oe::pow(x / m, c) + b;
+  const float S = P - (P - S1) * oe::exp(CP * (x - S0));
   const float Lc = m + a * (x - m);
   return T * w0 + Lc * w1 + S * w2;
 }
-static inline float srgb1(float x) { return x < 0.0031308 ? (float)(12.92 * x) : (float)(1.055 * fhe_pow(x, 1.0f / 2.4f) - 0.055); }
+static inline float srgb1(float x) { return x < 0.0031308 ? (float)(12.92 * x) : (float)(1.055 * oe::pow(x, 1.0f / 2.4f) - 0.055); }
 
 static void post_process(const float* in, float* hi, float* tmp, int w, int h, const PostParams& pp, float* out)
 {
@@ -765,7 +765,7 @@ static void post_process(const float* in, float* hi, float* tmp, int w, int h, c
             const int x = clampi(i + u, 0, w - 1), y = clampi(j + v, 0, h - 1);
             const float* b1 = hi + 4 * (x + w * y);
             const float dist2 = (float)(u * u + v * v);
-            const float hh = fhe_exp(-dist2 / (2.0f * pp.bloom_sigma));
+            const float hh = oe::exp(-dist2 / (2.0f * pp.bloom_sigma));
             sum += hh * v4(b1[0], b1[1], b1[2], b1[3]);
             wsum += hh;
           }
@@ -778,8 +778,8 @@ static void post_process(const float* in, float* hi, float* tmp, int w, int h, c
       for (int i = 0; i < w; ++i)
         if (covered(i, j)) std::memcpy(tmp + 4 * (i + w * j), in + 4 * (i + w * j), 16);
   }
-  const float EV100 = fhe_log2((float)(1.0f * 1.0f / 1.0f * 100.0 / pp.ISO));
-  const float maxLum = (float)(1.2 * fhe_pow(2.0f, EV100));
+  const float EV100 = oe::log2((float)(1.0f * 1.0f / 1.0f * 100.0 / pp.ISO));
+  const float maxLum = (float)(1.2 * oe::pow(2.0f, EV100));
   const float exposure = 1.0f / maxLum;
   for (int j = 0; j < h; ++j)
     for (int i = 0; i < w; ++i) {
@@ -853,14 +853,15 @@ void orc_elementary(int fn, int n, const float* x, const float* y, float* out)
 {
   for (int i = 0; i < n; ++i) {
     switch (fn) {
-      case 0: out[i] = fhe_sin(x[i]); break;
-      case 1: out[i] = fhe_cos(x[i]); break;
-      case 2: out[i] = fhe_exp(x[i]); break;
-      case 3: out[i] = fhe_log(x[i]); break;
-      case 4: out[i] = fhe_pow(x[i], y[i]); break;
-      case 5: out[i] = fhe_acos(x[i]); break;
-      case 6: out[i] = fhe_atan2(x[i], y[i]); break;
-      case 7: out[i] = fhe_log2(x[i]); break;
+      case 0: out[i] = oe::sin(x[i]); break;
+      case 1: out[i] = oe::cos(x[i]); break;
+      case 2: out[i] = oe::exp(x[i]); break;
+      case 3: out[i] = oe::log(x[i]); break;
+      case 4: out[i] = oe::pow(x[i], y[i]); break;
+      case 5: out[i] = oe::acos(x[i]); break;
+      case 6: out[i] = oe::atan2(x[i], y[i]); break;
+      case 7: out[i] = oe::log2(x[i]); break;
+      case 8: out[i] = oe::pow1p5(x[i]); break;
     }
   }
 }
@@ -895,7 +896,7 @@ void orc_bsdf(const void* material180, int entering, int n, const float* wo, con
 }
 void orc_hosek_cook(float turbidity, float albedo, const float* sun_dir, float* out30)
 {
-  const float elevation = (float)(0.5f * M_PI - fhe_acos(clampf(sun_dir[1], -1.0f, 1.0f)));  // renderer.h:592-601
+  const float elevation = (float)(0.5f * M_PI - oe::acos(clampf(sun_dir[1], -1.0f, 1.0f)));  // renderer.h:592-601
   const HosekState st = hosek_cook(turbidity, albedo, elevation);
   std::memcpy(out30, &st, sizeof st);
 }
@@ -1012,7 +1013,7 @@ void orc_set_hosek(void* h, int enable, float turbidity, float albedo)
   Scene* s = (Scene*)h;
   s->has_hosek = enable != 0;
   if (!enable) return;
-  const float elevation = (float)(0.5f * M_PI - fhe_acos(clampf(s->sun_dir.y, -1.0f, 1.0f)));
+  const float elevation = (float)(0.5f * M_PI - oe::acos(clampf(s->sun_dir.y, -1.0f, 1.0f)));
   s->hosek = hosek_cook(turbidity, albedo, elevation);
 }
 // rays: o.xyz, d.xyz, tmax per ray; out: t,u,v as float + prim as uint32 (0xffffffff = miss)
@@ -1077,8 +1078,8 @@ void orc_math(int kind, int n, const float* in, float* out)
       case 3: { const V3 r = to_local(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
       case 4: { const V3 r = to_world(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
       case 5: {  // math.cu:111-118, as env_radiance evaluates it
-        o[0] = fhe_acos(clampf(a[1], -1.0f, 1.0f));
-        float phi = fhe_atan2(a[2], a[0]);
+        o[0] = oe::acos(clampf(a[1], -1.0f, 1.0f));
+        float phi = oe::atan2(a[2], a[0]);
         if (phi < 0) phi += 2.0f * kPi;
         o[1] = phi;
         break;
@@ -1087,14 +1088,14 @@ void orc_math(int kind, int n, const float* in, float* out)
       case 7: o[0] = uchimura1(a[0]); o[1] = uchimura1(a[1]); o[2] = uchimura1(a[2]); break;  // post-process.h:78-111
       case 8: o[0] = srgb1(a[0]); o[1] = srgb1(a[1]); o[2] = srgb1(a[2]); break;        // post-process.h:19-29
       case 9: {                                                                        // post-process.h:114-125
-        o[0] = fhe_log2((float)(a[0] * a[0] / a[1] * 100.0 / a[2]));
-        const float max_lum = (float)(1.2 * fhe_pow(2.0f, o[0]));
+        o[0] = oe::log2((float)(a[0] * a[0] / a[1] * 100.0 / a[2]));
+        const float max_lum = (float)(1.2 * oe::pow(2.0f, o[0]));
         o[1] = 1.0f / max_lum;
         break;
       }
       case 10: {                                                                       // post-process.cu:139-152
-        const float ev = fhe_log2((float)(1.0f * 1.0f / 1.0f * 100.0 / a[3]));
-        const float e = 1.0f / (float)(1.2 * fhe_pow(2.0f, ev));
+        const float ev = oe::log2((float)(1.0f * 1.0f / 1.0f * 100.0 / a[3]));
+        const float e = 1.0f / (float)(1.2 * oe::pow(2.0f, ev));
         o[0] = srgb1(uchimura1(a[0] * e)); o[1] = srgb1(uchimura1(a[1] * e)); o[2] = srgb1(uchimura1(a[2] * e));
         break;
       }
@@ -1135,7 +1136,7 @@ void orc_denoise(uint32_t w, uint32_t h, const float* beauty, const float* norma
             const float m = (a[4 * q] + a[4 * q + 1] + a[4 * q + 2]) + (a[4 * p] + a[4 * p + 1] + a[4 * p + 2]);
             const float den = m * m * (1.0f / 9.0f) + 1e-4f;  // colour distance relative to the mean level of the two pixels
             const float e = ((dcx * dcx + dcy * dcy + dcz * dcz) / den) * inv_sc + (dnx * dnx + dny * dny + dnz * dnz) * inv_sn + (dax * dax + day * day + daz * daz) * inv_sa;
-            const float wgt = kern[std::abs(dx)] * kern[std::abs(dy)] * fhe_exp(-e);
+            const float wgt = kern[std::abs(dx)] * kern[std::abs(dy)] * oe::exp(-e);
             sx += wgt * a[4 * q]; sy += wgt * a[4 * q + 1]; sz += wgt * a[4 * q + 2]; sw += wgt;
           }
         const float inv = 1.0f / sw;

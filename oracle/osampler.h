@@ -6,9 +6,9 @@
 //   Sobol' + Owen scrambling (Burley)    fredholm/modules/sobol.cu:10661-10742
 //   disk / hemisphere / triangle / VNDF  fredholm/modules/sampling.cu:54-110
 //   discrete 1-D distribution            fredholm/modules/sampling.cu:112-150
-// Integer parts are bit-exact by construction; float parts use include/fh_elementary.h.
+// Integer parts are bit-exact by construction; float parts use the checker's own elementary functions (oelementary.h).
 #pragma once
-#include "../include/fh_elementary.h"
+#include "oelementary.h"
 #include "ovec.h"
 
 namespace orc {
@@ -161,9 +161,8 @@ inline V2 concentric_disk(V2 u)
   if (u0.x == 0.0f && u0.y == 0.0f) return v2(0.0f);
   const float r = fabsf(u0.x) > fabsf(u0.y) ? u0.x : u0.y;
   const float theta = fabsf(u0.x) > fabsf(u0.y) ? 0.25f * kPi * u0.y / u0.x : 0.5f * kPi - 0.25f * kPi * u0.x / u0.y;
-  float s, c;
-  fhe_sincos(theta, &s, &c);
-  return v2(r * c, r * s);
+  const oe::SinCos sc = oe::sincos(theta);
+  return v2(r * sc.c, r * sc.s);
 }
 // sampling.cu:66-78
 inline V3 cosine_hemisphere(V2 u)
@@ -190,8 +189,8 @@ inline V3 vndf(V3 wo, V2 alpha, V2 u)
   const V3 T2 = cross(Vh, T1);
   const float r = sqrtf(u.x);
   const float phi = (float)(2.0f * M_PI * u.y);
-  float sp, cp;
-  fhe_sincos(phi, &sp, &cp);
+  const oe::SinCos scp = oe::sincos(phi);
+  const float sp = scp.s, cp = scp.c;
   const float t1 = r * cp;
   float t2 = r * sp;
   const float s = 0.5f * (1.0f + Vh.y);

@@ -74,7 +74,7 @@ def offset_origin(p, n):
     return out
 
 
-ELEMENTARY = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "acos": 5, "atan2": 6, "log2": 7}
+ELEMENTARY = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "acos": 5, "atan2": 6, "log2": 7, "pow1p5": 8}
 
 
 def elementary(fn, x, y=None):

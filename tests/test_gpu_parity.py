@@ -265,6 +265,37 @@ def test_closest_and_any_hit_match_checker(oracle, n_tris, edge):
     r.close()
 
 
+@pytest.mark.parametrize("n_tris,edge,n", [(5000, 0.02, 40000), (200000, 0.01, 2500)])
+def test_rays_from_far_outside_the_scene_match_checker(oracle, n_tris, edge, n):
+    """A ray that starts 10^3 .. 10^6 scene sizes away: the slab distances (p - o) * inv then carry a rounding error that grows with |p - o| and passes the
+    absolute padding of the child boxes (and the triangle test itself sees the ray displaced by as much); the node test moves its near planes in and its far
+    planes out by 2^-21 of each axis' offset so that no box on the way to what the triangle test calls a hit is skipped (fh_trace.h: node8_test).  Every ray is
+    aimed at a point of a triangle; the truth is the checker's test of EVERY triangle (no tree)."""
+    sc = scenes.triangle_soup(n_tris, edge)
+    r = F.Renderer(0)
+    r.load_scene(sc)
+    r.build_ias()
+    S = oracle.Scene(sc)
+    rng = np.random.default_rng(n_tris + 1)
+    v = sc["vertices"].reshape(-1, 3, 3)
+    b = rng.dirichlet((1.0, 1.0, 1.0), n).astype(np.float32)
+    target = (v[rng.integers(0, n_tris, n)] * b[:, :, None]).sum(axis=1)
+    d = _dirs(rng, n)
+    dist = (10.0 ** rng.uniform(3.0, 6.0, n)).astype(np.float32)[:, None]
+    o = (target - d * dist).astype(np.float32)
+    dd = (target - o)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    rays = np.concatenate([o, dd.astype(np.float32), np.full((n, 1), 1e9, np.float32)], axis=1).astype(np.float32)
+    tuv_g, prim_g = r.trace_rays(rays)
+    tuv_o, prim_o = S.trace(rays, brute=True)
+    assert (prim_o != 0xFFFFFFFF).mean() > 0.2  # (from 10^6 scene sizes the direction itself is only good to a triangle or two)
+    assert np.array_equal(prim_g, prim_o)
+    assert np.array_equal(_bits(tuv_g), _bits(tuv_o))
+    occ_g = r.trace_rays(rays, any_hit=True)[1] != 0xFFFFFFFF
+    assert np.array_equal(occ_g, prim_o != 0xFFFFFFFF)
+    r.close()
+
+
 def test_degenerate_and_coplanar_triangles(oracle):
     sc = scenes.cornell_box()
     v = sc["vertices"].copy()

@@ -124,6 +124,47 @@ def test_elementary_accuracy(oracle):
     assert np.abs(oracle.elementary("atan2", a, b) - np.arctan2(a.astype(np.float64), b.astype(np.float64))).max() < 1e-6
 
 
+def test_product_and_checker_elementary_functions_are_two_implementations_with_the_same_bits(oracle, tmp_path):
+    """The checker computes sin / cos / exp / log / pow / acos / atan2 with its OWN code (oracle/oelementary.h), written from the numerical specification in
+    DESIGN.md 2; the product's is include/fh_elementary.h (here compiled for the host through tests/shims/elementary_host.cpp; the device build is compared on the
+    GPU by test_gpu_parity.py::test_elementary_functions_identical_on_device).  No header is shared -- and the two must agree bit for bit, special cases included."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("oracle/oelementary.h", "oracle/osampler.h", "oracle/obsdf.h", "oracle/oracle.cpp", "oracle/ovec.h", "oracle/otexture.h"):
+        text = open(os.path.join(root, f)).read()
+        assert not [ln for ln in text.splitlines() if ln.lstrip().startswith("#include") and "include/" in ln and "fredholm_hip.h" not in ln], f"{f} includes a product header"
+    so = tmp_path / "libfhe_host.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma", os.path.join(root, "tests", "shims", "elementary_host.cpp"), "-o", str(so)])
+    host = ctypes.CDLL(str(so))
+
+    def product(fn, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = x if y is None else np.ascontiguousarray(y, dtype=np.float32)
+        out = np.zeros_like(x)
+        fp = ctypes.POINTER(ctypes.c_float)
+        host.fhe_host(oracle.ELEMENTARY[fn], int(x.size), x.ctypes.data_as(fp), y.ctypes.data_as(fp), out.ctypes.data_as(fp))
+        return out
+
+    def same(a, b):
+        return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+    rng = np.random.default_rng(7)
+    n = 1 << 20
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.50000006, -0.50000006, 1.0000001, -1.0000001, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.1754944e-38, 3.4028235e38, -3.4028235e38,
+                     88.72284, 88.7229, -103.97208, -103.9721, 2.4142137, 0.41421357, 2.0, 3.0, -2.0, -3.0, 2.5, -2.5, 0.3333333, 1e4, -1e4, 6.2831855, 1.5707964, 128.5, -151.0], np.float32)
+    wide = rng.standard_normal(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 5, n).astype(np.float32)
+    anybits = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    unit = rng.uniform(-1.0, 1.0, n).astype(np.float32)
+    pos = np.abs(wide) + np.float32(1e-30)
+    for fn, xs in (("sin", [wide, unit * 8.0, edge]), ("cos", [wide, unit * 8.0, edge]), ("exp", [unit * 100.0, wide, anybits, edge]), ("log", [pos, anybits, edge]), ("log2", [pos, anybits, edge]),
+                   ("acos", [unit, unit * 1.001, anybits, edge]), ("pow1p5", [pos, anybits, edge])):
+        for x in xs:
+            assert same(product(fn, x), oracle.elementary(fn, x)), fn
+    for fn in ("pow", "atan2"):
+        for x, y in ((pos, unit * 8.0), (wide, np.round(unit * 6.0)), (wide, rng.permutation(wide)), (anybits, rng.permutation(anybits)), (np.repeat(edge, edge.size), np.tile(edge, edge.size))):
+            assert same(product(fn, x, y), oracle.elementary(fn, x, y)), fn
+
+
 def test_elementary_special_cases(oracle):
     assert np.isnan(oracle.elementary("acos", [1.0000001])[0])  # dot(sun, dir) may exceed 1: pt.cu:355 has no clamp
     assert oracle.elementary("pow", [0.0], [2.5])[0] == 0.0

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > gpurun_out/c7_pytest.txt 2>&1; echo "pytest rc $?"; tail -6 gpurun_out/c7_pytest.txt
+bash tools/gpu_ab.sh "base" "2 1 3" "--steps 2 --warmup 1 --no-extras"
