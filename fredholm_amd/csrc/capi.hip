@@ -293,20 +293,24 @@ int upload_textures(fh_ctx* ctx, uint32_t n, const fh_texture_desc* descs)
 int rebuild_ownership(fh_ctx* ctx)
 {
   if (ctx->d_owned) { (void)hipFree(ctx->d_owned); ctx->d_owned = nullptr; }
+  if (ctx->d_owned_xy) { (void)hipFree(ctx->d_owned_xy); ctx->d_owned_xy = nullptr; }
   ctx->n_owned = 0;
   if (ctx->width == 0 || ctx->height == 0) return FH_OK;
-  std::vector<uint32_t> owned;
+  if (ctx->width > 65535u || ctx->height > 65535u) return fail(ctx, FH_E_UNSUPPORTED, "frames wider or higher than 65535 pixels are not supported");
+  std::vector<uint32_t> owned, owned_xy;
   const uint32_t tw = ctx->tile_w, th = ctx->tile_h;
   const uint32_t tx = (ctx->width + tw - 1) / tw, ty = (ctx->height + th - 1) / th;
   for (uint32_t t = 0; t < tx * ty; ++t) {
     if (t % ctx->shard_world != ctx->shard_rank) continue;
     const uint32_t x0 = (t % tx) * tw, y0 = (t / tx) * th;
     for (uint32_t y = y0; y < y0 + th && y < ctx->height; ++y)
-      for (uint32_t x = x0; x < x0 + tw && x < ctx->width; ++x) owned.push_back(x + ctx->width * y);
+      for (uint32_t x = x0; x < x0 + tw && x < ctx->width; ++x) { owned.push_back(x + ctx->width * y); owned_xy.push_back(x | (y << 16)); }
   }
   ctx->n_owned = (uint32_t)owned.size();
   FH_HIP(hipMalloc((void**)&ctx->d_owned, owned.empty() ? 16 : owned.size() * 4));
+  FH_HIP(hipMalloc((void**)&ctx->d_owned_xy, owned.empty() ? 16 : owned.size() * 4));
   if (!owned.empty()) FH_HIP(hipMemcpy(ctx->d_owned, owned.data(), owned.size() * 4, hipMemcpyHostToDevice));
+  if (!owned.empty()) FH_HIP(hipMemcpy(ctx->d_owned_xy, owned_xy.data(), owned_xy.size() * 4, hipMemcpyHostToDevice));
   return FH_OK;
 }
 
@@ -357,6 +361,7 @@ int fh_ctx_create(int device, fh_ctx** out)
   if (hipMalloc((void**)&ctx->d_lut_refl, kLutReflectionBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_sheen, kLutSheenBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_trace_counters, 32 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
+  if (hipMalloc((void**)&ctx->d_hosek, sizeof(fh::HosekSky)) != hipSuccess || hipMemset(ctx->d_hosek, 0, sizeof(fh::HosekSky)) != hipSuccess) return bail("hipMalloc failed");
   if (hipMemcpy(ctx->d_sobol, kSobolMatrices, kSobolMatricesBytes, hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
   {
     // byte-indexed form of the generator matrices: entry [dim][k][b] = XOR of the columns 8k + j selected by the bits j of b, so that the XOR over the 32 index
@@ -429,7 +434,7 @@ int fh_ctx_destroy(fh_ctx* ctx)
   void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_sobol_bytes, ctx->d_alpha_rec, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
                   ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl,
                   ctx->d_bloom_weights, ctx->d_quirk_seen, ctx->d_quirk_aov, ctx->d_obj_vertices, ctx->d_obj_normals, ctx->d_obj_texcoords, ctx->d_obj_indices, ctx->d_face_meta, ctx->d_o2w, ctx->d_w2o,
-                  ctx->d_bvh8_box, ctx->d_denoise_tmp[0], ctx->d_denoise_tmp[1]};
+                  ctx->d_bvh8_box, ctx->d_denoise_tmp[0], ctx->d_denoise_tmp[1], ctx->d_hosek, ctx->d_owned_xy};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -597,6 +602,8 @@ int fh_load_arhosek_sky(fh_ctx* ctx, float turbidity, float albedo)
   const float elevation = (float)(0.5f * 3.14159265358979323846 - fhe_acos(clampf(ctx->sun_dir[1], -1.0f, 1.0f)));  // renderer.h:592-601
   ctx->hosek = hosek_cook(kHosekRgb, turbidity, albedo, elevation);
   ctx->has_hosek = true;
+  FH_HIP(hipMemcpyAsync(ctx->d_hosek, &ctx->hosek, sizeof ctx->hosek, hipMemcpyHostToDevice, ctx->stream));  // (ordered after the frames already submitted)
+  FH_HIP(hipStreamSynchronize(ctx->stream));
   return FH_OK;
 }
 int fh_clear_arhosek_sky(fh_ctx* ctx)
@@ -687,6 +694,7 @@ int fh_unpack_shard(fh_ctx* ctx, uint32_t rank, uint32_t world, const float* pac
   if (tmp.n_owned) hipLaunchKernelGGL(k_unpack, dim3((tmp.n_owned * fpp + 255) / 256), dim3(256), 0, ctx->stream, packed, tmp.d_owned, tmp.n_owned, fpp, layer);
   (void)hipStreamSynchronize(ctx->stream);
   if (tmp.d_owned) (void)hipFree(tmp.d_owned);
+  if (tmp.d_owned_xy) (void)hipFree(tmp.d_owned_xy);
   FH_HIP(hipGetLastError());
   return FH_OK;
 }

@@ -88,6 +88,7 @@ struct fh_ctx {
   uint32_t* d_sample_issued = nullptr;  // samples started per pixel (written after k_generate): the next pass does not wait for the accumulate
   uint32_t shard_rank = 0, shard_world = 1, tile_w = 32, tile_h = 32;
   uint32_t* d_owned = nullptr;  // image indices of owned pixels, in tile order
+  uint32_t* d_owned_xy = nullptr;  // the same pixels as x | y << 16
   uint32_t n_owned = 0;
 
   // environment (renderer.h:819-827)
@@ -97,6 +98,7 @@ struct fh_ctx {
   float sun_dir[3] = {0.0f, 1.0f, 0.0f};
   bool has_hosek = false;
   fh::HosekSky hosek{};
+  fh::HosekSky* d_hosek = nullptr;  // device copy (FrameDev::hosek)
 
   // path pools: one per pass in flight (pass j uses slot j % n_slots and the stream of that slot); allocated on first use
   fh::PoolDev pool[3] = {};

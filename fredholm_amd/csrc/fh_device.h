@@ -75,11 +75,12 @@ struct FrameDev {
   // camera (camera.cu:24-53)
   m34 cam_xf;
   float cam_inv_tan, cam_F, cam_focus;
+  float cam_a_plus_b, cam_lens_radius;  // a + b with a = 1 / (1 + f - 1 / b), and 2 f / F (camera.cu:33-36): per-frame constants, formed on the host
   // environment
   f3 bg;
   float sky_intensity;
   f3 sun_dir;
-  HosekSky hosek;
+  const HosekSky* hosek;  // 30 floats in device memory (fh_ctx::d_hosek); kernels that evaluate the sky per path stage them in LDS (render.hip: stage_sky) -- as a kernel argument they sat in 30 SGPRs next to everything else and the compiler spilled scalars into vector lanes (k_generate: 162 v_readlane / v_writelane)
   f3 dir_le, dir_dir;
   float dir_disk_radius;  // 1e9 * tan(rad(angle/2)), pt.cu:333-335
   // padded scene bounds: camera rays that miss them skip the traversal queue

@@ -24,6 +24,13 @@ struct RayPre {
 
 FH_D float comp(f3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
+// 1 / d with zero components replaced by +-1e-20
+FH_D f3 safe_reciprocal(f3 d)
+{
+  return mk3(1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x), 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y),
+             1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z));
+}
+
 FH_D RayPre ray_prepare(f3 o, f3 d)
 {
   RayPre r;
@@ -37,8 +44,7 @@ FH_D RayPre ray_prepare(f3 o, f3 d)
   r.Sx = comp(d, r.kx) / dz;
   r.Sy = comp(d, r.ky) / dz;
   r.Sz = 1.0f / dz;
-  r.inv = mk3(1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x), 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y),
-              1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z));
+  r.inv = safe_reciprocal(d);
   return r;
 }
 

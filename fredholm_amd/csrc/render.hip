@@ -67,6 +67,14 @@ FH_D void load_sobol_rows(SobolRows<N>& rows, const uint32_t* tables, const uint
   __syncthreads();
 }
 
+// the sky coefficients of the frame, copied to the workgroup's LDS; the caller's next barrier publishes them
+FH_D void stage_sky(FrameDev& fr, HosekSky& lds_sky)
+{
+  if (!fr.has_hosek) return;
+  if (threadIdx.x < sizeof(HosekSky) / 4u) reinterpret_cast<float*>(&lds_sky)[threadIdx.x] = reinterpret_cast<const float*>(fr.hosek)[threadIdx.x];
+  fr.hosek = &lds_sky;
+}
+
 // environment seen along d: IBL, else Hosek sky, else the constant background (pt.cu:511-517, :536-542)
 FH_D f3 env_radiance(const FrameDev& fr, f3 d)
 {
@@ -78,42 +86,46 @@ FH_D f3 env_radiance(const FrameDev& fr, f3 d)
     fht_tex2d(&fr.ibl, nullptr, phi / (2.0f * kPi), theta / kPi, o);
     return fr.sky_intensity * mk3(o[0], o[1], o[2]);
   }
-  return fr.has_hosek ? hosek_radiance(fr.hosek, fr.sun_dir, fr.sky_intensity, d) : fr.bg;
+  return fr.has_hosek ? hosek_radiance(*fr.hosek, fr.sun_dir, fr.sky_intensity, d) : fr.bg;
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, const uint32_t* issued, const uint32_t* owned, uint32_t n_owned, uint32_t n_paths)
+// grid: x over the owned pixels (grid-stride), y = sample of the pass -- slot p = sample * n_owned + pixel without a division per path, and the pixel's
+// coordinates come packed from the ownership list instead of from image_idx / width and % width (four integer divisions by run-time values were ~60 of the
+// kernel's ~1070 non-FMA instructions per path)
+__global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, const uint32_t* issued, const uint32_t* owned, const uint32_t* owned_xy, uint32_t n_owned)
 {
   __shared__ SobolRows<1> rows;
+  __shared__ HosekSky s_sky;
+  stage_sky(fr, s_sky);
   const uint32_t dims[1] = {1u};
   load_sobol_rows<1>(rows, fr.sobol_bytes, dims);
   const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < n_paths; base += stride) {
-    const uint32_t p = base + threadIdx.x;
-    const bool valid = p < n_paths;
+  const uint32_t k = blockIdx.y;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n_owned; base += stride) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < n_owned;
+    const uint32_t p = k * n_owned + i;  // slot p = sample-major: lanes of a wave hold neighbouring pixels of one sample index
     bool enter = false;
     if (valid) {
       bool alive = false;
-      const uint32_t i = p % n_owned, k = p / n_owned;  // slot p = sample-major: lanes of a wave hold neighbouring pixels of one sample index
       const uint32_t image_idx = owned[i];
       const uint32_t n_spp = issued[image_idx] + k;  // sample index = samples started on this pixel so far (pt.cu:423: params.sample_count)
-      const uint32_t px = image_idx % fr.width, py = image_idx / fr.width;
+      const uint32_t xy = owned_xy[i];
+      const uint32_t px = xy & 0xffffu, py = xy >> 16;
       f2 u = cmj_draw(n_spp, image_idx, 0u, fr.seed_hash);
       float uvx = (2.0f * (px + u.x) - fr.width) / fr.height;
       const float uvy = (2.0f * (py + u.y) - fr.height) / fr.height;
       uvx = -uvx;
       u = cmj_draw(n_spp, image_idx, 1u, fr.seed_hash);
-      // thin lens (camera.cu:24-53)
+      // thin lens (camera.cu:24-53); a + b and the lens radius are the same for every ray: computed once on the host, in fp32 with the reference's operations
       const float f = fr.cam_inv_tan;
-      const float b = fr.cam_focus;
-      const float a = 1.0f / (1.0f + f - 1.0f / b);
-      const float lens_radius = 2.0f * f / fr.cam_F;
       const f3 p_sensor = mk3(uvx, uvy, 0.0f);
       const f3 p_lens_center = mk3(0.0f, 0.0f, f);
-      const f2 pd = lens_radius * concentric_disk(u);
+      const f2 pd = fr.cam_lens_radius * concentric_disk(u);
       const f3 p_lens = p_lens_center + mk3(pd.x, pd.y, 0.0f);
       const f3 s2c = normalize(p_lens_center - p_sensor);
-      const f3 p_object = p_sensor + ((a + b) / s2c.z) * s2c;
+      const f3 p_object = p_sensor + (fr.cam_a_plus_b / s2c.z) * s2c;
       const f3 org = xform_point(fr.cam_xf, p_lens);
       f3 d = normalize(p_object - p_lens);
       d.z *= -1.0f;
@@ -125,7 +137,9 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
       // camera rays that miss the (padded) scene bounds cannot hit anything: they are finished right here
       // (radiance = 0 + 1 * environment, pt.cu:504-523) and never enter the traversal queue, so the waves of
       // bounce 0 only hold rays that enter the scene and no path state is written for the others
-      const RayPre rp = ray_prepare(org, dir);
+      RayPre rp;  // (only what the slab test reads: origin and reciprocal direction, as ray_prepare forms them)
+      rp.o = org;
+      rp.inv = safe_reciprocal(dir);
       float tn;
       enter = alive && slab_test(rp, fr.scene_lo.x, fr.scene_lo.y, fr.scene_lo.z, fr.scene_hi.x, fr.scene_hi.y, fr.scene_hi.z, 1e9f, tn);
       if (enter) {
@@ -745,6 +759,8 @@ __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : FH_SHADE_BLOCKS)
     s_srgb[threadIdx.x] = sc.srgb_lut[threadIdx.x];
     sc.srgb_lut = s_srgb;
   }
+  __shared__ HosekSky s_sky;
+  stage_sky(fr, s_sky);
   BounceSlots bs;
   bs.set(fr, sc.n_lights, depth);
   bs.load_rows(rows, fr.sobol_bytes);  // (ends with the workgroup barrier that also publishes the tables above)
@@ -1042,6 +1058,8 @@ __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolD
     for (uint32_t i = threadIdx.x; i < sc.n_materials * (uint32_t)(sizeof(MaterialDev) / 4); i += blockDim.x) dst[i] = src[i];
     sc.materials = s_mat;
   }
+  __shared__ HosekSky s_sky;
+  stage_sky(fr, s_sky);
   __syncthreads();
   const uint32_t count = pool.counters[first_depth * kCounterStride + CNT_RAD];
   const uint32_t* q = pool.q_rad[first_depth & 1u];
@@ -1416,10 +1434,22 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   for (int r = 0; r < 3; ++r) fr.cam_xf.r[r] = make_float4(cam->transform[4 * r], cam->transform[4 * r + 1], cam->transform[4 * r + 2], cam->transform[4 * r + 3]);
   fr.cam_inv_tan = 1.0f / tanf(0.5f * cam->fov);
   fr.cam_F = cam->F; fr.cam_focus = cam->focus;
+  {  // camera.cu:33-36, in fp32 like the device code these lines used to be in (volatile: no contraction, no double-precision intermediates)
+    volatile float f = fr.cam_inv_tan, b = cam->focus;
+    volatile float inv_b = 1.0f / b;
+    volatile float den = 1.0f + f;
+    den = den - inv_b;
+    volatile float a = 1.0f / den;
+    volatile float apb = a + b;
+    volatile float two_f = 2.0f * f;
+    volatile float lr = two_f / cam->F;
+    fr.cam_a_plus_b = apb;
+    fr.cam_lens_radius = lr;
+  }
   fr.bg = mk3(bg[0], bg[1], bg[2]);
   fr.sky_intensity = ctx->sky_intensity;
   fr.sun_dir = mk3(ctx->sun_dir[0], ctx->sun_dir[1], ctx->sun_dir[2]);
-  fr.hosek = ctx->hosek;
+  fr.hosek = ctx->d_hosek;
   fr.dir_le = mk3(ctx->dir_le[0], ctx->dir_le[1], ctx->dir_le[2]);
   fr.dir_dir = mk3(ctx->dir_dir[0], ctx->dir_dir[1], ctx->dir_dir[2]);
   fr.dir_disk_radius = 1e9f * tanf(0.5f * ctx->dir_angle * kPi / 180.0f);
@@ -1539,7 +1569,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     if (prev != slot && ctx->gen_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_gen[prev], 0));
     {
       Span sp(ctx, st, 4);
-      hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, n_paths);
+      hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx->n_owned), nb), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, ctx->d_owned, ctx->d_owned_xy, ctx->n_owned);
       hipLaunchKernelGGL(k_bump_issued, dim3((ctx->n_owned + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, nb);
       ctx->stats.n_generate_launches++;
     }
