@@ -46,7 +46,7 @@ struct Bvh8Dev {
   const float4* tris;   // 3 x float4 per triangle slot, eight slots per node (slot 8 * node + child slot)
   uint32_t n_nodes;
   uint32_t n_tris;
-  uint32_t depth;       // levels of the tree (>= 2): entries of the LDS traversal stack
+  uint32_t depth;       // entries of the LDS traversal stack: levels of the tree - 1 (fh_trace.h: stack_entries_for)
 };
 
 struct SceneDev {

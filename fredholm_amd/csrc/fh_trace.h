@@ -278,7 +278,10 @@ FH_D uint32_t node8_test(const Ray8& r, const uint4 n0, const uint4 n1, const ui
   // triangle test itself makes of a ray from far away; so the near planes of every axis are moved in and the far planes out by 2^-21 of that axis' own offset:
   // nothing next to the padding for a ray that starts in or near the scene, and what keeps a thin box from being skipped by a camera far outside it.
   // Six FMA-class instructions per node, which issue beside the others (profiles/r03_issue_peak.txt).
-  const float kSlack = 4.76837158203125e-7f;
+#ifndef FH_NODE_SLACK
+#define FH_NODE_SLACK 1
+#endif
+  const float kSlack = FH_NODE_SLACK ? 4.76837158203125e-7f : 0.0f;  // (FH_NODE_SLACK=0: timing experiments only)
   const float fx = fmaf(fabsf(ox), kSlack, ox), fy = fmaf(fabsf(oy), kSlack, oy), fz = fmaf(fabsf(oz), kSlack, oz);
   const float nx = fmaf(fabsf(ox), -kSlack, ox), ny = fmaf(fabsf(oy), -kSlack, oy), nz = fmaf(fabsf(oz), -kSlack, oz);
   const float two126 = 8.507059173023462e37f;
@@ -359,6 +362,10 @@ struct GroupStack<true> {
 };
 // dynamic LDS of one 256-thread workgroup whose lanes keep `depth` stack entries there
 FH_HD uint32_t lds_stack_bytes(uint32_t depth) { return (depth * 256u * 5u + 15u) & ~15u; }
+// Entries a traversal stack needs for a tree of `levels` node levels: a group is pushed while the ray descends into one of its nodes with siblings still to
+// visit; the root's group holds the root alone and is never pushed, so the groups that can be on the stack at once are those of levels 1 .. levels - 1.
+// (One entry fewer than levels is 1.25 KB per workgroup: the sixth workgroup per CU on an 11-level tree.)
+FH_HD uint32_t stack_entries_for(uint32_t levels) { return levels < 2u ? 1u : levels - 1u; }
 
 template <bool ANY_HIT, bool COUNT, bool LDS = false, bool ALPHA = false>
 FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws = nullptr, uint2* lds_column = nullptr,

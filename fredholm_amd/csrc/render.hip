@@ -363,6 +363,9 @@ __global__ void __launch_bounds__(kBlock) k_route(SceneDev sc, PoolDev pool, uin
 // paths that leave the scene at depth 0 see the environment directly (pt.cu:504-523)
 __global__ void __launch_bounds__(kBlock) k_miss_primary(FrameDev fr, PoolDev pool)
 {
+  __shared__ HosekSky s_sky;
+  stage_sky(fr, s_sky);
+  __syncthreads();
   const uint32_t count = pool.counters[CNT_RAD];
   const uint32_t* q = pool.q_rad[0];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -832,6 +835,8 @@ template <bool COUNT, bool WIDE, bool LIGHTS, bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
+  __shared__ HosekSky s_sky;  // (light rays that escape see the sky: resolve_light_ray)
+  if (LIGHTS) { stage_sky(fr, s_sky); __syncthreads(); }
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
   constexpr bool has_lights = LIGHTS;
   uint32_t nn = 0, nt = 0, nr = 0;
@@ -881,6 +886,8 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? 5 : 6)) k_trace_
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
   const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  __shared__ HosekSky s_sky;  // (light rays that escape see the sky: resolve_light_ray)
+  if (LIGHTS) { stage_sky(fr, s_sky); __syncthreads(); }
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
   constexpr bool has_lights = LIGHTS;
   uint32_t nn = 0, nt = 0, nr = 0;
@@ -993,12 +1000,14 @@ struct SecondaryStream {
 };
 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
-__global__ void __launch_bounds__(kBlock, COUNT ? 1 : ((LIGHTS || ALPHA) ? FH_SECONDARY_BLOCKS_HEAVY : 6)) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays)
+__global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : 6)) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_SEC];
   if (stream_block_idle(count, min_rays)) return;
+  __shared__ HosekSky s_sky;  // (light rays that escape see the sky: resolve_light_ray)
+  if (LIGHTS) { stage_sky(fr, s_sky); __syncthreads(); }
   const ClockStamp stamp;
   const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
   uint32_t nn = 0, nt = 0;
@@ -1284,7 +1293,7 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.bvh8.tris = ctx->d_bvh8_tris;
   s.bvh8.n_nodes = ctx->bvh8_n_nodes;
   s.bvh8.n_tris = ctx->bvh8_n_tris;
-  s.bvh8.depth = ctx->bvh8_depth < 2u ? 2u : ctx->bvh8_depth;
+  s.bvh8.depth = stack_entries_for(ctx->bvh8_depth);
   s.use_bvh8 = ctx->use_bvh8 ? 1u : 0u;
   return s;
 }
@@ -1507,7 +1516,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   // batches run without the refill machinery (1000-triangle soup: closest 7.4 -> 4.6 ms, secondary 2.6 -> 1.0 ms per 256 spp; even at ~2 K nodes; behind at 20 K)
   const bool stream = coop && tun.stream && (tun.stream_forced || ctx->bvh8_n_nodes >= 4096u);
   // the traversal stack of every lane lives in LDS, one entry per level of the BVH (bvh_build.hip records the depth): no overflow path
-  const uint32_t stack_bytes = lds_stack_bytes(ctx->bvh8_depth < 2u ? 2u : ctx->bvh8_depth);
+  const uint32_t stack_bytes = lds_stack_bytes(stack_entries_for(ctx->bvh8_depth));
   if (sc.use_bvh8 && ctx->lds_configured_bytes != stack_bytes) {  // kernels that may need more than the default 64 KB of LDS are told so once per BVH depth
     const int rc = configure_traversal_lds(ctx, stack_bytes);
     if (rc) return rc;
