@@ -42,6 +42,9 @@ TRI_TEST_SIMD_CYCLES = 177.0   # one wave-level watertight triangle test (fh_tra
 NOMINAL_CLOCK_GHZ = 2.4
 N_SIMDS = 1024
 VALU_FMA_PEAK_PER_CYCLE, VALU_OTHER_PEAK_PER_CYCLE = 1.0 / 2.2, 1.0 / 4.1  # wave64 instructions per cycle and SIMD, by class
+# share of FMA-class instructions (v_fma / v_fmac / v_mul / v_add / v_sub_f32 and their packed forms) among the VALU instructions of the kernels that have no step counters of
+# their own, counted over the code object (tools/isa_stats.py --hist): with the two classes issuing side by side an instruction of such a mix costs max(share x 2.2, (1 - share) x 4.1) cycles
+STATIC_FMA_SHARE = {"k_shade": 0.39, "k_generate": 0.37}
 
 
 def workload(cfg, tmpdir):
@@ -449,6 +452,23 @@ def main():
                     "note": where + "; achieved = (wave-level node tests x 566 + wave-level triangle tests x 177 SIMD cycles) per launch / launch time measured inside the timed region, where passes on the other "
                             "streams share the GPU with the launch; *_alone: the same launch with the GPU to itself (one untimed step with serial passes); algorithmic_* = SURVEY.md 8(d) bytes per ray x rays, "
                             "priced against HBM only for reference -- node and triangle arrays (80 MB) are served by L2 / Infinity Cache, see traffic"}
+        elif pmc_k and pmc_k.get("valu_insts_per_launch") and dom in STATIC_FMA_SHARE and avg_ms > 0:
+            # ---- the shade / generate kernels are VALU-issue-bound as well (software transcendentals, hashing, divisions): executed VALU instructions per launch (counter
+            # run of the same launch size) x the issue cycles an instruction of the kernel's mix costs, against the issue cycles the chip has
+            share = STATIC_FMA_SHARE[dom]
+            cyc = max(share / VALU_FMA_PEAK_PER_CYCLE, (1.0 - share) / VALU_OTHER_PEAK_PER_CYCLE)
+            issue_cycles_per_launch = pmc_k["valu_insts_per_launch"] * cyc
+            achieved = issue_cycles_per_launch / (avg_ms * 1e-3) / 1e9
+            peak = N_SIMDS * NOMINAL_CLOCK_GHZ
+            roof = {"bound": "valu_issue", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "G SIMD issue cycles/s", "frac": round(achieved / peak, 5), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": int(f["launches"]), "avg_launch_ms_alone": round(avg_alone_ms, 4),
+                    "frac_alone": round(issue_cycles_per_launch / (avg_alone_ms * 1e-3) / 1e9 / peak, 5) if avg_alone_ms > 0 else None,
+                    "issue_model": {"valu_insts_per_launch": pmc_k["valu_insts_per_launch"], "fma_class_share": share, "cycles_per_instruction_of_this_mix": round(cyc, 3),
+                                    "source": "SQ_INSTS_VALU of the kernel (" + str(pmc_k.get("file")) + "), class rates from profiles/r03_issue_peak.txt, class share from the code object (tools/isa_stats.py)"},
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_gbs": round(alg_gbs, 1), "frac_algorithmic_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 5),
+                    "measured_hbm_gbs": {"read": round(bw_read, 1), "copy": round(bw_copy, 1)},
+                    "note": where + "; achieved = executed VALU instructions per launch x issue cycles per instruction of the kernel's mix / launch time inside the timed region (passes on the other streams share the "
+                            "GPU with the launch: *_alone is the same launch with the GPU to itself); algorithmic_* = DESIGN.md 4 bytes per hit, for reference"}
         else:
             roof = {"bound": "hbm", "kernel": kernel_name, "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(f["launches"]), "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms_alone": round(avg_alone_ms, 4),

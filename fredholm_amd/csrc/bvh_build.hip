@@ -1157,7 +1157,7 @@ int bvh_build_device(fh_ctx* ctx)
   if (getenv("FH_BVH2")) ctx->use_bvh8 = false;  // developer switch: traverse the binary layout instead of the wide one
   ctx->stats.bvh_nodes = ctx->use_bvh8 ? ctx->bvh8_n_nodes : ctx->bvh2_n_nodes;
   ctx->stats.bvh_node_bytes = ctx->use_bvh8 ? 16ull * kBvh8NodeVec * ctx->bvh8_n_nodes : 64ull * ctx->bvh2_n_nodes;
-  ctx->stats.bvh_tri_bytes = 48ull * (ctx->use_bvh8 ? ctx->bvh8_n_tris : ctx->bvh2_n_tris);
+  ctx->stats.bvh_tri_bytes = ctx->use_bvh8 ? 48ull * 8ull * ctx->bvh8_n_nodes : 48ull * ctx->bvh2_n_tris;  // (wide tree: eight triangle slots per node)
   ctx->stats.bvh_depth = ctx->use_bvh8 ? ctx->bvh8_depth : 0;
   return FH_OK;
 }
