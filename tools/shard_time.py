@@ -14,7 +14,12 @@ for world in WORLDS:
     r.set_resolution(W, H)
     if world > 1:
         r.set_tile_shard(0, world, 32, 32)
-    r.set_path_pool(min(r.owned_pixel_count() * POOL_SPP, 160 * 1024 * 1024))
+    if os.environ.get('BENCH_SIZING') == '1':  # passes as bench.py sizes them: equal passes of at most ~128 spp of a 1080p frame, at least three per step
+        cap = int(1920 * 1080 * 128 * 1.02)
+        passes = max(3, -(-r.owned_pixel_count() * SPP // cap))
+        r.set_path_pool(r.owned_pixel_count() * max(-(-SPP // passes), 1))
+    else:
+        r.set_path_pool(min(r.owned_pixel_count() * POOL_SPP, 160 * 1024 * 1024))
     L = F.RenderLayer(r, W, H)
     cam = F.Camera(**scenes.SOUP_CAMERA)
     for _ in range(3):
