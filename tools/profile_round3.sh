@@ -8,6 +8,7 @@ R=$GRAFT_REPO_ROOT
 B="python3 $R/bench.py --config $cfg"
 $B > $R/gpurun_out/${tag}_bench.json 2> $R/gpurun_out/${tag}_bench.err; echo "bench rc=$?"
 S="--steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+[ "$cfg" -le 2 ] && S="--steps 6 --warmup 2 --no-cpu-baseline --no-extras"   # (short frames: enough of them that the warm-up frame, whose passes still run with the initial switch depth, does not colour the averages)
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -- $B $S > $R/gpurun_out/${tag}_stats.log 2>&1
 find $R/gpurun_out/${tag}_stats -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${tag}_kernel_stats.csv \;
 export FH_PIPELINE=0
