@@ -87,17 +87,30 @@ def apply_environment(x, w):
         x.load_arhosek_sky(*w["sky"])
 
 
+_CHECKER = {}
+
+
+def checker_scene(w):
+    """the CPU checker's scene of this workload (its own BVH build takes seconds on a million triangles: built once for the parity crop and the CPU baseline)"""
+    import ctypes
+    from oracle import pyoracle as O
+
+    if "scene" not in _CHECKER:
+        S = O.Scene(w["scene"])
+        apply_environment(S, w)
+        if w["sun"] is not None and not w["dir_le"]:
+            O.lib().orc_set_directional_light(S.h, 0, None, None, ctypes.c_float(0))  # ... without a directional light (SURVEY.md 8(d) C3)
+        _CHECKER["scene"] = S
+    return _CHECKER["scene"]
+
+
 def cpu_baseline(w, seconds_target=12.0):
     """Time the CPU checker (oracle/, kind "port") on a bounded sample of the SAME workload: whole 1-spp passes of the frame, all host threads.
     Reported next to the GPU number; never the thing measured."""
-    import ctypes
     from fredholm_amd.renderer import Camera
     from oracle import pyoracle as O
 
-    S = O.Scene(w["scene"])
-    apply_environment(S, w)
-    if w["sun"] is not None and not w["dir_le"]:
-        O.lib().orc_set_directional_light(S.h, 0, None, None, ctypes.c_float(0))  # ... without a directional light (SURVEY.md 8(d) C3)
+    S = checker_scene(w)
     cam = Camera(**w["camera"]).params()
     threads = max(1, O.hardware_threads())
     W, H = w["width"], w["height"]
@@ -147,11 +160,7 @@ def parity_block(r, w, cam, layers, bufs, rows, spp):
     r.wait_for_completion()
     y0, y1 = rows
     gpu = bufs["beauty"][y0:y1].cpu().numpy()
-    S = O.Scene(w["scene"])
-    apply_environment(S, w)
-    if w["sun"] is not None and not w["dir_le"]:
-        import ctypes
-        O.lib().orc_set_directional_light(S.h, 0, None, None, ctypes.c_float(0))
+    S = checker_scene(w)
     L = S.new_layers(w["width"], w["height"])
     for _ in range(spp):
         S.render(cam.params(), w["width"], w["height"], L, 1, w["depth"], bg=w["bg"], n_threads=max(1, O.hardware_threads()), rows=rows)
@@ -183,15 +192,16 @@ def latency_block(r, w, cam, layers, frames=(200, 100)):
     return out
 
 
-def pmc_file(cfg):
-    """newest committed counter summary for this configuration (separate rocprofv3 --pmc passes, tools/profile_round3.sh): counters cannot be read from inside this process"""
+def pmc_file(cfg, pool_spp, width, height):
+    """newest committed counter summary for this configuration AND launch size (separate rocprofv3 --pmc passes, tools/profile_round3.sh): counters cannot be read
+    from inside this process, and per-launch counts only describe launches of the samples per pass they were collected with"""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
         try:
             tj = json.load(open(f))
         except Exception:
             continue
-        if tj.get("config", 2) == cfg:
+        if tj.get("config", 2) == cfg and tj.get("spp_per_pass", 128 if cfg == 2 else None) == pool_spp:
             tj["file"] = os.path.relpath(f, ROOT)
             return tj
     return None
@@ -420,7 +430,7 @@ def main():
         avg_ms = f["ms"] / launches
         avg_alone_ms = f["alone"] / max(launches / steps, 1)
         alg_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        pmc = pmc_file(args.config)
+        pmc = pmc_file(args.config, pool_spp, WIDTH, HEIGHT) if world == 1 else None  # (a shard's launches are not the launches the counters saw)
         pmc_k = pmc if (pmc and pmc.get("kernel", "").startswith(dom)) else None  # the dominant kernel's own counters
         traffic = pmc_k.get("traffic_bytes_per_launch") if pmc_k else None
         kernel_name = dom.replace("_stream", "_coop") if dom.startswith("k_trace") and small_tree else dom

@@ -225,6 +225,41 @@ def test_two_rank_bench_step_gathers_the_unsharded_frame(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and "gather" in out["config"]["gather"]
 
 
+@pytest.mark.parametrize("cfg,spp", [(1, 8), (2, 12)])
+def test_bench_line_contract(tmp_path, cfg, spp):
+    """one short run of bench.py per kind of dominant kernel (shade on the Cornell box, traversal on the soup): ONE JSON line with the metric, the roofline record
+    (no fraction above 1, a bound that is named, launch times from HIP events), parity against the checker (bit-identical crop), the small-launch latencies and the
+    whole-frame figures"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", str(cfg), "--spp", str(spp), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "parity", "latency", "whole_frame", "rates"):
+        assert k in out, k
+    assert out["unit"] == "Msamples/s" and out["n_gpus"] == 1 and out["steps"] == 2 and out["dtype"] == "f32" and out["vs_baseline"] is None and "workload" in out["config"]
+    assert abs(out["value"] - 1920 * 1080 * spp / (out["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * out["value"]
+    r = out["roofline"]
+    assert r["bound"] in ("valu_issue", "hbm") and r["unit"] in ("G SIMD issue cycles/s", "GB/s") and r["peak"] > 0 and r["avg_launch_ms"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    for k, v in r.items():
+        if k.startswith("frac") and v is not None:
+            assert 0.0 <= v <= 1.0, (k, v)
+    if cfg == 2:
+        assert r["bound"] == "valu_issue" and r["kernel"].startswith("k_trace") and 1.0 < r["clock_ghz_in_kernel"] < 2.6
+        assert 0.0 < r["lane_utilisation"]["node_tests"] <= 1.0 and 0.0 < r["lane_utilisation"]["triangle_tests"] <= 1.0
+    p = out["parity"]
+    assert p["rmse"] == 0.0 and p["bit_identical_pixels"] == 1.0 and p["pixels"] == 8 * 1920
+    lat = out["latency"]
+    assert 0.0 < lat["spp1"]["min_ms"] <= lat["spp1"]["median_ms"] < lat["spp16"]["median_ms"] * 4
+
+
 def test_rccl_leg_on_two_gpus(tmp_path):
     """The RCCL leg itself -- dist.init_process_group("nccl", device_id=...) and dist.gather of device tensors, bench.py's N > 1 path as the driver's multi-GPU run
     takes it -- needs one GPU per rank: runs wherever two or more are visible (the one-GPU boxes of the development pool skip it; the two-rank test above covers
