@@ -80,16 +80,20 @@ FH_D bool tri_test(const RayPre& r, f3 p0, f3 p1, f3 p2, float& t, float& bu, fl
 
 struct HitRec { float t, u, v; uint32_t prim; };
 
-// conservative slab test against (lo, hi); returns entry distance in tn
+// conservative slab test against (lo, hi); returns entry distance in tn.  Every plane distance is moved by 2^-21 of itself to the safe side (entries earlier,
+// exits later): (p - o) * inv carries a rounding error of 2^-24 of |p - o| per axis, which for a ray that starts far outside the box is more than the box's padding
 FH_D bool slab_test(const RayPre& r, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmax, float& tn)
 {
+  const float k = 4.76837158203125e-7f;
   float t0 = (lox - r.o.x) * r.inv.x, t1 = (hix - r.o.x) * r.inv.x;
-  float tnr = fminf(t0, t1), tf = fmaxf(t0, t1);
+  float n = fminf(t0, t1), f = fmaxf(t0, t1);
+  float tnr = fmaf(fabsf(n), -k, n), tf = fmaf(fabsf(f), k, f);
   t0 = (loy - r.o.y) * r.inv.y; t1 = (hiy - r.o.y) * r.inv.y;
-  tnr = fmaxf(tnr, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  n = fminf(t0, t1); f = fmaxf(t0, t1);
+  tnr = fmaxf(tnr, fmaf(fabsf(n), -k, n)); tf = fminf(tf, fmaf(fabsf(f), k, f));
   t0 = (loz - r.o.z) * r.inv.z; t1 = (hiz - r.o.z) * r.inv.z;
-  tnr = fmaxf(tnr, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-  tf *= 1.000001f;
+  n = fminf(t0, t1); f = fmaxf(t0, t1);
+  tnr = fmaxf(tnr, fmaf(fabsf(n), -k, n)); tf = fminf(tf, fmaf(fabsf(f), k, f));
   tn = tnr;
   return tnr <= tf && tf >= 0.0f && tnr <= tmax;
 }
