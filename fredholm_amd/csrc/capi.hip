@@ -412,6 +412,8 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_off("FH_SORT_SMALL", t.sort_small);
     env_uint("FH_STREAM_CHUNK", 16, 65535, t.stream_chunk);
     t.stream_chunk_fixed = getenv("FH_STREAM_CHUNK") != nullptr;
+    if (t.stream_chunk_fixed) t.stream_chunk_closest = t.stream_chunk;  // (FH_STREAM_CHUNK alone sets both launches)
+    env_uint("FH_STREAM_CHUNK_CLOSEST", 16, 65535, t.stream_chunk_closest);
     env_uint("FH_TAIL_DEPTH", 0, 64, t.tail_depth);
     env_uint("FH_TAIL_PATHS", 64, 1 << 30, t.tail_paths);
     env_off("FH_SORT", t.sort_queues);

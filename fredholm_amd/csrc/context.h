@@ -140,6 +140,9 @@ struct fh_ctx {
     bool sort_small = false;        // FH_SORT_SMALL=1: cell-order the bounce queues of trees the fixed-batch kernels trace as well
     uint32_t stream_chunk = 64;     // FH_STREAM_CHUNK: queue entries a wave takes per global atomic (setting it also switches the adaptive maximum off)
     bool stream_chunk_fixed = false;
+    uint32_t stream_chunk_closest = 128; // FH_STREAM_CHUNK_CLOSEST: the same for the closest-hit launch (0 = stream_chunk).  Its queue is in cell order, so a longer run of it is a more coherent
+                                         // wave: 64 / 96 / 128 / 192 / 256 / 512 entries measure 78.5 / 74.0 / 74.2 / 75.7 / 76.7 / 84.1 ms per configs[2] frame; configs[4] 2795 -> 2559 ms.  (The secondary launch,
+                                         // whose items are whole paths with two to four rays each, loses with more than 64: 113.9 -> 115.7 ms at 128)
     uint32_t tail_depth = 0;        // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail
     uint32_t tail_paths = 0;        // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail; 0 = 65536, 131072 for passes of at most 4 Mi paths on trees the streaming kernels trace
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order

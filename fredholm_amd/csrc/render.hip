@@ -1551,6 +1551,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   // (rays through a small tree are cheap enough to run into the atomic rate of the work cursor: allow larger chunks there, stream_chunk_for)
   const uint32_t chunk_max = tun.stream_chunk_fixed ? tun.stream_chunk : (ctx->bvh8_n_nodes < 512u ? 256u : (ctx->bvh8_n_nodes < 4096u ? 128u : tun.stream_chunk));
   const uint32_t stream_refill = tun.stream_refill, stream_chunk = (tun.stream_chunk & 0xffffu) | ((chunk_max > tun.stream_chunk ? chunk_max : 0u) << 16);
+  // (the closest-hit launch takes its own chunk size, FH_STREAM_CHUNK_CLOSEST)
+  const uint32_t chunk_closest = tun.stream_chunk_closest ? tun.stream_chunk_closest : tun.stream_chunk;
+  const uint32_t stream_chunk_closest = (chunk_closest & 0xffffu) | ((chunk_max > chunk_closest ? chunk_max : 0u) << 16);
   const uint32_t env_tail_depth = tun.tail_depth;
   // cell-ordered queues pay where rays of one cell share the nodes they fetch; a tree the fixed-batch kernels trace (under 4096 nodes) sits in the caches whatever
   // the order, and there the six sort launches per bounce are what a small frame waits for (Cornell box, 1 spp: 0.33 of 2.15 ms)
@@ -1627,7 +1630,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), stack_bytes, st, sc, pd, depth, tc_closest,
-                               coop_flush, stream_refill, stream_chunk, tun.stream_min_rays);
+                               coop_flush, stream_refill, stream_chunk_closest, tun.stream_min_rays);
           }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
