@@ -1427,6 +1427,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   uint32_t target = ctx->pool_target > ctx->n_owned ? ctx->pool_target : ctx->n_owned;
   uint32_t batch = target / ctx->n_owned;
   if (batch > n_samples) batch = n_samples;
+  if (batch > 65535u) batch = 65535u;  // (k_generate's grid has one row per sample of the pass)
   if (batch < 1) batch = 1;
 
   FrameDev fr{};

@@ -296,6 +296,29 @@ def test_rays_from_far_outside_the_scene_match_checker(oracle, n_tris, edge, n):
     r.close()
 
 
+def test_many_samples_of_a_tiny_frame_in_one_call():
+    """a 4 x 3 frame with 70 000 samples in ONE fh_render: the default pool would hold all of them in one pass, but k_generate's grid has one row per sample of
+    a pass (at most 65 535), so the call is split -- and has to give the bits of the same samples rendered 1000 at a time"""
+    sc = scenes.cornell_box()
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    w, h, n = 4, 3, 70000
+    out = []
+    for chunk in (n, 1000):
+        r = F.Renderer(0)
+        r.load_scene(sc)
+        r.build_ias()
+        r.set_resolution(w, h)
+        L = F.RenderLayer(r, w, h)
+        for _ in range(n // chunk):
+            r.render(cam, (0.0, 0.0, 0.0), L, chunk, 3)
+        r.wait_for_completion()
+        out.append({k: L.download(k) for k in F.RenderLayer.NAMES})
+        r.close()
+    for k in F.RenderLayer.NAMES:
+        assert np.array_equal(_bits(out[0][k]), _bits(out[1][k])), k
+    assert np.isfinite(out[0]["beauty"]).all() and out[0]["beauty"][..., :3].mean() > 0.01
+
+
 def test_degenerate_and_coplanar_triangles(oracle):
     sc = scenes.cornell_box()
     v = sc["vertices"].copy()
