@@ -1033,7 +1033,10 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
 // (trace -> shade -> secondary rays -> Russian roulette), so slow rays of different paths overlap
 // instead of adding up.  Same device functions, same per-path operation order as the wavefront
 // kernels, hence the same bits.
-__global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth, uint32_t coop_flush)
+// One instantiation per lobe set, like k_shade: the generic seven-lobe form needs 430 registers (one wave per SIMD, so the 128 Ki paths a small pass hands over took two
+// rounds), the forms for the lobe sets real scenes have fit two waves per SIMD.
+template <uint32_t LOBES>
+__global__ void __launch_bounds__(kBlock, LOBES == L_ALL ? 1 : 2) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth, uint32_t coop_flush)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // traversal stack of every lane ([entry][thread], as in the streaming kernels): a private array lands in scratch
   __shared__ __attribute__((aligned(16))) unsigned char lds_coop[(kBlock / 64) * kCoopLdsBytesPerWave];
@@ -1096,7 +1099,7 @@ __global__ void __launch_bounds__(kBlock) k_tail(SceneDev sc, FrameDev fr, PoolD
       ShadeOut o;
       if (alive) {
         if (!hit) alive = false;  // pt.cu:504-523 with firsthit == false: nothing added
-        else shade_hit<L_ALL>(sc, fr, rows, bs, depth, make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)), rd, T, L, image_idx, n_spp, o);
+        else shade_hit<LOBES>(sc, fr, rows, bs, depth, make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)), rd, T, L, image_idx, n_spp, o);
       }
       // secondary rays in the reference's order (one call per slot: the slot index has to be a constant for the rays to stay in registers)
       auto secondary = [&](auto slot_c) {
@@ -1403,7 +1406,10 @@ int configure_traversal_lds(fh_ctx* ctx, uint32_t stack_bytes)
             set((const void*)k_trace_secondary_static<decltype(C)::value, false, decltype(Li)::value, decltype(A)::value>);
           });
       }); });
-  set((const void*)k_tail);
+  set((const void*)k_tail<L_DIFF>);
+  set((const void*)k_tail<L_METAL | L_SPEC | L_DIFF>);
+  set((const void*)k_tail<L_COAT | L_METAL | L_SPEC | L_DIFF>);
+  set((const void*)k_tail<L_ALL>);
   if (err != hipSuccess) return fail(ctx, FH_E_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(err));
   ctx->lds_configured_bytes = stack_bytes;
   ctx->lds_static_max = max_static;
@@ -1694,7 +1700,14 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     }
     if (wave_depth < max_depth) {
       Span sp(ctx, st, 3);
-      hipLaunchKernelGGL(k_tail, dim3(grid_for(n_paths / 16 + 1)), dim3(kBlock), sc.use_bvh8 ? stack_bytes : 0u, st, sc, fr, pd, wave_depth, coop ? coop_flush : 0u);
+      uint32_t lobes = 0;  // every lobe a material of the scene can have: the tail shades all classes in one kernel
+      for (uint32_t c = 0; c < ctx->n_classes; ++c) lobes |= ctx->class_lobes[c];
+      const dim3 tg(grid_for(n_paths / 16 + 1)), tb(kBlock);
+      const uint32_t tl = sc.use_bvh8 ? stack_bytes : 0u, tf = coop ? coop_flush : 0u;
+      if ((lobes & ~(uint32_t)L_DIFF) == 0) hipLaunchKernelGGL(k_tail<L_DIFF>, tg, tb, tl, st, sc, fr, pd, wave_depth, tf);
+      else if ((lobes & ~(uint32_t)(L_METAL | L_SPEC | L_DIFF)) == 0) hipLaunchKernelGGL((k_tail<L_METAL | L_SPEC | L_DIFF>), tg, tb, tl, st, sc, fr, pd, wave_depth, tf);
+      else if ((lobes & ~(uint32_t)(L_COAT | L_METAL | L_SPEC | L_DIFF)) == 0) hipLaunchKernelGGL((k_tail<L_COAT | L_METAL | L_SPEC | L_DIFF>), tg, tb, tl, st, sc, fr, pd, wave_depth, tf);
+      else hipLaunchKernelGGL(k_tail<L_ALL>, tg, tb, tl, st, sc, fr, pd, wave_depth, tf);
       ctx->stats.n_tail_launches++;
     }
     if (prev != slot && ctx->acc_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[prev], 0));
