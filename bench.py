@@ -14,7 +14,9 @@ un-permutation into the frame.  For N > 1 the frame is sharded by interleaved 32
     python bench.py --gpus 1 --steps 16 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0: the metric, `roofline` (what binds the dominant kernel: VALU issue, priced with measured issue ceilings; the SURVEY 8(d) bytes beside it),
+`cpu_baseline` / `cpu_baseline_1t` (the CPU checker on the host cores), and -- N = 1 -- `parity` (a crop of the frame against the checker), `latency` (1-spp and 16-spp calls)
+and `whole_frame`; DESIGN.md 5 describes every field.
 """
 import argparse
 import json
@@ -214,7 +216,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4), help="BASELINE.json configs[] index (default 2: the configuration the metric is quoted on)")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step; 0 = the configuration's (one fh_render call = one presented frame)")
-    ap.add_argument("--pool-spp", type=int, default=0, help="samples per pixel per pass of the path pool; 0 = equal passes of at most ~64 spp of a 1080p frame, at least two per step")
+    ap.add_argument("--pool-spp", type=int, default=0, help="samples per pixel per pass of the path pool; 0 = equal passes of at most ~128 spp of a 1080p frame and 3/4 of the free device memory, at least three per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras of the N = 1 line (parity crop, small-launch latency)")
     ap.add_argument("--check-frame", action="store_true", help="N > 1: rank 0 re-renders the whole frame unsharded and compares it bit for bit with the gathered one")
