@@ -481,16 +481,19 @@ FH_D void coop_test(const Bvh8Dev& bvh, const CoopLds& cl, uint32_t e, uint32_t&
   if (cl.key[owner] == mine) cl.uv[owner] = make_float2(bu, bv);
 }
 
-template <bool ANY_HIT, bool COUNT, bool LDS, bool ALPHA>
-FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws, const CoopLds& cl,
-                             uint32_t flush, uint2* lds_column, int lds_stride, const SceneDev* sc)
+// MODE 0: every ray wants its closest hit; 1: every ray stops at its first hit; 2: per lane (`any_lane`), as in the streaming kernels
+template <int MODE, bool COUNT, bool LDS, bool ALPHA>
+FH_D bool traverse_bvh8_coop_mode(const Bvh8Dev& bvh, bool valid, bool any_lane, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws, const CoopLds& cl,
+                                  uint32_t flush, uint2* lds_column, int lds_stride, const SceneDev* sc)
 {
+  constexpr bool ANY_HIT = MODE != 0;  // (the triangle tests look at the ray's own flag)
+  const bool any = MODE == 2 ? any_lane : MODE == 1;
   const uint32_t lane = __lane_id();
   if (!valid) { o = mk3(0.0f); d = mk3(0.0f, 0.0f, 1.0f); tmax = 0.0f; }
   const RayPre rp = ray_prepare(o, d);
   const Ray8 r = ray8_prepare(rp, d);
   cl.ray[lane] = make_float4(rp.o.x, rp.o.y, rp.o.z, rp.Sx);
-  cl.ray[64 + lane] = make_float4(rp.Sy, rp.Sz, __uint_as_float((uint32_t)rp.kx | ((uint32_t)rp.ky << 2) | ((uint32_t)rp.kz << 4)), ANY_HIT ? 1.0f : 0.0f);
+  cl.ray[64 + lane] = make_float4(rp.Sy, rp.Sz, __uint_as_float((uint32_t)rp.kx | ((uint32_t)rp.ky << 2) | ((uint32_t)rp.kz << 4)), any ? 1.0f : 0.0f);
   const unsigned long long key0 = ((unsigned long long)__float_as_uint(tmax) << 32) | 0xffffffffull;
   cl.key[lane] = key0;
   cl.uv[lane] = make_float2(0.0f, 0.0f);
@@ -508,7 +511,7 @@ FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float t
     if (!done) {
       const unsigned long long k = cl.key[lane];
       best_t = __uint_as_float((uint32_t)(k >> 32));
-      if (ANY_HIT && (uint32_t)k != 0xffffffffu) done = true;
+      if (ANY_HIT && any && (uint32_t)k != 0xffffffffu) done = true;
     }
     if (!done) {
       const uint32_t hits_imask = group.y;
@@ -558,6 +561,12 @@ FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float t
   best.u = uv.x; best.v = uv.y;
   best.prim = (uint32_t)k;
   return valid && best.prim != 0xffffffffu;
+}
+template <bool ANY_HIT, bool COUNT, bool LDS, bool ALPHA>
+FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float tmax, HitRec& best, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws, const CoopLds& cl,
+                             uint32_t flush, uint2* lds_column, int lds_stride, const SceneDev* sc)
+{
+  return traverse_bvh8_coop_mode<ANY_HIT ? 1 : 0, COUNT, LDS, ALPHA>(bvh, valid, ANY_HIT, o, d, tmax, best, n_nodes, n_tris, ws, cl, flush, lds_column, lds_stride, sc);
 }
 
 // A wave's share of a work queue: chunks of `chunk` consecutive entries taken from a global cursor.  All members are wave-uniform.

@@ -1035,27 +1035,76 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
 // kernels, hence the same bits.
 // One instantiation per lobe set, like k_shade: the generic seven-lobe form needs 430 registers (one wave per SIMD, so the 128 Ki paths a small pass hands over took two
 // rounds), the forms for the lobe sets real scenes have fit two waves per SIMD.
+//
+// The rays of a bounce are traced PACKED.  A path in the tail has up to five rays per bounce -- its secondary rays and, once it is shaded, the closest-hit ray of the
+// NEXT bounce, which depends on none of them -- and by its third bounce most lanes of a wave have no path left.  Traced one kind after the other, each kind costs the wave its
+// longest ray (~1 us per dependent step with the SIMD to itself), three to five times per bounce; instead all rays of the wave are numbered (kind by kind, lane by lane:
+// ballot + popcount), staged in LDS 64 at a time, traced by whichever lanes the numbering gives them to -- each ray stops at its first hit or not as its kind says -- and the
+// results go back to their owners through LDS.  The additions into a path's radiance stay in the reference's order (they are applied from the returned results, slot by slot), so
+// the bits do not change; the chain of a bounce is one traversal and one shade instead of three traversals and one shade once a wave is sparse.
+constexpr uint32_t kTailRays = SEC_COUNT + 1u;  // the secondary-ray slots and the next bounce's closest-hit ray
+static_assert(kTailRays == 5u, "trace_all spells its per-lane fallback out ray by ray");
+__device__ __attribute__((noinline)) bool tail_trace_lane(const SceneDev& sc, uint2* lds_stack, bool any, f3 o, f3 d, float tmax, HitRec& h)
+{
+  uint32_t a = 0, b = 0;
+  if (!sc.use_bvh8) return any ? traverse<true, false>(sc, o, d, tmax, h, a, b) : traverse<false, false>(sc, o, d, tmax, h, a, b);
+  if (sc.has_alpha) return any ? traverse_bvh8<true, false, true, true>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc)
+                               : traverse_bvh8<false, false, true, true>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc);
+  return any ? traverse_bvh8<true, false, true, false>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc)
+             : traverse_bvh8<false, false, true, false>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc);
+}
+struct TailRay { bool has = false; bool any = true; f3 o, d; float tmax = 0.0f; HitRec h; bool hit = false; };
+
 template <uint32_t LOBES>
 __global__ void __launch_bounds__(kBlock, LOBES == L_ALL ? 1 : 2) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth, uint32_t coop_flush)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // traversal stack of every lane ([entry][thread], as in the streaming kernels): a private array lands in scratch
   __shared__ __attribute__((aligned(16))) unsigned char lds_coop[(kBlock / 64) * kCoopLdsBytesPerWave];
+  __shared__ float4 s_in[kBlock / 64][2][64];  // one round of packed rays of a wave: (origin, tmax), (direction, stops at its first hit)
+  __shared__ float4 s_out[kBlock / 64][64];    // and their hits: t, u, v, face id bits
   const CoopLds cl = coop_lds(lds_coop, threadIdx.x >> 6);
-  // One ray per lane through the scene, called by all 64 lanes of a wave together (lanes without a ray pass valid = false).  The wide tree is walked with
-  // wave-cooperative triangle tests (coop_flush != 0; fh_trace.h: traverse_bvh8_coop): in a per-lane loop nearly every step of a wave ran one to three triangle tests
-  // for a handful of lanes, and a wave that has its SIMD to itself issues an instruction every five cycles however few lanes want it -- the tail of a 1-spp
-  // 1080p frame of the 1 M-triangle scene took 1.46 of the frame's 3.0 ms.  Tiny scenes (binary tree) and FH_COOP=0 keep the per-lane loops.
-  auto trace = [&](auto any_hit, bool valid, f3 o, f3 d, float tmax, HitRec& h) -> bool {
-    constexpr bool ANY = decltype(any_hit)::value;
-    uint32_t a = 0, b = 0;
-    if (sc.use_bvh8 && coop_flush) {
-      if (sc.has_alpha) return traverse_bvh8_coop<ANY, false, true, true>(sc.bvh8, valid, o, d, tmax, h, a, b, nullptr, cl, coop_flush, lds_stack, (int)sc.bvh8.depth, &sc);
-      return traverse_bvh8_coop<ANY, false, true, false>(sc.bvh8, valid, o, d, tmax, h, a, b, nullptr, cl, coop_flush, lds_stack, (int)sc.bvh8.depth, &sc);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const bool coop = sc.use_bvh8 && coop_flush != 0u;
+  // all rays of the wave (called by its 64 lanes together)
+  auto trace_all = [&](TailRay (&rays)[kTailRays]) {
+    if (!coop) {  // one ray per lane, per-lane loops: tiny scenes (binary tree) and FH_COOP=0 (an out-of-line call per ray: five inlined copies of every traversal would be most of the kernel)
+      HitRec t;  // (only this one has its address taken: the rays themselves stay in registers)
+      if (rays[0].has) { rays[0].hit = tail_trace_lane(sc, lds_stack, rays[0].any, rays[0].o, rays[0].d, rays[0].tmax, t); rays[0].h = t; }
+      if (rays[1].has) { rays[1].hit = tail_trace_lane(sc, lds_stack, rays[1].any, rays[1].o, rays[1].d, rays[1].tmax, t); rays[1].h = t; }
+      if (rays[2].has) { rays[2].hit = tail_trace_lane(sc, lds_stack, rays[2].any, rays[2].o, rays[2].d, rays[2].tmax, t); rays[2].h = t; }
+      if (rays[3].has) { rays[3].hit = tail_trace_lane(sc, lds_stack, rays[3].any, rays[3].o, rays[3].d, rays[3].tmax, t); rays[3].h = t; }
+      if (rays[4].has) { rays[4].hit = tail_trace_lane(sc, lds_stack, rays[4].any, rays[4].o, rays[4].d, rays[4].tmax, t); rays[4].h = t; }
+      return;
     }
-    if (!valid) return false;
-    if (!sc.use_bvh8) return traverse<ANY, false>(sc, o, d, tmax, h, a, b);
-    if (sc.has_alpha) return traverse_bvh8<ANY, false, true, true>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc);
-    return traverse_bvh8<ANY, false, true, false>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc);
+    uint32_t idx[kTailRays], total = 0;  // position of this lane's ray of kind k among the wave's rays; total: wave-uniform
+#pragma unroll
+    for (uint32_t k = 0; k < kTailRays; ++k) {
+      const unsigned long long m = __ballot(rays[k].has);
+      idx[k] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      total += (uint32_t)__popcll(m);
+    }
+    for (uint32_t lo = 0; lo < total; lo += 64u) {
+#pragma unroll
+      for (uint32_t k = 0; k < kTailRays; ++k)
+        if (rays[k].has && idx[k] - lo < 64u) {
+          s_in[wave][0][idx[k] - lo] = mk4(rays[k].o, rays[k].tmax);
+          s_in[wave][1][idx[k] - lo] = mk4(rays[k].d, rays[k].any ? 1.0f : 0.0f);
+        }
+      const bool valid = lo + lane < total;
+      const float4 a = valid ? s_in[wave][0][lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = valid ? s_in[wave][1][lane] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+      HitRec h;
+      uint32_t na = 0, nb = 0;
+      if (sc.has_alpha) traverse_bvh8_coop_mode<2, false, true, true>(sc.bvh8, valid, b.w != 0.0f, mk3(a), mk3(b), a.w, h, na, nb, nullptr, cl, coop_flush, lds_stack, (int)sc.bvh8.depth, &sc);
+      else traverse_bvh8_coop_mode<2, false, true, false>(sc.bvh8, valid, b.w != 0.0f, mk3(a), mk3(b), a.w, h, na, nb, nullptr, cl, coop_flush, lds_stack, (int)sc.bvh8.depth, &sc);
+      if (valid) s_out[wave][lane] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+#pragma unroll
+      for (uint32_t k = 0; k < kTailRays; ++k)
+        if (rays[k].has && idx[k] - lo < 64u) {
+          const float4 r = s_out[wave][idx[k] - lo];
+          rays[k].h.t = r.x; rays[k].h.u = r.y; rays[k].h.v = r.z; rays[k].h.prim = __float_as_uint(r.w);
+          rays[k].hit = rays[k].h.prim != 0xffffffffu;
+        }
+    }
   };
   __shared__ SobolRows<4> rows;
   __shared__ float s_lut[kLutReflFloats + kLutSheenFloats];  // as in k_shade: small tables every hit reads live in LDS
@@ -1088,41 +1137,46 @@ __global__ void __launch_bounds__(kBlock, LOBES == L_ALL ? 1 : 2) k_tail(SceneDe
       ro = mk3(o); rd = mk3(pool.ray_d[p]); T = mk3(pool.thr[p]); L = mk3(pool.rad[p]);
       image_idx = pool.pixel[p]; n_spp = pool.nspp[p];
     }
+    // the closest hit of the first bounce; every later one comes back with the rays of the bounce before it
+    HitRec h;
+    bool hit = false;
+    {
+      TailRay rays[kTailRays];
+      rays[SEC_COUNT].has = alive; rays[SEC_COUNT].any = false; rays[SEC_COUNT].o = ro; rays[SEC_COUNT].d = rd; rays[SEC_COUNT].tmax = 1e9f;
+      trace_all(rays);
+      h = rays[SEC_COUNT].h; hit = rays[SEC_COUNT].hit;
+    }
     for (uint32_t depth = first_depth; depth < fr.max_depth; ++depth) {
       BounceSlots bs;
       bs.set(fr, sc.n_lights, depth);
       __syncthreads();  // rows of the previous bounce are no longer read
       bs.load_rows(rows, fr.sobol_bytes);
       if (__ballot(alive) == 0ull) continue;  // (wave-uniform; the barriers above are still met)
-      HitRec h;
-      const bool hit = trace(std::false_type{}, alive, ro, rd, 1e9f, h);
       ShadeOut o;
       if (alive) {
         if (!hit) alive = false;  // pt.cu:504-523 with firsthit == false: nothing added
         else shade_hit<LOBES>(sc, fr, rows, bs, depth, make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)), rd, T, L, image_idx, n_spp, o);
       }
-      // secondary rays in the reference's order (one call per slot: the slot index has to be a constant for the rays to stay in registers)
-      auto secondary = [&](auto slot_c) {
-        constexpr uint32_t slot = decltype(slot_c)::value;
-        if (slot == SEC_DIR && !fr.has_dir) return;
-        if (slot == SEC_AREA && !has_lights) return;
-        const bool valid = alive && o.sec[slot].active;
-        if (__ballot(valid) == 0ull) return;
-        HitRec sh;
-        if (slot == SEC_LIGHT && has_lights) {
-          const bool lhit = trace(std::false_type{}, valid, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh);
-          if (valid) L += resolve_light_ray(sc, fr, o.lp_T, o.lp_cos, o.lp_f, o.lp_pdf, o.sec[slot].o, o.sec[slot].d, lhit, sh);
-        } else {
-          const bool occluded = trace(std::true_type{}, valid, o.sec[slot].o, o.sec[slot].d, o.sec[slot].tmax, sh);
-          if (valid && !occluded) L += o.sec[slot].c;
-        }
-      };
-      secondary(std::integral_constant<uint32_t, SEC_DIR>{});
-      secondary(std::integral_constant<uint32_t, SEC_SKY>{});
-      secondary(std::integral_constant<uint32_t, SEC_AREA>{});
-      secondary(std::integral_constant<uint32_t, SEC_LIGHT>{});
+      TailRay rays[kTailRays];
+#pragma unroll
+      for (uint32_t slot = SEC_DIR; slot <= SEC_LIGHT; ++slot) {
+        if (slot == SEC_DIR && !fr.has_dir) continue;
+        if (slot == SEC_AREA && !has_lights) continue;
+        rays[slot].has = alive && o.sec[slot].active;
+        rays[slot].any = !(slot == SEC_LIGHT && has_lights);
+        rays[slot].o = o.sec[slot].o; rays[slot].d = o.sec[slot].d; rays[slot].tmax = o.sec[slot].tmax;
+      }
+      rays[SEC_COUNT].has = alive && o.cont; rays[SEC_COUNT].any = false; rays[SEC_COUNT].o = o.next_o; rays[SEC_COUNT].d = o.next_d; rays[SEC_COUNT].tmax = 1e9f;
+      trace_all(rays);
+      // secondary rays in the reference's order
+#pragma unroll
+      for (uint32_t slot = SEC_DIR; slot <= SEC_LIGHT; ++slot) {
+        if (!rays[slot].has) continue;
+        if (slot == SEC_LIGHT && has_lights) L += resolve_light_ray(sc, fr, o.lp_T, o.lp_cos, o.lp_f, o.lp_pdf, o.sec[slot].o, o.sec[slot].d, rays[slot].hit, rays[slot].h);
+        else if (!rays[slot].hit) L += o.sec[slot].c;
+      }
       if (alive) {
-        if (o.cont) { ro = o.next_o; rd = o.next_d; T = o.T; }
+        if (o.cont) { rd = o.next_d; T = o.T; h = rays[SEC_COUNT].h; hit = rays[SEC_COUNT].hit; }
         else alive = false;
       }
     }
