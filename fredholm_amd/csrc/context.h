@@ -144,7 +144,7 @@ struct fh_ctx {
                                          // wave: 64 / 96 / 128 / 192 / 256 / 512 entries measure 78.5 / 74.0 / 74.2 / 75.7 / 76.7 / 84.1 ms per configs[2] frame; configs[4] 2795 -> 2559 ms.  (The secondary launch,
                                          // whose items are whole paths with two to four rays each, loses with more than 64: 113.9 -> 115.7 ms at 128)
     uint32_t tail_depth = 0;        // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail
-    uint32_t tail_paths = 0;        // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail; 0 = 65536, 131072 for passes of at most 4 Mi paths on trees the streaming kernels trace
+    uint32_t tail_paths = 0;        // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail; 0 = 65536, 262144 for passes of at most 4 Mi paths
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
     bool debug_tail = false;        // FH_DEBUG_TAIL
     bool force_alpha = false;       // FH_FORCE_ALPHA=1 (timing experiments): the kernels with the any-hit path compiled in, whatever the scene

@@ -1652,10 +1652,11 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     // bounces run as bounce-synchronous wavefront kernels; the survivors are finished by k_tail.  Adaptive mode picks the
     // first depth at which an earlier pass had at most kTailPaths survivors (counts come from an asynchronous snapshot of
     // the device counters: no host/device synchronisation)
-    // (a wavefront bounce of a big tree costs two streaming launches, each as long as its longest ray whatever the number of rays: 0.5 ms on the 1 M-triangle scene
-    // against 0.25 ms for a bounce inside the fused tail, so in a small pass the tail takes over earlier there -- 1-spp 1080p frame 3.02 -> 2.73 ms; in a big pass the
-    // tail runs next to the streaming launches of the passes in flight, one wave per SIMD against their six, and twice the paths cost configs[2] 1.3 %)
-    const uint32_t kTailPaths = tun.tail_paths ? tun.tail_paths : ((stream && n_paths <= (1u << 22)) ? 131072u : 65536u);
+    // (a wavefront bounce costs two traversal launches, each as long as its longest ray whatever the number of rays, and a dozen small launches: 0.5 ms on the
+    // 1 M-triangle scene against 0.14 ms for a bounce inside the fused tail, so in a small pass the tail takes over earlier -- 1-spp 1080p frames: configs[2] 3.02 -> 2.73 ms
+    // at 128 Ki, configs[1] 1.90 -> 1.77 ms at 256 Ki; in a big pass the tail runs next to the streaming launches of the passes in flight, two waves per SIMD
+    // against their six, and more paths in it cost 0-1 %)
+    const uint32_t kTailPaths = tun.tail_paths ? tun.tail_paths : (n_paths <= (1u << 22) ? 262144u : 65536u);
     for (int k = 0; k < 3; ++k) {
       if (!(ctx->counters_in_flight[k] && hipEventQuery(ctx->ev_counters[k]) == hipSuccess)) continue;
       ctx->counters_in_flight[k] = false;
