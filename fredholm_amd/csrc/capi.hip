@@ -410,6 +410,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_STREAM_REFILL", 1, 64, t.stream_refill);
     env_uint("FH_STREAM_MIN_RAYS", 0, 65535, t.stream_min_rays);
     env_off("FH_SORT_SMALL", t.sort_small);
+    env_off("FH_OVERLAP", t.overlap_secondary);
     env_uint("FH_STREAM_CHUNK", 16, 65535, t.stream_chunk);
     t.stream_chunk_fixed = getenv("FH_STREAM_CHUNK") != nullptr;
     if (t.stream_chunk_fixed) t.stream_chunk_closest = t.stream_chunk;  // (FH_STREAM_CHUNK alone sets both launches)
@@ -441,6 +442,7 @@ int fh_ctx_destroy(fh_ctx* ctx)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (auto e : ctx->ev_bounce) (void)hipEventDestroy(e);
   for (int k = 0; k < 3; ++k) {
     if (ctx->h_counters[k]) (void)hipHostFree(ctx->h_counters[k]);
     (void)hipEventDestroy(ctx->ev_counters[k]);

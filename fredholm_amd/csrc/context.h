@@ -120,6 +120,7 @@ struct fh_ctx {
   bool gen_valid[3] = {false, false, false}, acc_valid[3] = {false, false, false};
   int n_slots = 3;  // passes in flight (FH_PIPELINE=0: 1, every pass on the main stream; =2: two).  Three against two: +2.3 % on configs[2], +0.3-0.9 % on the others, one more path pool
   int last_slot_used = 0;  // slot of the pass submitted last (what the next pass orders itself after)
+  std::vector<hipEvent_t> ev_bounce;  // single-pass calls: (shade done, secondary done) per bounce, for the secondary launch on a second stream (render.hip)
   // FH_FLAG_REFERENCE_FIRSTHIT (render.hip: k_firsthit_scan): per-pixel "a sample of this launch has hit something" + the AOVs of that hit
   uint32_t* d_quirk_seen = nullptr;
   float4* d_quirk_aov = nullptr;
@@ -137,6 +138,7 @@ struct fh_ctx {
     uint32_t stream_grid = 0;       // FH_STREAM_GRID: blocks (0 = n_cus * workgroups per CU)
     uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill
     uint32_t stream_min_rays = 64;  // FH_STREAM_MIN_RAYS: queue entries per wave below which workgroups of a streaming launch stay out (render.hip: stream_block_idle); 0 = all take part
+    bool overlap_secondary = true;  // FH_OVERLAP=0: single-pass calls keep every launch on one stream
     bool sort_small = false;        // FH_SORT_SMALL=1: cell-order the bounce queues of trees the fixed-batch kernels trace as well
     uint32_t stream_chunk = 64;     // FH_STREAM_CHUNK: queue entries a wave takes per global atomic (setting it also switches the adaptive maximum off)
     bool stream_chunk_fixed = false;

@@ -1636,6 +1636,20 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     ctx->last_slot_used = slot;
     hipStream_t st = slot ? ctx->aux_stream[slot - 1] : ctx->stream;
     last_slot = slot;
+    // A call that is ONE pass (the reference's callers: 1 or 16 samples per call) has no other pass to share the GPU with, and its bounces are chains of launches that
+    // each end in a few long rays.  The secondary rays of bounce b and the closest-hit launch of bounce b + 1 do not depend on each other -- the secondary launch reads the
+    // secondary-ray records and adds to the radiance, the closest-hit launch and the routing read rays and write hits -- so the secondary launch goes to a second stream;
+    // the shade kernels of bounce b + 1, which overwrite the records it reads, wait for it.  (Calls of several passes overlap whole passes instead.)
+    const bool overlap = !serial && tun.overlap_secondary && batch >= n_samples && n_samples == nb;
+    hipStream_t sb = st;
+    if (overlap) {
+      sb = (st == ctx->aux_stream[0]) ? ctx->aux_stream[1] : ctx->aux_stream[0];
+      while (ctx->ev_bounce.size() < 2u * (max_depth + 1u)) {
+        hipEvent_t e = nullptr;
+        FH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ev_bounce.push_back(e);
+      }
+    }
     { const int rc = pool_ensure(ctx, slot, ctx->n_owned * batch); if (rc) return rc; }
     const PoolDev& pool = ctx->pool[slot];
     FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
@@ -1710,6 +1724,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         Span sp(ctx, st, 6);
         hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pd, depth, ctx->n_classes, count ? ctx->d_trace_counters + 26 : nullptr);
       }
+      if (overlap && depth > 0) FH_HIP(hipStreamWaitEvent(st, ctx->ev_bounce[2u * (depth - 1u) + 1u], 0));  // the secondary launch of the bounce before reads what the shade kernels and the sorts below overwrite
       {
         Span sp(ctx, st, 2);
         for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pd, c, depth);
@@ -1733,26 +1748,29 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         }
       }
       {
-        Span sp(ctx, st, 1);
+        if (overlap) { FH_HIP(hipEventRecord(ctx->ev_bounce[2u * depth], st)); FH_HIP(hipStreamWaitEvent(sb, ctx->ev_bounce[2u * depth], 0)); }
+        Span sp(ctx, sb, 1);
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stack_bytes, st, sc,
+            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stack_bytes, sb, sc,
                                fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk, tun.stream_min_rays);
           }); }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), stack_bytes, st, sc, fr, ps, depth, tc_shadow,
+            hipLaunchKernelGGL((k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), stack_bytes, sb, sc, fr, ps, depth, tc_shadow,
                                coop_flush);
           }); }); });
         } else {
           with_bool(count, [&](auto C) { with_bool(sc.use_bvh8 != 0, [&](auto W) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_static<decltype(C)::value, decltype(W)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), stack_bytes, st, sc, fr, ps,
+            hipLaunchKernelGGL((k_trace_secondary_static<decltype(C)::value, decltype(W)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid), dim3(kBlock), stack_bytes, sb, sc, fr, ps,
                                depth, tc_shadow);
           }); }); }); });
         }
         ctx->stats.n_shadow_launches++;
       }
+      if (overlap) FH_HIP(hipEventRecord(ctx->ev_bounce[2u * depth + 1u], sb));
     }
+    if (overlap && wave_depth > 0) FH_HIP(hipStreamWaitEvent(st, ctx->ev_bounce[2u * (wave_depth - 1u) + 1u], 0));  // the tail and the accumulate read the radiance the last secondary launch completes
     if (wave_depth < max_depth) {
       Span sp(ctx, st, 3);
       uint32_t lobes = 0;  // every lobe a material of the scene can have: the tail shades all classes in one kernel
