@@ -39,8 +39,8 @@ GENERATE_BYTES_PER_PATH, ACCUMULATE_BYTES_PER_SAMPLE = 116, 84 + 88
 # v_max3 / v_min3 / v_max / v_min, v_cmp, v_cndmask, shifts, logic, integer multiply -- in ~4.1 cycles (0.56-0.58 G/s), the two kinds side by side (a 1:1 mix of v_fma_f32
 # and v_max3_f32: 2.3 cycles per instruction).  The cost of a piece of code is therefore ~4.1 cycles x its non-FMA instructions, and what the kernels are made of was
 # measured directly, operands in registers, eight waves per SIMD, nothing but issue in the way:
-NODE_TEST_SIMD_CYCLES = 566.0  # one wave-level 8-wide node test incl. the octant permutation (fh_trace.h: node8_test): 0.0042 G tests/s per SIMD at 2.377 GHz
-TRI_TEST_SIMD_CYCLES = 177.0   # one wave-level watertight triangle test (fh_trace.h: tri_test): 0.0134 G tests/s per SIMD at 2.369 GHz
+NODE_TEST_SIMD_CYCLES = 510.0  # one wave-level 8-wide node test incl. the octant permutation (fh_trace.h: node8_test): 0.0047 G tests/s per SIMD at 2.384 GHz
+TRI_TEST_SIMD_CYCLES = 175.0   # one wave-level watertight triangle test (fh_trace.h: tri_test): 0.0135 G tests/s per SIMD at 2.367 GHz
 NOMINAL_CLOCK_GHZ = 2.4
 N_SIMDS = 1024
 VALU_FMA_PEAK_PER_CYCLE, VALU_OTHER_PEAK_PER_CYCLE = 1.0 / 2.2, 1.0 / 4.1  # wave64 instructions per cycle and SIMD, by class
@@ -461,7 +461,7 @@ def main():
                     "per_ray": {"nodes": round(nodes / max(rays, 1), 2), "triangles": round(tris / max(rays, 1), 2), "bytes": round(f["bytes"] / max(rays, 1), 1)},
                     "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_gbs": round(alg_gbs, 1), "frac_algorithmic_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 5),
                     "measured_hbm_gbs": {"read": round(bw_read, 1), "copy": round(bw_copy, 1)},
-                    "note": where + "; achieved = (wave-level node tests x 566 + wave-level triangle tests x 177 SIMD cycles) per launch / launch time measured inside the timed region, where passes on the other "
+                    "note": where + "; achieved = (wave-level node tests x %g + wave-level triangle tests x %g SIMD cycles)" % (NODE_TEST_SIMD_CYCLES, TRI_TEST_SIMD_CYCLES) + " per launch / launch time measured inside the timed region, where passes on the other "
                             "streams share the GPU with the launch; *_alone: the same launch with the GPU to itself (one untimed step with serial passes); algorithmic_* = SURVEY.md 8(d) bytes per ray x rays, "
                             "priced against HBM only for reference -- node and triangle arrays (80 MB) are served by L2 / Infinity Cache, see traffic"}
         elif pmc_k and pmc_k.get("valu_insts_per_launch") and dom in STATIC_FMA_SHARE and avg_ms > 0:
@@ -496,6 +496,10 @@ def main():
                 roof["valu"] = {"insts_per_launch": pmc_k["valu_insts_per_launch"], "insts_per_cycle_per_simd": round(per_cycle, 4),
                                 "peak_per_cycle_per_simd": {"fma_mul_add_f32": round(VALU_FMA_PEAK_PER_CYCLE, 3), "everything_else": round(VALU_OTHER_PEAK_PER_CYCLE, 3)},
                                 "lane_utilisation": pmc_k.get("valu_lane_utilisation"), "wait_any_frac_of_wave_cycles": pmc_k.get("wait_any_frac_of_wave_cycles")}
+            if pmc_k.get("vl1d"):
+                # the second limit of the traversal kernels: every lane of a node or triangle load asks the vector L1 for its own line (profiles/r03_issue_peak.txt,
+                # "global_load_dwordx4, 64 lanes in 64 L1-resident lines", holds the rate the L1 serves such loads at)
+                roof["vl1d"] = dict(pmc_k["vl1d"], note="TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / (GRBM_GUI_ACTIVE / 8 XCDs) and TA_TA_BUSY_sum likewise, kernels serialised")
             roof["counters_from"] = pmc_k.get("file")
         sec = lambda k: fam[k]["alone"] * 1e-3  # seconds per step with the kernel alone on the GPU
         rates = {"closest_hit_grays_per_s": round(cnt["rays_closest"] / sec("k_trace_closest_stream") / 1e9, 3) if sec("k_trace_closest_stream") > 0 else None,

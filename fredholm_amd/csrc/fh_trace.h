@@ -225,84 +225,75 @@ FH_D uint32_t octant_permute(uint32_t m, uint32_t oct)
   return m;
 }
 
-// EXPERIMENT, not used by the kernels (node8_test<true>; tools/micro/issue_peak.hip measures it): byte k of w as a float, scaled by 2^-23 -- the byte,
-// read as the bit pattern of a (denormal) float, is k * 2^-149; times 2^126 that is exact.  On gfx950 v_fma / v_mul / v_add_f32 issue in ~2.2 cycles per
-// wave and run BESIDE the 4-cycle instructions of everything else (a 1:1 mix of v_fma_f32 and v_max3_f32 issues at 2.3 cycles per instruction,
-// profiles/r03_issue_peak.txt), so a node test costs 4 cycles x its ~140 non-FMA instructions and the 48 v_cvt_f32_ubyte are a third of them.  Moving the
-// conversion to an FMA-class instruction through the SDWA byte select does NOT move it to the fast pipe: v_mul_f32_sdwa issues at 4.3 cycles and the
-// node test gets 18 % slower (0.0035 against 0.0042 G tests/s per SIMD), so the plain conversion stays.  v_fma_mix_f32 (f16 planes) is a 4-cycle form too.
-template <int K>
-FH_D float byte_scaled(uint32_t w, float two126)
-{
-  float f;
-  if (K == 0) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(f) : "v"(w), "v"(two126));
-  if (K == 1) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(f) : "v"(w), "v"(two126));
-  if (K == 2) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(f) : "v"(w), "v"(two126));
-  if (K == 3) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(f) : "v"(w), "v"(two126));
-  return f;
-}
-
-template <int J, bool SDWA>
-FH_D void node8_child(uint32_t& hits, uint32_t nearx, uint32_t farx, uint32_t neary, uint32_t fary, uint32_t nearz, uint32_t farz, float sx, float sy, float sz, float ox, float oy, float oz,
-                      float fx, float fy, float fz, float tmax, float two126)
-{
-  float b0x, b1x, b0y, b1y, b0z, b1z;
-  if (SDWA) {
-    b0x = byte_scaled<J>(nearx, two126); b1x = byte_scaled<J>(farx, two126); b0y = byte_scaled<J>(neary, two126); b1y = byte_scaled<J>(fary, two126);
-    b0z = byte_scaled<J>(nearz, two126); b1z = byte_scaled<J>(farz, two126);
-  } else {
-    b0x = (float)((nearx >> (8 * J)) & 0xffu); b1x = (float)((farx >> (8 * J)) & 0xffu); b0y = (float)((neary >> (8 * J)) & 0xffu); b1y = (float)((fary >> (8 * J)) & 0xffu);
-    b0z = (float)((nearz >> (8 * J)) & 0xffu); b1z = (float)((farz >> (8 * J)) & 0xffu);
-  }
-  const float t0x = fmaf(b0x, sx, ox), t1x = fmaf(b1x, sx, fx);
-  const float t0y = fmaf(b0y, sy, oy), t1y = fmaf(b1y, sy, fy);
-  const float t0z = fmaf(b0z, sz, oz), t1z = fmaf(b1z, sz, fz);
-  const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
-  const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));
-  // hits = 2 * hits + (tn <= tf): the compare leaves its result in the carry, the add-with-carry shifts it in (one VALU instruction per child
-  // instead of a select, a shift and an or)
-  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(tn), "v"(tf) : "vcc");
-}
-
-#ifndef FH_NODE_SDWA
-#define FH_NODE_SDWA 0
+// The node test in units of the ray's current limit.  All distances are computed as t' = t / tmax: the planes' conversions and the
+// min / max / compare instructions are what a node costs (gfx950 issues v_fma / v_mul / v_add_f32 in ~2.2 cycles per wave BESIDE the ~4.1-cycle
+// instructions of everything else, profiles/r03_issue_peak.txt, and a node has ~2 of the second kind for each of the first), so the test is
+// arranged to need as few of those as possible:
+//   - the clamp of a v_fma_f32 (a free output modifier) bounds every plane distance to [0, 1] = [ray start, tmax]: no max(., 0), no min(., tmax);
+//   - with both ends inside [0, 1] the ray enters the box iff max3(near) < min3(far); the difference is one v_sub_f32 (the fast class) whose sign
+//     bit a v_alignbit_b32 shifts into the mask: one slow instruction where compare + add-with-carry were two.
+// Per child: 6 conversions, max3, min3, alignbit = 9 of the slow kind (12 before), plus v_min + v_rcp per node for 1 / tmax.
+// The comparison is strict because both sides saturate: a box behind the ray gives 0 < 0, one beyond tmax 1 < 1, an empty slot (lo 255, hi 0) never has
+// near < far.  A box the ray really enters has near' < far' by what the build's padding and the slack below put between them, and 1 / tmax is rounded
+// down by two units (v_rcp_f32 is good to one), so a box that starts just before tmax is never cut off.  tmax <= 0 or NaN: no child is hit
+// (the scaled distances change sign or saturate), as with the unscaled comparison.
+#ifndef FH_NODE_SLACK
+#define FH_NODE_SLACK 1
 #endif
+FH_D float fma_clamp01(float a, float b, float c)
+{
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+template <int J>
+FH_D void node8_child(uint32_t& hits, uint32_t nearx, uint32_t farx, uint32_t neary, uint32_t fary, uint32_t nearz, uint32_t farz, float sx, float sy, float sz, float nx, float ny, float nz,
+                      float fx, float fy, float fz)
+{
+  const float t0x = fma_clamp01((float)((nearx >> (8 * J)) & 0xffu), sx, nx), t1x = fma_clamp01((float)((farx >> (8 * J)) & 0xffu), sx, fx);
+  const float t0y = fma_clamp01((float)((neary >> (8 * J)) & 0xffu), sy, ny), t1y = fma_clamp01((float)((fary >> (8 * J)) & 0xffu), sy, fy);
+  const float t0z = fma_clamp01((float)((nearz >> (8 * J)) & 0xffu), sz, nz), t1z = fma_clamp01((float)((farz >> (8 * J)) & 0xffu), sz, fz);
+  float tn, tf;  // (as instructions: the operands are clamped, never NaN, and need no canonicalising first)
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(t0x), "v"(t0y), "v"(t0z));
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(t1x), "v"(t1y), "v"(t1z));
+  hits = __builtin_amdgcn_alignbit(hits, __float_as_uint(tn - tf), 31u);  // hits = 2 * hits + (tn < tf)
+}
+
 // one bit per child slot whose (conservative) box the ray enters before tmax
-template <bool SDWA = (FH_NODE_SDWA != 0)>
 FH_D uint32_t node8_test(const Ray8& r, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, float tmax)
 {
+  float tl;
+  asm("v_min_f32 %0, 0x7149f2ca, %1" : "=v"(tl) : "v"(tmax));  // min(tmax, 1e30): a ray without a limit still has a finite unit
+  const float rt = __builtin_amdgcn_rcpf(tl) * 0.99999976158142090f;
+  const float ix = r.inv.x * rt, iy = r.inv.y * rt, iz = r.inv.z * rt;
   const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
   // scale of an axis = 2^(e - 127) with e the low byte of the origin word (<< 23 shifts everything else out; bit 8 lands in the sign, hence the fabsf, a free
-  // source modifier); the SDWA form of the byte conversion delivers byte * 2^-23, so its scale carries 2^23 (the builder keeps e + 23 below 255)
-  const float kx = fabsf(__uint_as_float((n0.x + (SDWA ? 23u : 0u)) << 23)), ky = fabsf(__uint_as_float((n0.y + (SDWA ? 23u : 0u)) << 23)), kz = fabsf(__uint_as_float((n0.z + (SDWA ? 23u : 0u)) << 23));
-  const float sx = kx * r.inv.x, sy = ky * r.inv.y, sz = kz * r.inv.z;
-  const float ox = (px - r.o.x) * r.inv.x, oy = (py - r.o.y) * r.inv.y, oz = (pz - r.o.z) * r.inv.z;
+  // source modifier)
+  const float kx = fabsf(__uint_as_float(n0.x << 23)), ky = fabsf(__uint_as_float(n0.y << 23)), kz = fabsf(__uint_as_float(n0.z << 23));
+  const float sx = kx * ix, sy = ky * iy, sz = kz * iz;
+  const float ox = (px - r.o.x) * ix, oy = (py - r.o.y) * iy, oz = (pz - r.o.z) * iz;
   // The child boxes carry the build's absolute padding (2^-16 of the scene's largest coordinate), ~100 x the rounding error of these distances while the ray
   // starts within a few hundred scene sizes of the node.  The error of (p - o) * inv grows with |p - o| though (2^-24 of it, per axis), and so does what the
   // triangle test itself makes of a ray from far away; so the near planes of every axis are moved in and the far planes out by 2^-21 of that axis' own offset:
   // nothing next to the padding for a ray that starts in or near the scene, and what keeps a thin box from being skipped by a camera far outside it.
-  // Six FMA-class instructions per node, which issue beside the others (profiles/r03_issue_peak.txt).
-#ifndef FH_NODE_SLACK
-#define FH_NODE_SLACK 1
-#endif
+  // Six FMA-class instructions per node, which issue beside the others.
   const float kSlack = FH_NODE_SLACK ? 4.76837158203125e-7f : 0.0f;  // (FH_NODE_SLACK=0: timing experiments only)
   const float fx = fmaf(fabsf(ox), kSlack, ox), fy = fmaf(fabsf(oy), kSlack, oy), fz = fmaf(fabsf(oz), kSlack, oz);
   const float nx = fmaf(fabsf(ox), -kSlack, ox), ny = fmaf(fabsf(oy), -kSlack, oy), nz = fmaf(fabsf(oz), -kSlack, oz);
-  const float two126 = 8.507059173023462e37f;
   uint32_t hits = 0;
   {  // slots 7 .. 4, then 3 .. 0: every test shifts the mask left and moves its result in at the bottom
     const uint32_t nearx = r.nx ? n2.w : n1.y, farx = r.nx ? n1.y : n2.w, neary = r.ny ? n3.y : n1.w, fary = r.ny ? n1.w : n3.y, nearz = r.nz ? n3.w : n2.y, farz = r.nz ? n2.y : n3.w;
-    node8_child<3, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
-    node8_child<2, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
-    node8_child<1, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
-    node8_child<0, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
+    node8_child<3>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz);
+    node8_child<2>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz);
+    node8_child<1>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz);
+    node8_child<0>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz);
   }
   {
     const uint32_t nearx = r.nx ? n2.z : n1.x, farx = r.nx ? n1.x : n2.z, neary = r.ny ? n3.x : n1.z, fary = r.ny ? n1.z : n3.x, nearz = r.nz ? n3.z : n2.x, farz = r.nz ? n2.x : n3.z;
-    node8_child<3, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
-    node8_child<2, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
-    node8_child<1, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
-    node8_child<0, SDWA>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz, tmax, two126);
+    node8_child<3>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz);
+    node8_child<2>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz);
+    node8_child<1>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz);
+    node8_child<0>(hits, nearx, farx, neary, fary, nearz, farz, sx, sy, sz, nx, ny, nz, fx, fy, fz);
   }
   return hits;
 }
@@ -322,12 +313,25 @@ FH_D Ray8 ray8_prepare(const RayPre& rp, f3 d)
 // and the group of its candidate triangles (first triangle slot, one bit per slot)
 FH_D void node8_visit(const Bvh8Dev& bvh, const Ray8& r, uint32_t ni, float tmax, uint2& group, uint2& tg)
 {
-  const uint4* nd = bvh.nodes + kBvh8NodeVec * (size_t)ni;
+  // (a 32-bit byte offset -- the builder refuses trees of 2^23 nodes -- lets the four loads share the base in scalar registers)
+  const uint4* nd = (const uint4*)((const char*)bvh.nodes + (ni << 6));
   const uint4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-  const uint32_t hm = node8_test<>(r, n0, n1, n2, n3, tmax);
+  const uint32_t hm = node8_test(r, n0, n1, n2, n3, tmax);
   const uint32_t imask = n0.w & 0xffu;
+  // (the permutation is 15 instructions; reading it from a 2 KB table in global memory instead -- one instruction and a byte load -- made the streaming kernels
+  // 4-7 % SLOWER, configs[2] closest 71.4 -> 74.7 ms, secondary 111 -> 118.5 ms: a fifth load per node visit costs more in the memory pipeline than 14 instructions
+  // cost in the VALU; LDS has no room for the table without giving up a workgroup per CU)
   group = make_uint2(n0.w >> 8, (octant_permute(hm & imask, r.oct) << 24) | imask);
   tg = make_uint2(8u * ni, hm & ~imask);
+}
+
+// the three float4 of triangle slot `slot` (48 bytes each).  The byte offset fits 32 bits (kCoopMaxTris slots) and is built from shifts and adds:
+// a 32-bit multiply is a quarter-rate instruction, a 64-bit address two more
+FH_D const float4* tri_slot_ptr(const Bvh8Dev& bvh, uint32_t slot)
+{
+  uint32_t s3;
+  asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(s3) : "v"(slot));
+  return (const float4*)((const char*)bvh.tris + (s3 << 4));
 }
 
 // wave-level step counters of the instrumented build: how many times a wave executed the node test /
@@ -401,8 +405,8 @@ FH_D bool traverse_bvh8(const Bvh8Dev& bvh, f3 o, f3 d, float tmax, HitRec& best
     while (tg.y) {
       const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
       tg.y &= tg.y - 1u;
-      const size_t ti = 3 * (size_t)(tg.x + b);
-      const float4 a = bvh.tris[ti], bb = bvh.tris[ti + 1], c = bvh.tris[ti + 2];
+      const float4* tp = tri_slot_ptr(bvh, tg.x + b);
+      const float4 a = tp[0], bb = tp[1], c = tp[2];
       if (COUNT) { n_tris++; if (ws && first_active_lane()) ws->tri++; }
       float t, bu, bv;
       if (!tri_test(rp, mk3(a), mk3(bb), mk3(c), t, bu, bv)) continue;
@@ -461,8 +465,8 @@ template <bool ANY_HIT, bool COUNT, bool ALPHA>
 FH_D void coop_test(const Bvh8Dev& bvh, const CoopLds& cl, uint32_t e, uint32_t& n_tris, WaveSteps* ws, const SceneDev* sc)
 {
   const uint32_t owner = e & 63u;
-  const size_t ti = 3 * (size_t)(e >> 6);
-  const float4 a = bvh.tris[ti], bb = bvh.tris[ti + 1], c = bvh.tris[ti + 2];
+  const float4* tp = tri_slot_ptr(bvh, e >> 6);
+  const float4 a = tp[0], bb = tp[1], c = tp[2];
   if (COUNT) { n_tris++; if (ws && first_active_lane()) ws->tri++; }
   const float4 r0 = cl.ray[owner], r1 = cl.ray[64 + owner];
   if (ANY_HIT && r1.w != 0.0f && (uint32_t)cl.key[owner] != 0xffffffffu) return;  // the owner's ray stops at its first hit and has one

@@ -36,6 +36,12 @@ d = {"kernel": k["name"], "config": cfg, "spp_per_pass": pmc_pass_spp,
      "lds_insts_per_launch": int(g("SQ_INSTS_LDS")), "valu_lane_utilisation": round(g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_INSTS_VALU")), 4),
      "wait_any_frac_of_wave_cycles": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4), "waves_per_launch": int(g("SQ_WAVES")),
      "grbm_gui_active_per_launch": g("GRBM_GUI_ACTIVE"),
+     # the vector-memory side: GRBM_GUI_ACTIVE sums the eight XCDs' cycles, the TA / TCP counters the 256 CUs' units
+     "vl1d": ({"accesses_per_launch": int(g("TCP_TOTAL_CACHE_ACCESSES_sum")), "l2_read_requests_per_launch": int(g("TCP_TCC_READ_REQ_sum")),
+               "accesses_per_cycle_per_cu": round(g("TCP_TOTAL_CACHE_ACCESSES_sum") / 256.0 / (g("GRBM_GUI_ACTIVE") / 8.0), 4),
+               "ta_busy_frac": round(g("TA_TA_BUSY_sum") / 256.0 / (g("GRBM_GUI_ACTIVE") / 8.0), 4),
+               "accesses_per_load_instruction": round(g("TCP_TOTAL_CACHE_ACCESSES_sum") / max(g("TA_FLAT_READ_WAVEFRONTS_sum"), 1.0), 2)}
+              if "TCP_TOTAL_CACHE_ACCESSES_sum" in k and "TA_TA_BUSY_sum" in k else None),
      "frame_traffic_bytes_per_spp": frame / (renders * pspp),
      "frame_note": f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every kernel of the run / ({renders} renders x {pspp} spp): fabric-side bytes one sample per pixel of the whole frame costs",
      "note": "fabric-side bytes (L2 misses; Infinity-Cache hits are counted)."}

@@ -29,11 +29,14 @@
 struct Stamp { unsigned long long cycles, ticks; };
 
 enum Kind { FMA, MAX3, CVT_UBYTE, CNDMASK, CMP_ADDC, AND_OR, LSHL, MUL_U24, RCP, SQRT, FMA_F64, NODE_TEST, TRI_TEST,
-            MUL, ADD, MAX2, SDWA_MUL, FMA_MIX, PAIR_FMA_MAX3, PAIR_FMA_CVT, PAIR_SDWA_FMA, TRIPLE_FMA_FMA_MAX3, NODE_TEST_SDWA, PERM, N_KINDS };
+            MUL, ADD, MAX2, SDWA_MUL, FMA_MIX, PAIR_FMA_MAX3, PAIR_FMA_CVT, PAIR_SDWA_FMA, TRIPLE_FMA_FMA_MAX3, PERM, FMA_CLAMP, ALIGNBIT, MUL_LO, LSHL_B64, LSHL_ADD_U64, PK_FMA, CVT_PK_FP8,
+            BFE, L1_GATHER, L1_COALESCED, N_KINDS };
 static const char* kNames[N_KINDS] = {"v_fma_f32", "v_max3_f32", "v_cvt_f32_ubyte", "v_cndmask_b32 (sgpr mask)", "v_cmp_le_f32 + v_addc_co_u32", "v_and_or_b32", "v_lshlrev_b32", "v_mul_u32_u24",
                                       "v_rcp_f32", "v_sqrt_f32", "v_fma_f64", "node8_test (fh_trace.h)", "tri_test (fh_trace.h)",
                                       "v_mul_f32", "v_add_f32", "v_max_f32", "v_mul_f32_sdwa (byte select)", "v_fma_mix_f32 (f16 src0)", "v_fma_f32 + v_max3_f32 (1:1)",
-                                      "v_fma_f32 + v_cvt_f32_ubyte (1:1)", "v_mul_f32_sdwa + v_fma_f32 (1:1)", "2 v_fma_f32 + v_max3_f32", "node8_test<SDWA> (fh_trace.h)", "v_perm_b32"};
+                                      "v_fma_f32 + v_cvt_f32_ubyte (1:1)", "v_mul_f32_sdwa + v_fma_f32 (1:1)", "2 v_fma_f32 + v_max3_f32", "v_perm_b32", "v_fma_f32 clamp", "v_alignbit_b32", "v_mul_lo_u32",
+                                      "v_lshlrev_b64", "v_lshl_add_u64", "v_pk_fma_f32 (2 fma)", "v_cvt_pk_f32_fp8 (2 values)", "v_bfe_u32",
+                                      "global_load_dwordx4, 64 lanes in 64 L1-resident lines", "global_load_dwordx4, 64 lanes contiguous (L1-resident)"};
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_issue(int iters, float* sink, Stamp* stamps)
@@ -81,19 +84,38 @@ __global__ void __launch_bounds__(256) k_issue(int iters, float* sink, Stamp* st
         if (KIND == SDWA_MUL) asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(a[i]) : "v"(u[i]), "v"(s));
         if (KIND == FMA_MIX) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(u[i]), "v"(s));
         if (KIND == PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 15]), "v"(u[(i + 2) & 15]));
+        if (KIND == FMA_CLAMP) asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(a[i]) : "v"(s), "v"(o));
+        if (KIND == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(u[i]) : "v"(u[(i + 1) & 15]));
+        if (KIND == MUL_LO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 15]));
+        if (KIND == LSHL_B64 && i < 8) asm volatile("v_lshlrev_b64 %0, 6, %0" : "+v"(d[i]));
+        if (KIND == LSHL_ADD_U64 && i < 8) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));
+        if (KIND == PK_FMA && i < 8) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d[i]) : "v"(d[(i + 1) & 7]), "v"(d[(i + 2) & 7]));
+        if (KIND == CVT_PK_FP8 && i < 8) asm volatile("v_cvt_pk_f32_fp8 %0, %1" : "=v"(d[i]) : "v"(u[i]));
+        if (KIND == BFE) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(u[i]));
         if (KIND == PAIR_FMA_MAX3) { if (i & 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(o)); else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(o)); }
         if (KIND == PAIR_FMA_CVT) { if (i & 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(o)); else asm volatile("v_cvt_f32_ubyte2_e32 %0, %1" : "=v"(a[i]) : "v"(u[i])); }
         if (KIND == PAIR_SDWA_FMA) { if (i & 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(o)); else asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(a[i]) : "v"(u[i]), "v"(s)); }
         if (KIND == TRIPLE_FMA_FMA_MAX3 && i < 15) { if (i % 3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(o)); else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(o)); }
       }
     }
-    if (KIND == NODE_TEST || KIND == NODE_TEST_SDWA) {
+    if (KIND == L1_GATHER || KIND == L1_COALESCED) {
+      // what a node visit asks of the vector L1: every lane 16 bytes of its own 128-byte line (the four loads of a node go to one line per lane), against the
+      // same loads with the lanes side by side; an 8 KB window every CU keeps in its L1
+      const unsigned voff = KIND == L1_GATHER ? (threadIdx.x & 63u) * 128u : (threadIdx.x & 63u) * 16u;
+      float4 q0, q1, q2, q3, q4, q5, q6, q7;
+      asm volatile("global_load_dwordx4 %0, %8, %9\n\tglobal_load_dwordx4 %1, %8, %9 offset:16\n\tglobal_load_dwordx4 %2, %8, %9 offset:32\n\tglobal_load_dwordx4 %3, %8, %9 offset:48\n\t"
+                   "global_load_dwordx4 %4, %8, %9 offset:64\n\tglobal_load_dwordx4 %5, %8, %9 offset:80\n\tglobal_load_dwordx4 %6, %8, %9 offset:96\n\tglobal_load_dwordx4 %7, %8, %9 offset:112\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7) : "v"(voff), "s"(sink) : "memory");
+      facc += q0.x + q1.y + q2.z + q3.w + q4.x + q5.y + q6.z + q7.w;
+    }
+    if (KIND == NODE_TEST) {
 #pragma unroll
       for (int rep = 0; rep < 4; ++rep) {
         // every operand counts as modified (no instruction is issued for this): nothing of the test is loop invariant
         asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w));
         asm volatile("" : "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y), "+v"(n3.z), "+v"(n3.w));
-        const uint32_t hm = fh::node8_test<KIND == NODE_TEST_SDWA>(r8, n0, n1, n2, n3, 1e9f);
+        const uint32_t hm = fh::node8_test(r8, n0, n1, n2, n3, 1e9f);
         const uint32_t perm = fh::octant_permute(hm & (n0.w & 0xffu), r8.oct);
         acc += perm + (hm & ~n0.w);
         n1.x ^= hm; n2.y += perm; n3.z ^= acc;  // the next test depends on this one like a traversal step depends on the node before it
@@ -118,8 +140,9 @@ __global__ void __launch_bounds__(256) k_issue(int iters, float* sink, Stamp* st
   if ((threadIdx.x & 63) == 0) stamps[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = Stamp{t1 - t0, r1 - r0};
 }
 
-// the SDWA form of the node test must return the hit mask of the plain form, bit for bit, on arbitrary nodes and rays
-__global__ void k_verify_sdwa(uint32_t n, uint32_t* mismatches, uint32_t* hits_seen)
+// The node test against the same boxes in double precision: it may flag a child the ray misses (it is conservative) but never the other way round.
+// Random nodes and rays; "must" = the exact test enters the box with a relative margin of 1e-5 between entry and exit.
+__global__ void k_verify_node(uint32_t n, uint32_t* out)  // out: missed, must, flagged
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -129,25 +152,44 @@ __global__ void k_verify_sdwa(uint32_t n, uint32_t* mismatches, uint32_t* hits_s
   fh::f3 o = fh::mk3(rf() * 4.0f - 2.0f, rf() * 4.0f - 2.0f, rf() * 4.0f - 2.0f), d = fh::mk3(rf() * 2.0f - 1.0f, rf() * 2.0f - 1.0f, rf() * 2.0f - 1.0f);
   if (i % 7 == 0) d.x = 0.0f;
   if (i % 11 == 0) d.y = -0.0f;
+  if (i % 13 == 0) o = o * 1.0e4f;  // a ray from far outside
   const fh::RayPre rp = fh::ray_prepare(o, d);
   const fh::Ray8 r = fh::ray8_prepare(rp, d);
   const uint32_t e = 100u + rnd() % 30u;
   uint4 n0 = make_uint4((__float_as_uint(rf() * 2.0f - 1.0f) & ~0xffu) | e, (__float_as_uint(rf() * 2.0f - 1.0f) & ~0xffu) | (e + 1u), (__float_as_uint(rf() * 2.0f - 1.0f) & ~0xffu) | (e - 1u), rnd());
   uint4 n1 = make_uint4(rnd(), rnd(), rnd(), rnd()), n2 = make_uint4(rnd(), rnd(), rnd(), rnd()), n3 = make_uint4(rnd(), rnd(), rnd(), rnd());
   if (i % 5 == 0) { n1 = make_uint4(0u, 0u, 0u, 0u); n2.x = n2.y = 0u; n2.z = n2.w = ~0u; n3 = make_uint4(~0u, ~0u, ~0u, ~0u); }  // every child the whole node box
-  const float tmax = (i & 1) ? 1e9f : rf() * 3.0f;
-  const uint32_t a = fh::node8_test<false>(r, n0, n1, n2, n3, tmax), b = fh::node8_test<true>(r, n0, n1, n2, n3, tmax);
-  if (a != b) atomicAdd(mismatches, 1u);
-  atomicAdd(hits_seen, (uint32_t)__popc(a));
+  const float tmax = (i & 1) ? 1e9f : ((i & 2) ? 3.0e38f : rf() * 3.0f);
+  const uint32_t got = fh::node8_test(r, n0, n1, n2, n3, tmax);
+  const uint32_t lo_w[3][2] = {{n1.x, n1.y}, {n1.z, n1.w}, {n2.x, n2.y}}, hi_w[3][2] = {{n2.z, n2.w}, {n3.x, n3.y}, {n3.z, n3.w}};
+  const uint32_t ow[3] = {n0.x, n0.y, n0.z};
+  const double ro[3] = {o.x, o.y, o.z}, ri[3] = {r.inv.x, r.inv.y, r.inv.z};
+  uint32_t must = 0;
+  for (int c = 0; c < 8; ++c) {
+    double tn = 0.0, tf = (double)tmax;
+    bool empty = false;
+    for (int ax = 0; ax < 3; ++ax) {
+      const double org = (double)__uint_as_float(ow[ax]), sc = ldexp(1.0, (int)(ow[ax] & 0xffu) - 127);
+      const double lo = org + sc * (double)((lo_w[ax][c >> 2] >> (8 * (c & 3))) & 0xffu), hi = org + sc * (double)((hi_w[ax][c >> 2] >> (8 * (c & 3))) & 0xffu);
+      if (lo > hi) empty = true;
+      const double a = (lo - ro[ax]) * ri[ax], b = (hi - ro[ax]) * ri[ax];
+      tn = fmax(tn, fmin(a, b)); tf = fmin(tf, fmax(a, b));
+    }
+    if (!empty && tn * (1.0 + 1e-5) + 1e-30 < tf * (1.0 - 1e-5)) must |= 1u << c;
+  }
+  if (must & ~got) atomicAdd(out, 1u);
+  atomicAdd(out + 1, (uint32_t)__popc(must));
+  atomicAdd(out + 2, (uint32_t)__popc(got));
 }
-static void verify_sdwa()
+static void verify_node()
 {
-  uint32_t* d; uint32_t h[2] = {0, 0};
-  CHECK(hipMalloc((void**)&d, 8)); CHECK(hipMemset(d, 0, 8));
+  uint32_t* d; uint32_t h[3] = {0, 0, 0};
+  CHECK(hipMalloc((void**)&d, 12)); CHECK(hipMemset(d, 0, 12));
   const uint32_t n = 1u << 24;
-  hipLaunchKernelGGL(k_verify_sdwa, dim3(n / 256), dim3(256), 0, 0, n, d, d + 1);
-  CHECK(hipMemcpy(h, d, 8, hipMemcpyDeviceToHost));
-  printf("node8_test<SDWA> against node8_test on %u random (node, ray) pairs: %u mismatching hit masks (%.2f children hit per test)\n", n, h[0], (double)h[1] / n);
+  hipLaunchKernelGGL(k_verify_node, dim3(n / 256), dim3(256), 0, 0, n, d);
+  CHECK(hipMemcpy(h, d, 12, hipMemcpyDeviceToHost));
+  printf("node8_test against the exact slab test on %u random (node, ray) pairs: %u tests missed a child the ray enters; children entered %.3f per test, flagged %.3f\n", n, h[0], (double)h[1] / n,
+         (double)h[2] / n);
   CHECK(hipFree(d));
 }
 
@@ -233,10 +275,9 @@ int main(int argc, char** argv)
     printf("warm-up: %.0f ms of v_fma_f32 launches\n", total);
   }
   const std::vector<int> all = {1, 2, 4, 6, 8}, few = {1, 6, 8}, two = {6, 8};
-  verify_sdwa();
+  verify_node();
   run_kind<FMA>(n_cus, target_ms, sink, stamps, all, 64.0, "instr");
   run_kind<NODE_TEST>(n_cus, target_ms, sink, stamps, all, 4.0, "test");
-  run_kind<NODE_TEST_SDWA>(n_cus, target_ms, sink, stamps, all, 4.0, "test");
   run_kind<TRI_TEST>(n_cus, target_ms, sink, stamps, few, 4.0, "test");
   run_kind<PAIR_FMA_MAX3>(n_cus, target_ms, sink, stamps, few, 64.0, "instr");
   run_kind<TRIPLE_FMA_FMA_MAX3>(n_cus, target_ms, sink, stamps, two, 60.0, "instr");
@@ -247,6 +288,16 @@ int main(int argc, char** argv)
   run_kind<MUL>(n_cus, target_ms, sink, stamps, two, 64.0, "instr");
   run_kind<ADD>(n_cus, target_ms, sink, stamps, two, 64.0, "instr");
   run_kind<MAX2>(n_cus, target_ms, sink, stamps, two, 64.0, "instr");
+  run_kind<FMA_CLAMP>(n_cus, target_ms, sink, stamps, two, 64.0, "instr");
+  run_kind<ALIGNBIT>(n_cus, target_ms, sink, stamps, two, 64.0, "instr");
+  run_kind<MUL_LO>(n_cus, target_ms, sink, stamps, two, 64.0, "instr");
+  run_kind<LSHL_B64>(n_cus, target_ms, sink, stamps, two, 32.0, "instr");
+  run_kind<LSHL_ADD_U64>(n_cus, target_ms, sink, stamps, two, 32.0, "instr");
+  run_kind<PK_FMA>(n_cus, target_ms, sink, stamps, two, 32.0, "instr");
+  run_kind<CVT_PK_FP8>(n_cus, target_ms, sink, stamps, two, 32.0, "instr");
+  run_kind<BFE>(n_cus, target_ms, sink, stamps, two, 64.0, "instr");
+  run_kind<L1_GATHER>(n_cus, target_ms, sink, stamps, few, 8.0, "load");
+  run_kind<L1_COALESCED>(n_cus, target_ms, sink, stamps, few, 8.0, "load");
   if (!quick) {
     run_kind<MAX3>(n_cus, target_ms, sink, stamps, few, 64.0, "instr");
     run_kind<CVT_UBYTE>(n_cus, target_ms, sink, stamps, few, 64.0, "instr");

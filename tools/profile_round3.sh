@@ -16,13 +16,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_ser
 find $R/gpurun_out/${tag}_serial_stats -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${tag}_serial_kernel_stats.csv \;
 find $R/gpurun_out/${tag}_stats $R/gpurun_out/${tag}_serial_stats -name "*kernel_trace.csv" -delete
 run() { name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_$name -- $B --steps 1 --warmup 1 --spp $pspp --no-cpu-baseline --no-extras > $R/gpurun_out/${tag}_$name.log 2>&1; echo "pmc $name rc=$?"
+  timeout -k 5 300 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_$name -- $B --steps 1 --warmup 1 --spp $pspp --no-cpu-baseline --no-extras > $R/gpurun_out/${tag}_$name.log 2>&1; echo "pmc $name rc=$?"
 }
 run sqa SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD
 run sqb SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
 run tcc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+# the vector-memory side (two counters of a block per pass: more "exceeds the capabilities of the hardware")
+run l1a TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
+run l1b TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 cd $R
-python3 tools/pmc_summary.py "gpurun_out/${tag}_sq?/**/*counter_collection.csv" "gpurun_out/${tag}_fetch/**/*counter_collection.csv" "gpurun_out/${tag}_tcc/**/*counter_collection.csv" > gpurun_out/${tag}_pmc_summary.txt 2>&1
-find gpurun_out/${tag}_sq? gpurun_out/${tag}_fetch gpurun_out/${tag}_tcc -name "*counter_collection.csv" -delete
+python3 tools/pmc_summary.py "gpurun_out/${tag}_sq?/**/*counter_collection.csv" "gpurun_out/${tag}_fetch/**/*counter_collection.csv" "gpurun_out/${tag}_tcc/**/*counter_collection.csv" "gpurun_out/${tag}_l1?/**/*counter_collection.csv" > gpurun_out/${tag}_pmc_summary.txt 2>&1
+find gpurun_out/${tag}_sq? gpurun_out/${tag}_fetch gpurun_out/${tag}_tcc gpurun_out/${tag}_l1? -name "*counter_collection.csv" -delete
 cut -c1-600 gpurun_out/${tag}_bench.json; echo; head -12 gpurun_out/${tag}_serial_kernel_stats.csv | cut -c1-200
