@@ -21,6 +21,19 @@ ks = [parse(x) for x in blocks if x.startswith("k_")]
 cand = [k for k in ks if k["name"].startswith(dom) and not k["name"].startswith(dom + "<true")]
 k = max(cand, key=lambda k: k["dispatches"] * k.get("SQ_INSTS_VALU", (0, 0))[0])
 g = lambda n: k[n][0]
+# the vector-memory side, from its own passes (gpurun_out/<tag>_l1_summary.txt -> profiles/): GRBM_GUI_ACTIVE sums the eight XCDs' cycles, the TA / TCP counters the 256 CUs' units
+vl1d = None
+try:
+    shutil.copy(f"gpurun_out/{tag}_l1_summary.txt", f"profiles/{tag}_l1_summary.txt")
+    kl = [parse(x) for x in re.split(r"\n(?=k_)", open(f"gpurun_out/{tag}_l1_summary.txt").read()) if x.startswith("k_")]
+    kl = [x for x in kl if x["name"] == k["name"]][0]
+    cyc = kl["GRBM_GUI_ACTIVE"][0] / 8.0
+    vl1d = {"accesses_per_launch": int(kl["TCP_TOTAL_CACHE_ACCESSES_sum"][0]), "l2_read_requests_per_launch": int(kl["TCP_TCC_READ_REQ_sum"][0]), "cycles_per_launch": int(cyc),
+            "accesses_per_cycle_per_cu": round(kl["TCP_TOTAL_CACHE_ACCESSES_sum"][0] / 256.0 / cyc, 4), "ta_busy_frac": round(kl["TA_TA_BUSY_sum"][0] / 256.0 / cyc, 4),
+            "accesses_per_load_instruction": round(kl["TCP_TOTAL_CACHE_ACCESSES_sum"][0] / max(kl["TA_FLAT_READ_WAVEFRONTS_sum"][0], 1.0), 2),
+            "peak_accesses_per_cycle_per_cu": 1.0, "source": f"profiles/{tag}_l1_summary.txt; peak: profiles/r03_issue_peak.txt (64 lanes in 64 L1-resident lines: 64 cycles per load instruction and CU)"}
+except Exception as e:
+    print("no vector-memory passes:", e)
 renders = 4  # --warmup 1 --steps 1 + the serial step + the counting replay
 pmc_line = [ln for ln in open(f"gpurun_out/{tag}_sqa.log") if ln.startswith("{")][-1]
 pmc_pass_spp = json.loads(pmc_line)["config"]["spp_per_pass"]  # the launch size the counters belong to: bench.py quotes them only for runs with the same samples per pass
@@ -36,12 +49,7 @@ d = {"kernel": k["name"], "config": cfg, "spp_per_pass": pmc_pass_spp,
      "lds_insts_per_launch": int(g("SQ_INSTS_LDS")), "valu_lane_utilisation": round(g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_INSTS_VALU")), 4),
      "wait_any_frac_of_wave_cycles": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4), "waves_per_launch": int(g("SQ_WAVES")),
      "grbm_gui_active_per_launch": g("GRBM_GUI_ACTIVE"),
-     # the vector-memory side: GRBM_GUI_ACTIVE sums the eight XCDs' cycles, the TA / TCP counters the 256 CUs' units
-     "vl1d": ({"accesses_per_launch": int(g("TCP_TOTAL_CACHE_ACCESSES_sum")), "l2_read_requests_per_launch": int(g("TCP_TCC_READ_REQ_sum")),
-               "accesses_per_cycle_per_cu": round(g("TCP_TOTAL_CACHE_ACCESSES_sum") / 256.0 / (g("GRBM_GUI_ACTIVE") / 8.0), 4),
-               "ta_busy_frac": round(g("TA_TA_BUSY_sum") / 256.0 / (g("GRBM_GUI_ACTIVE") / 8.0), 4),
-               "accesses_per_load_instruction": round(g("TCP_TOTAL_CACHE_ACCESSES_sum") / max(g("TA_FLAT_READ_WAVEFRONTS_sum"), 1.0), 2)}
-              if "TCP_TOTAL_CACHE_ACCESSES_sum" in k and "TA_TA_BUSY_sum" in k else None),
+     "vl1d": vl1d,
      "frame_traffic_bytes_per_spp": frame / (renders * pspp),
      "frame_note": f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every kernel of the run / ({renders} renders x {pspp} spp): fabric-side bytes one sample per pixel of the whole frame costs",
      "note": "fabric-side bytes (L2 misses; Infinity-Cache hits are counted)."}
