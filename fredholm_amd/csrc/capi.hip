@@ -411,6 +411,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_STREAM_MIN_RAYS", 0, 65535, t.stream_min_rays);
     env_off("FH_SORT_SMALL", t.sort_small);
     env_off("FH_OVERLAP", t.overlap_secondary);
+    env_uint("FH_STACK_LDS", 1, 99, t.stack_lds_entries);
     env_uint("FH_STREAM_CHUNK", 16, 65535, t.stream_chunk);
     t.stream_chunk_fixed = getenv("FH_STREAM_CHUNK") != nullptr;
     if (t.stream_chunk_fixed) t.stream_chunk_closest = t.stream_chunk;  // (FH_STREAM_CHUNK alone sets both launches)
@@ -437,7 +438,7 @@ int fh_ctx_destroy(fh_ctx* ctx)
   void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_sobol_bytes, ctx->d_alpha_rec, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
                   ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl,
                   ctx->d_bloom_weights, ctx->d_quirk_seen, ctx->d_quirk_aov, ctx->d_obj_vertices, ctx->d_obj_normals, ctx->d_obj_texcoords, ctx->d_obj_indices, ctx->d_face_meta, ctx->d_o2w, ctx->d_w2o,
-                  ctx->d_bvh8_box, ctx->d_denoise_tmp[0], ctx->d_denoise_tmp[1], ctx->d_hosek, ctx->d_owned_xy};
+                  ctx->d_bvh8_box, ctx->d_denoise_tmp[0], ctx->d_denoise_tmp[1], ctx->d_hosek, ctx->d_owned_xy, ctx->d_stack_spill};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }

@@ -76,6 +76,9 @@ struct fh_ctx {
   uint32_t bvh8_depth = 0;            // levels of the wide tree = most entries a traversal stack can hold
   uint32_t occupancy_key = 0xffffffffu, occupancy_blocks = 0, occupancy_blocks_secondary = 0;  // resident workgroups per CU of the streaming kernels, as the runtime reports them (render.hip)
   uint32_t lds_configured_bytes = 0;  // dynamic-LDS size the traversal kernels were last configured for (render.hip)
+  uint32_t stream_lds_entries = 0;    // stack levels the streaming kernels keep in LDS (the rest spills to d_stack_spill)
+  uint2* d_stack_spill = nullptr;     // [6 launches in flight][entry beyond the LDS part][thread of the launch]
+  size_t stack_spill_capacity = 0;    // in uint2
   uint32_t lds_static_max = 0;        // largest static LDS of a kernel that keeps its traversal stack in dynamic LDS (hipFuncGetAttributes; render.hip: configure_traversal_lds)
   bool use_bvh8 = false;
   int builder_choice = 0;  // 0 = not decided for this scene, 1 = radix tree (LBVH), 2 = PLOC; decided at the first build after an upload
@@ -139,6 +142,7 @@ struct fh_ctx {
     uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill
     uint32_t stream_min_rays = 64;  // FH_STREAM_MIN_RAYS: queue entries per wave below which workgroups of a streaming launch stay out (render.hip: stream_block_idle); 0 = all take part
     bool overlap_secondary = true;  // FH_OVERLAP=0: single-pass calls keep every launch on one stream
+    uint32_t stack_lds_entries = 0; // FH_STACK_LDS=n: stack levels the streaming kernels keep in LDS (0: as many as cost no workgroup; 99: all)
     bool sort_small = false;        // FH_SORT_SMALL=1: cell-order the bounce queues of trees the fixed-batch kernels trace as well
     uint32_t stream_chunk = 64;     // FH_STREAM_CHUNK: queue entries a wave takes per global atomic (setting it also switches the adaptive maximum off)
     bool stream_chunk_fixed = false;

@@ -353,6 +353,7 @@ struct GroupStack<false> {
   int sp = 0;
   uint2 spill[kBvh8Stack];
   FH_D GroupStack(uint2*, int) {}
+  FH_D GroupStack(uint2*, int, uint2*, uint32_t, uint32_t) {}
   FH_D void push(uint2 g) { if (sp < kBvh8Stack) spill[sp++] = g; }
   FH_D uint2 pop() { return spill[--sp]; }
 };
@@ -361,13 +362,33 @@ struct GroupStack<true> {
   // 5 bytes per entry: a word (first-child node index << 8 | pending hit bits) and a byte (the group's inner-child mask), each in its own
   // column array [entry][thread] -- 1.25 KB per tree level and workgroup instead of 2 KB, which is a workgroup more per CU on every tree
   // deeper than eight levels (node indices stay below 2^24: the builder refuses larger trees)
+  // The streaming kernels may keep only the first `cap` levels there (StackSpill): deeper entries go to a column of global memory, [entry][thread of the launch]
+  // like the LDS part, so that a tree of many levels -- whose deep entries are rarely reached -- does not cost a workgroup per CU.
   uint32_t* word;
   uint8_t* mask;
   int sp = 0;
+  int cap = kBvh8Stack;
+  uint2* over = nullptr;   // this thread's column of the spill area
+  uint32_t ostride = 0;    // threads of the launch
   FH_D GroupStack(uint2* block_lds, int depth) : word((uint32_t*)block_lds + threadIdx.x), mask((uint8_t*)((uint32_t*)block_lds + depth * 256) + threadIdx.x) {}
-  FH_D void push(uint2 g) { word[sp * 256] = (g.x << 8) | (g.y >> 24); mask[sp * 256] = (uint8_t)g.y; ++sp; }
-  FH_D uint2 pop() { --sp; const uint32_t w = word[sp * 256]; return make_uint2(w >> 8, (w << 24) | mask[sp * 256]); }
+  FH_D GroupStack(uint2* block_lds, int depth, uint2* spill, uint32_t threads, uint32_t thread)
+      : word((uint32_t*)block_lds + threadIdx.x), mask((uint8_t*)((uint32_t*)block_lds + depth * 256) + threadIdx.x), cap(spill ? depth : kBvh8Stack), over(spill ? spill + thread : nullptr), ostride(threads) {}
+  FH_D void push(uint2 g)
+  {
+    if (sp < cap) { word[sp * 256] = (g.x << 8) | (g.y >> 24); mask[sp * 256] = (uint8_t)g.y; }
+    else over[(size_t)(uint32_t)(sp - cap) * ostride] = g;
+    ++sp;
+  }
+  FH_D uint2 pop()
+  {
+    --sp;
+    if (sp >= cap) return over[(size_t)(uint32_t)(sp - cap) * ostride];
+    const uint32_t w = word[sp * 256];
+    return make_uint2(w >> 8, (w << 24) | mask[sp * 256]);
+  }
 };
+// where the streaming kernels put stack entries beyond the LDS part (null: everything in LDS)
+struct StackSpill { uint2* area; uint32_t lds_entries; };  // lds_entries: levels kept in LDS when area is set
 // dynamic LDS of one 256-thread workgroup whose lanes keep `depth` stack entries there
 FH_HD uint32_t lds_stack_bytes(uint32_t depth) { return (depth * 256u * 5u + 15u) & ~15u; }
 // Entries a traversal stack needs for a tree of `levels` node levels: a group is pushed while the ray descends into one of its nodes with siblings still to
@@ -614,10 +635,10 @@ struct ChunkFeed {
 // ---------------------------------------------------------------------------------------------
 template <bool MIXED, bool COUNT, bool LDS, bool ALPHA, class Policy>
 FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws, const CoopLds& cl, uint32_t flush, uint32_t refill,
-                          uint2* lds_column, int lds_stride, const SceneDev* sc)
+                          uint2* lds_column, int lds_stride, const SceneDev* sc, StackSpill spill = StackSpill{nullptr, 0u})
 {
   const uint32_t lane = __lane_id();
-  GroupStack<LDS> stack(lds_column, lds_stride);
+  GroupStack<LDS> stack(lds_column, spill.area ? (int)spill.lds_entries : lds_stride, spill.area, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x);
   Ray8 r;
   r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct = 0u; r.nx = r.ny = r.nz = false;
   uint2 group = make_uint2(0u, 0u);

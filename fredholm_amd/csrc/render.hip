@@ -298,7 +298,8 @@ struct ClosestStream {
 };
 
 template <bool COUNT, bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays)
+__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays,
+                                                                 StackSpill spill)
 {
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_RAD];
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, Po
   WaveSteps ws;
   ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, stream_chunk_for(count, chunk)), tc.hist);
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // the traversal stack of every lane: [entry][thread], as many entries as the BVH has levels
-  traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc);
+  traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill);
   stamp.commit(tc.clk);
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
@@ -1000,7 +1001,7 @@ struct SecondaryStream {
 };
 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
-__global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : 6)) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays)
+__global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : 6)) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays, StackSpill spill)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
@@ -1013,7 +1014,7 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)), tc.hist);
-  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc);
+  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill);
   pol.finish();
   stamp.commit(tc.clk);
   if (COUNT) {
@@ -1584,24 +1585,46 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   }
   if (sc.use_bvh8 && stack_bytes + ctx->lds_static_max > tun.lds_per_block) return fail(ctx, FH_E_UNSUPPORTED, "fh_render: BVH too deep for the LDS traversal stack");
   // all workgroups of a streaming launch are resident: as many per CU as its LDS (160 KB on gfx950) holds (at most 6: the kernels' register budget)
-  uint32_t wgs_per_cu = tun.lds_per_cu / (stack_bytes + kCoopLdsBytesPerBlock);
-  wgs_per_cu = wgs_per_cu > 6u ? 6u : (wgs_per_cu < 1u ? 1u : wgs_per_cu);
+  const uint32_t stack_entries = stack_entries_for(ctx->bvh8_depth);
   if (stream) {  // what the runtime says really fits (LDS granularity, registers of the variant in use): a grid above it would leave blocks queued behind the resident ones
-    const uint32_t key = stack_bytes | (count ? 1u : 0u) | (sc.has_alpha ? 2u : 0u) | (sc.n_lights > 0 ? 4u : 0u);
+    const uint32_t key = stack_bytes | (count ? 1u : 0u) | (sc.has_alpha ? 2u : 0u) | (sc.n_lights > 0 ? 4u : 0u) | (tun.stack_lds_entries << 20);
     if (ctx->occupancy_key != key) {
+      auto occupancy = [&](uint32_t entries, int& a, int& b) {
+        const uint32_t bytes = lds_stack_bytes(entries);
+        with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
+          (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest_stream<decltype(C)::value, decltype(A)::value>, kBlock, bytes);
+          with_bool(sc.n_lights > 0, [&](auto Li) {
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>, kBlock, bytes);
+          });
+        }); });
+      };
+      // A deep tree's stack would cost a workgroup per CU (15 levels: five instead of six), and its deep entries are rarely reached: the streaming kernels keep the
+      // first levels in LDS and spill the rest to global memory (GroupStack<true>).  As many levels stay in LDS as still give the workgroups a tree of
+      // kStackLdsMin levels would have; FH_STACK_LDS=n fixes the number, FH_STACK_LDS=99 keeps everything in LDS.
+      constexpr uint32_t kStackLdsMin = 8;
+      uint32_t entries = stack_entries;
       int a = 0, b = 0;
-      with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest_stream<decltype(C)::value, decltype(A)::value>, kBlock, stack_bytes);
-        with_bool(sc.n_lights > 0, [&](auto Li) {
-          (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>, kBlock, stack_bytes);
-        });
-      }); });
+      occupancy(entries, a, b);
+      if (tun.stack_lds_entries) entries = tun.stack_lds_entries < stack_entries ? tun.stack_lds_entries : stack_entries;
+      else if (stack_entries > kStackLdsMin) {
+        int a_best = 0, b_best = 0;
+        occupancy(kStackLdsMin, a_best, b_best);
+        while (entries > kStackLdsMin && (a < a_best || b < b_best)) { --entries; occupancy(entries, a, b); }
+      }
+      if (entries != stack_entries) occupancy(entries, a, b);
       ctx->occupancy_key = key;
+      ctx->stream_lds_entries = entries;
       ctx->occupancy_blocks = a > 0 ? (uint32_t)a : 0u;
       ctx->occupancy_blocks_secondary = b > 0 ? (uint32_t)b : 0u;
-      if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[trace] stack %u B + %u B per workgroup: %d / %d resident workgroups per CU (closest / secondary)\n", stack_bytes, kCoopLdsBytesPerBlock, a, b);
+      if (getenv("FH_DEBUG_BVH"))
+        fprintf(stderr, "[trace] stack of %u entries, %u of them in LDS (%u B + %u B per workgroup): %d / %d resident workgroups per CU (closest / secondary)\n", stack_entries, entries, lds_stack_bytes(entries),
+                kCoopLdsBytesPerBlock, a, b);
     }
   }
+  const uint32_t stream_entries = stream ? ctx->stream_lds_entries : stack_entries;
+  const uint32_t stream_stack_bytes = lds_stack_bytes(stream_entries);
+  uint32_t wgs_per_cu = tun.lds_per_cu / (stream_stack_bytes + kCoopLdsBytesPerBlock);
+  wgs_per_cu = wgs_per_cu > 6u ? 6u : (wgs_per_cu < 1u ? 1u : wgs_per_cu);
   uint32_t wgs_closest = wgs_per_cu, wgs_secondary = wgs_per_cu;
   if (stream && ctx->occupancy_blocks && ctx->occupancy_blocks < wgs_closest) wgs_closest = ctx->occupancy_blocks;
   if (stream && ctx->occupancy_blocks_secondary && ctx->occupancy_blocks_secondary < wgs_secondary) wgs_secondary = ctx->occupancy_blocks_secondary;
@@ -1609,6 +1632,18 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < wgs_secondary) wgs_secondary = tun.stream_wgs_per_cu;
   const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_closest;
   const uint32_t stream_grid_secondary = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_secondary;
+  // spill area of the streaming launches: [launch in flight: pass slot x (closest, secondary)][entry beyond the LDS part][thread of the launch]
+  const uint32_t spill_entries = stream_entries < stack_entries ? stack_entries - stream_entries : 0u;
+  const size_t spill_threads = (size_t)(stream_grid > stream_grid_secondary ? stream_grid : stream_grid_secondary) * kBlock;
+  const size_t spill_region = (size_t)spill_entries * spill_threads;  // uint2 each
+  if (spill_region * 6u > ctx->stack_spill_capacity) {
+    FH_HIP(hipDeviceSynchronize());  // (launches of earlier calls may still use the old area)
+    if (ctx->d_stack_spill) FH_HIP(hipFree(ctx->d_stack_spill));
+    ctx->d_stack_spill = nullptr;
+    ctx->stack_spill_capacity = 0;
+    FH_HIP(hipMalloc((void**)&ctx->d_stack_spill, sizeof(uint2) * spill_region * 6u));
+    ctx->stack_spill_capacity = spill_region * 6u;
+  }
   // (rays through a small tree are cheap enough to run into the atomic rate of the work cursor: allow larger chunks there, stream_chunk_for)
   const uint32_t chunk_max = tun.stream_chunk_fixed ? tun.stream_chunk : (ctx->bvh8_n_nodes < 512u ? 256u : (ctx->bvh8_n_nodes < 4096u ? 128u : tun.stream_chunk));
   const uint32_t stream_refill = tun.stream_refill, stream_chunk = (tun.stream_chunk & 0xffffu) | ((chunk_max > tun.stream_chunk ? chunk_max : 0u) << 16);
@@ -1705,8 +1740,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         Span sp(ctx, st, 0);
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), stack_bytes, st, sc, pd, depth, tc_closest,
-                               coop_flush, stream_refill, stream_chunk_closest, tun.stream_min_rays);
+            hipLaunchKernelGGL((k_trace_closest_stream<decltype(C)::value, decltype(A)::value>), dim3(grid < stream_grid ? grid : stream_grid), dim3(kBlock), stream_stack_bytes, st, sc, pd, depth, tc_closest,
+                               coop_flush, stream_refill, stream_chunk_closest, tun.stream_min_rays, StackSpill{spill_entries ? ctx->d_stack_spill + (size_t)(2 * slot) * spill_region : nullptr, stream_entries});
           }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
@@ -1752,8 +1787,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         Span sp(ctx, sb, 1);
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stack_bytes, sb, sc,
-                               fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk, tun.stream_min_rays);
+            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stream_stack_bytes, sb, sc,
+                               fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk, tun.stream_min_rays,
+                               StackSpill{spill_entries ? ctx->d_stack_spill + (size_t)(2 * slot + 1) * spill_region : nullptr, stream_entries});
           }); }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
