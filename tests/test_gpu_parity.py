@@ -732,6 +732,22 @@ def test_small_path_pool_and_batching_do_not_change_results(oracle):
     _assert_image_parity(a["beauty"], ref["beauty"])
 
 
+@pytest.mark.parametrize("lds_levels", ["1", "3", "99"])
+def test_spilled_traversal_stack_does_not_change_results(oracle, monkeypatch, lds_levels):
+    """The streaming kernels keep the first levels of the traversal stack in LDS and spill deeper entries to global memory (render.hip: StackSpill; on its own only
+    for trees deep enough to cost a workgroup per CU).  FH_STACK_LDS forces the split: one level in LDS (nearly every push spills), three, all of them."""
+    monkeypatch.setenv("FH_STREAM", "1")
+    monkeypatch.setenv("FH_STACK_LDS", lds_levels)
+    cam = F.Camera(**scenes.SOUP_CAMERA)
+
+    def setup(x):
+        x.load_arhosek_sky(3.0, 0.3)
+
+    gpu, ref = _render_pair(oracle, scenes.triangle_soup(30000, 0.08), cam, 96, 54, launches=2, spp_per_launch=2, depth=6, setup=setup)
+    _assert_image_parity(gpu["beauty"], ref["beauty"])
+    _assert_image_parity(gpu["position"], ref["position"])
+
+
 def test_fused_tail_depth_does_not_change_results(oracle):
     sc = scenes.cornell_box()
     cam = F.Camera(**scenes.CORNELL_CAMERA)
