@@ -1577,7 +1577,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   // streaming form (FH_STREAM=0: one fixed batch per wave).  Through a small tree every ray takes the same few steps: nothing to rebalance, and the fixed
   // batches run without the refill machinery (1000-triangle soup: closest 7.4 -> 4.6 ms, secondary 2.6 -> 1.0 ms per 256 spp; even at ~2 K nodes; behind at 20 K)
   const bool stream = coop && tun.stream && (tun.stream_forced || ctx->bvh8_n_nodes >= 4096u);
-  // the traversal stack of every lane lives in LDS, one entry per level of the BVH (bvh_build.hip records the depth): no overflow path
+  // the traversal stack of every lane lives in LDS, one entry per level of the BVH (bvh_build.hip records the depth); the streaming kernels may spill deep levels (below)
   const uint32_t stack_bytes = lds_stack_bytes(stack_entries_for(ctx->bvh8_depth));
   if (sc.use_bvh8 && ctx->lds_configured_bytes != stack_bytes) {  // kernels that may need more than the default 64 KB of LDS are told so once per BVH depth
     const int rc = configure_traversal_lds(ctx, stack_bytes);
