@@ -412,6 +412,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_off("FH_SORT_SMALL", t.sort_small);
     env_off("FH_OVERLAP", t.overlap_secondary);
     env_uint("FH_STACK_LDS", 1, 99, t.stack_lds_entries);
+    env_uint("FH_SHADE_WGS", 2, 3, t.shade_wgs);
     env_uint("FH_STREAM_CHUNK", 16, 65535, t.stream_chunk);
     t.stream_chunk_fixed = getenv("FH_STREAM_CHUNK") != nullptr;
     if (t.stream_chunk_fixed) t.stream_chunk_closest = t.stream_chunk;  // (FH_STREAM_CHUNK alone sets both launches)

@@ -142,6 +142,7 @@ struct fh_ctx {
     uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill
     uint32_t stream_min_rays = 64;  // FH_STREAM_MIN_RAYS: queue entries per wave below which workgroups of a streaming launch stay out (render.hip: stream_block_idle); 0 = all take part
     bool overlap_secondary = true;  // FH_OVERLAP=0: single-pass calls keep every launch on one stream
+    uint32_t shade_wgs = 0;         // FH_SHADE_WGS=2|3: workgroups per CU the shade kernels are compiled for (0: three for textured scenes that stream)
     uint32_t stack_lds_entries = 0; // FH_STACK_LDS=n: stack levels the streaming kernels keep in LDS (0: as many as cost no workgroup; 99: all)
     bool sort_small = false;        // FH_SORT_SMALL=1: cell-order the bounce queues of trees the fixed-batch kernels trace as well
     uint32_t stream_chunk = 64;     // FH_STREAM_CHUNK: queue entries a wave takes per global atomic (setting it also switches the adaptive maximum off)

@@ -47,8 +47,11 @@ constexpr uint32_t kMatLds = 32;  // material records staged in LDS by the shade
 #define FH_SECONDARY_BLOCKS_HEAVY 5  // resident workgroups per CU the secondary streaming kernel is compiled for when it carries the emitter / any-hit code
 #endif
 #ifndef FH_SHADE_BLOCKS
-#define FH_SHADE_BLOCKS 2  // resident workgroups per CU the specialised shade kernels are compiled for (register budget = 512 / that per lane): they need 208-230 registers
-#endif                     // since their products go to memory as they are made (PoolSink); the generic seven-lobe kernel keeps one wave per SIMD (391 registers, no spills)
+#define FH_SHADE_BLOCKS 2  // resident workgroups per CU the specialised shade kernels are compiled for (register budget = 512 / that per lane): they take 159-182 registers
+#endif                     // since their products go to memory as they are made (PoolSink); the generic seven-lobe kernel keeps one wave per SIMD (350 registers).
+// A second set is compiled for THREE workgroups per CU (168 registers, 6-7 of them spilled: 28-32 B of scratch).  It is what textured scenes get (render_submit): their hits wait for
+// texels, and a third wave per SIMD covers that -- configs[3]: shade 3.87 -> 3.53 s alone, frame 525 -> 542 Msamples/s; the untextured configurations lose with it next to the
+// other passes' kernels (configs[1] 2210 -> 2025: three shade workgroups hold 80 KB of a CU's LDS), so they keep two.  FH_SHADE_WGS=2|3 forces either.
 
 // generator matrices of the N Sobol' dimensions a kernel draws from, staged in LDS in their byte-indexed form (4 KB per dimension, FrameDev::sobol_bytes):
 // the XOR over the 32 index bits is four LDS reads instead of 32 bit tests (~85 instructions less per draw; the shade kernels draw three or four per hit)
@@ -738,8 +741,8 @@ __global__ void __launch_bounds__(kSortBlock) k_cell_scatter(const uint32_t* cou
   }
 }
 
-template <uint32_t LOBES>
-__global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : FH_SHADE_BLOCKS)) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
+template <uint32_t LOBES, int BLOCKS = FH_SHADE_BLOCKS>
+__global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : BLOCKS)) k_shade(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t cls, uint32_t depth)
 {
   // (the grid is sized for every path of the pass; the blocks beyond this class's queue leave before they stage anything)
   if (blockIdx.x * blockDim.x >= pool.counters[depth * kCounterStride + CNT_CLS + cls]) return;
@@ -1290,20 +1293,21 @@ uint32_t grid_for(uint32_t n)  // multiple of 8 (one share per XCD), at most 819
 }
 
 template <uint32_t LOBES>
-void launch_shade(hipStream_t st, uint32_t grid, const SceneDev& sc, const FrameDev& fr, const PoolDev& pool, uint32_t cls, uint32_t depth)
+void launch_shade(hipStream_t st, uint32_t grid, const SceneDev& sc, const FrameDev& fr, const PoolDev& pool, uint32_t cls, uint32_t depth, bool three)
 {
-  hipLaunchKernelGGL(k_shade<LOBES>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, cls, depth);
+  if (three && LOBES != L_ALL) hipLaunchKernelGGL((k_shade<LOBES, (LOBES == L_ALL ? FH_SHADE_BLOCKS : 3)>), dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, cls, depth);
+  else hipLaunchKernelGGL(k_shade<LOBES>, dim3(grid), dim3(kBlock), 0, st, sc, fr, pool, cls, depth);
 }
 
-void dispatch_shade(hipStream_t st, uint32_t grid, uint32_t lobes, const SceneDev& sc, const FrameDev& fr, const PoolDev& pool, uint32_t cls, uint32_t depth)
+void dispatch_shade(hipStream_t st, uint32_t grid, uint32_t lobes, const SceneDev& sc, const FrameDev& fr, const PoolDev& pool, uint32_t cls, uint32_t depth, bool three)
 {
   // compiled variants, most specific first; a variant is usable when it contains every lobe the class needs
-  if ((lobes & ~(uint32_t)L_DIFF) == 0) return launch_shade<L_DIFF>(st, grid, sc, fr, pool, cls, depth);
-  if ((lobes & ~(uint32_t)L_METAL) == 0) return launch_shade<L_METAL>(st, grid, sc, fr, pool, cls, depth);
-  if ((lobes & ~(uint32_t)(L_SPEC | L_DIFF)) == 0) return launch_shade<L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth);
-  if ((lobes & ~(uint32_t)(L_METAL | L_SPEC | L_DIFF)) == 0) return launch_shade<L_METAL | L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth);  // glTF metallic-roughness materials
-  if ((lobes & ~(uint32_t)(L_COAT | L_METAL | L_SPEC | L_DIFF)) == 0) return launch_shade<L_COAT | L_METAL | L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth);  // ... with KHR_materials_clearcoat
-  return launch_shade<L_ALL>(st, grid, sc, fr, pool, cls, depth);
+  if ((lobes & ~(uint32_t)L_DIFF) == 0) return launch_shade<L_DIFF>(st, grid, sc, fr, pool, cls, depth, three);
+  if ((lobes & ~(uint32_t)L_METAL) == 0) return launch_shade<L_METAL>(st, grid, sc, fr, pool, cls, depth, three);
+  if ((lobes & ~(uint32_t)(L_SPEC | L_DIFF)) == 0) return launch_shade<L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth, three);
+  if ((lobes & ~(uint32_t)(L_METAL | L_SPEC | L_DIFF)) == 0) return launch_shade<L_METAL | L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth, three);  // glTF metallic-roughness materials
+  if ((lobes & ~(uint32_t)(L_COAT | L_METAL | L_SPEC | L_DIFF)) == 0) return launch_shade<L_COAT | L_METAL | L_SPEC | L_DIFF>(st, grid, sc, fr, pool, cls, depth, three);  // ... with KHR_materials_clearcoat
+  return launch_shade<L_ALL>(st, grid, sc, fr, pool, cls, depth, three);
 }
 
 hipEvent_t take_event(fh_ctx* ctx)
@@ -1654,6 +1658,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   // cell-ordered queues pay where rays of one cell share the nodes they fetch; a tree the fixed-batch kernels trace (under 4096 nodes) sits in the caches whatever
   // the order, and there the six sort launches per bounce are what a small frame waits for (Cornell box, 1 spp: 0.33 of 2.15 ms)
   const bool sort_queues = tun.sort_queues && (stream || tun.sort_small);
+  const bool shade_three = tun.shade_wgs ? tun.shade_wgs == 3u : (stream && sc.n_textures > 0);  // (above, FH_SHADE_BLOCKS)
 
   for (uint32_t done = 0; done < n_samples; done += batch) {
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
@@ -1762,7 +1767,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       if (overlap && depth > 0) FH_HIP(hipStreamWaitEvent(st, ctx->ev_bounce[2u * (depth - 1u) + 1u], 0));  // the secondary launch of the bounce before reads what the shade kernels and the sorts below overwrite
       {
         Span sp(ctx, st, 2);
-        for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pd, c, depth);
+        for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pd, c, depth, shade_three);
         if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pd);
         ctx->stats.n_shade_launches += ctx->n_classes;
       }
