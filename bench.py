@@ -39,7 +39,7 @@ GENERATE_BYTES_PER_PATH, ACCUMULATE_BYTES_PER_SAMPLE = 116, 84 + 88
 # v_max3 / v_min3 / v_max / v_min, v_cmp, v_cndmask, shifts, logic, integer multiply -- in ~4.1 cycles (0.56-0.58 G/s), the two kinds side by side (a 1:1 mix of v_fma_f32
 # and v_max3_f32: 2.3 cycles per instruction).  The cost of a piece of code is therefore ~4.1 cycles x its non-FMA instructions, and what the kernels are made of was
 # measured directly, operands in registers, eight waves per SIMD, nothing but issue in the way:
-NODE_TEST_SIMD_CYCLES = 510.0  # one wave-level 8-wide node test incl. the octant permutation (fh_trace.h: node8_test): 0.0047 G tests/s per SIMD at 2.384 GHz
+NODE_TEST_SIMD_CYCLES = 510.0  # one wave-level 8-wide node test incl. the octant permutation (fh_trace.h: node8_test): 0.0047 G tests/s per SIMD at 2.384 GHz (510.1 and 512.4 in two runs)
 TRI_TEST_SIMD_CYCLES = 175.0   # one wave-level watertight triangle test (fh_trace.h: tri_test): 0.0135 G tests/s per SIMD at 2.367 GHz
 NOMINAL_CLOCK_GHZ = 2.4
 N_SIMDS = 1024
