@@ -747,3 +747,28 @@ def test_damaged_files_raise_errors_never_crash(tmp_path, image_dump, scene_dump
             except ValueError:
                 outcomes["error"] += 1
     assert outcomes["error"] > 100 and outcomes["ok"] > 10
+
+
+def test_every_bench_configuration_has_a_counter_file_the_bench_line_can_quote():
+    """bench.py cannot read hardware counters from inside its process: roofline.traffic / .valu / .vl1d are quoted from the counter summaries committed under
+    profiles/ (tools/profile_round3.sh, tools/collect_profile3.py), matched by configuration and by the samples per pass the counters were collected with.
+    Every GPU configuration of BASELINE.json must have one, with the fields the line uses and numbers that can be what they say they are."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for cfg in (1, 2, 3, 4):
+        found = None
+        for spp in range(1, 257):  # whatever pass size the file was collected with
+            found = bench.pmc_file(cfg, spp, 1920, 1080)
+            if found:
+                break
+        assert found, f"no profiles/r*_traffic*.json for configs[{cfg}]"
+        assert os.path.exists(os.path.join(ROOT, found["file"]))
+        assert found["kernel"].startswith("k_") and found["traffic_bytes_per_launch"] > 0 and found["valu_insts_per_launch"] > 0
+        assert 0.0 < found["valu_lane_utilisation"] <= 1.0 and 0.0 < found["tcc_hit_rate"] <= 1.0
+        v = found.get("vl1d")
+        assert v, f"{found['file']}: no vector-memory passes"
+        # the L1 looks up at most one line per cycle and CU (profiles/r03_issue_peak.txt): a larger figure means cycles and accesses of different runs were mixed
+        assert 0.0 < v["accesses_per_cycle_per_cu"] <= v["peak_accesses_per_cycle_per_cu"] == 1.0
+        assert 0.0 < v["ta_busy_frac"] <= 1.0
+        assert os.path.exists(os.path.join(ROOT, v["source"].split(";")[0]))

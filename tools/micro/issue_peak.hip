@@ -1,7 +1,9 @@
-// issue_peak.hip -- sustained VALU issue rates on gfx950 with the shader clock measured in the kernel, and the rate at which the
+// issue_peak.hip -- sustained VALU issue rates on gfx950 with the shader clock measured in the kernel, the rate at which the
 // traversal kernels' own instruction mixes (the 8-wide node test, the watertight triangle test of fh_trace.h) can be issued when
-// nothing but instruction issue limits them.  These are the ceilings bench.py prices the traversal kernels against
-// (roofline.bound = "valu_issue"); profiles/r03_issue_peak.txt holds the output.
+// nothing but instruction issue limits them, and the rate at which the vector L1 serves the loads of a node visit (every lane its
+// own line).  These are the ceilings bench.py prices the traversal kernels against (roofline.bound = "valu_issue", roofline.vl1d);
+// profiles/r03_issue_peak.txt holds the output.  The run starts by checking the node test against the exact slab test in double
+// precision on 16.7 M random (node, ray) pairs: it may flag a child the ray misses, never miss one it enters.
 //
 // Method (MI355X_MICROARCH.md, "DVFS give-back" item 6): every point is ONE launch of >= 50 ms after >= 2 s of back-to-back
 // launches; every wave stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its loop, so
