@@ -343,7 +343,7 @@ FH_D bool first_active_lane() { return __lane_id() == (uint32_t)__ffsll((long lo
 // Traversal stack of node groups.  A group is pushed only while descending into one of its children, so the stack never holds
 // more entries than the tree has levels; the builder records that number (fh_ctx::bvh8_depth) and refuses trees deeper than kBvh8Stack.
 //   GroupStack<true>   every entry in LDS, column layout [entry][thread] (conflict-free; constructed from the block's LDS and the tree depth); the launcher sizes the dynamic LDS for the
-//                      tree's depth, so there is no overflow path and no private array: `sp` lives in a register.  (The first build kept
+//                      tree's depth (the streaming kernels may spill the deepest levels to global memory, below), so there is no private array: `sp` lives in a register.  (The first build kept
 //                      6 entries in LDS and the rest in a private array; the compiler then kept the whole object, `sp` included, in scratch:
 //                      every push and pop started with a scratch load on the dependent path -- 408 B of scratch, ~1 GB of writes per launch.)
 //   GroupStack<false>  a private array, for the per-lane loops of k_tail and the batch queries.
@@ -394,7 +394,7 @@ struct StackSpill { uint2* area; uint32_t lds_entries; };  // lds_entries: level
 FH_HD uint32_t lds_stack_bytes(uint32_t depth) { return (depth * 256u * 5u + 15u) & ~15u; }
 // Entries a traversal stack needs for a tree of `levels` node levels: a group is pushed while the ray descends into one of its nodes with siblings still to
 // visit; the root's group holds the root alone and is never pushed, so the groups that can be on the stack at once are those of levels 1 .. levels - 1.
-// (One entry fewer than levels is 1.25 KB per workgroup: five workgroups per CU instead of four on the 15-level tree of the Sponza-class scene.)
+// (One entry fewer than levels is 1.25 KB per workgroup: five workgroups per CU instead of four on the 15-level tree of the Sponza-class scene with the whole stack in LDS.)
 FH_HD uint32_t stack_entries_for(uint32_t levels) { return levels < 2u ? 1u : levels - 1u; }
 
 template <bool ANY_HIT, bool COUNT, bool LDS = false, bool ALPHA = false>
