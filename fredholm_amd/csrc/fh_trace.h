@@ -235,8 +235,8 @@ FH_D uint32_t octant_permute(uint32_t m, uint32_t oct)
 // Per child: 6 conversions, max3, min3, alignbit = 9 of the slow kind (12 before), plus v_min + v_rcp per node for 1 / tmax.
 // The comparison is strict because both sides saturate: a box behind the ray gives 0 < 0, one beyond tmax 1 < 1, an empty slot (lo 255, hi 0) never has
 // near < far.  A box the ray really enters has near' < far' by what the build's padding and the slack below put between them, and 1 / tmax is rounded
-// down by two units (v_rcp_f32 is good to one), so a box that starts just before tmax is never cut off.  tmax < 0: no child is hit (every scaled interval is reversed), as with the unscaled
-// comparison; tmax = 0: the scale is infinite and children may be flagged, but no triangle is accepted (the ray's hit record starts at its tmax); a NaN tmax
+// down by two units (v_rcp_f32 is good to one), so a box that starts just before tmax is never cut off.  tmax < 0: every scaled interval is reversed, so no child with a proper box is hit, as with the unscaled
+// comparison (an empty slot's inverted box can be flagged then: its triangle slot holds the degenerate triangle no ray hits); tmax = 0: the scale is infinite and children may be flagged, but no triangle is accepted (the ray's hit record starts at its tmax); a NaN tmax
 // counts as no limit in v_min_f32, as it did in the minimum of the unscaled form.
 #ifndef FH_NODE_SLACK
 #define FH_NODE_SLACK 1

@@ -3,7 +3,7 @@
 The HIP code itself is checked on the GPU (tools/micro/issue_peak.hip compares it with the slab test in double precision on 16.7 M random pairs, and every
 -m gpu parity test traverses with it); this file pins the ALGORITHM -- distances in units of the ray's limit, clamped to [0, 1], a strict comparison of
 max3(near) and min3(far), near planes moved in and far planes out by 2^-21 of the axis' offset -- and the properties the kernels rely on:
-it never misses a child the ray enters before tmax, it flags nothing for a negative tmax, an empty slot (lo 255, hi 0) is never flagged.
+it never misses a child the ray enters before tmax, it flags no proper box for a negative tmax, an empty slot (lo 255, hi 0) is never flagged for a limit >= 0.
 The model computes in float32 with the fused multiply-add taken in float64 and rounded once (exact products, one rounding)."""
 import numpy as np
 import pytest
@@ -105,7 +105,10 @@ def test_negative_limit_flags_nothing_and_empty_slots_are_never_flagged():
     rng = np.random.default_rng(7)
     n = 100_000
     o, inv, words, lo, hi = random_cases(rng, n)
-    assert not node8_test(o, inv, words, lo, hi, np.full(n, -1.0, f32)).any()
+    # a negative limit reverses every scaled interval: no box with lo <= hi on some axis can be flagged.  (A box inverted on all three axes can -- in a tree
+    # that is an empty slot, whose triangle slot holds the degenerate triangle no ray hits.)
+    flagged = node8_test(o, inv, words, lo, hi, np.full(n, -1.0, f32))
+    assert not (flagged & (lo <= hi).any(axis=1)).any()
     lo[:, :, 3], hi[:, :, 3] = 255, 0  # slot 3 empty everywhere (the builder's inverted box)
     got = node8_test(o, inv, words, lo, hi, np.full(n, 1e9, f32))
     assert not got[:, 3].any()
