@@ -1,3 +1,4 @@
+    # path-pool slots = owned pixels x samples per pass, one pool per pass in flight (pass_size above)
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the path-tracing hot path on MI355X (BASELINE.json metric).
 
@@ -47,6 +48,71 @@ VALU_FMA_PEAK_PER_CYCLE, VALU_OTHER_PEAK_PER_CYCLE = 1.0 / 2.2, 1.0 / 4.1  # wav
 # share of FMA-class instructions (v_fma / v_fmac / v_mul / v_add / v_sub_f32 and their packed forms) among the VALU instructions of the kernels that have no step counters of
 # their own, counted over the code object (tools/isa_stats.py --hist): with the two classes issuing side by side an instruction of such a mix costs max(share x 2.2, (1 - share) x 4.1) cycles
 STATIC_FMA_SHARE = {"k_shade": 0.39, "k_generate": 0.37}
+ISSUE_MODEL_SOURCE = "tools/micro/issue_peak.hip -> profiles/r03_issue_peak.txt (operands in registers, 8 waves per SIMD, >= 60 ms per point, clock from s_memtime / s_memrealtime)"
+
+
+def source_fingerprint():
+    """hash of everything the device code is compiled from: ties a counter file (profiles/*_traffic_config*.json) and the issue-model constants to the code that ran"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "fredholm_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "fredholm_amd", "csrc", "*.h")) + [os.path.join(ROOT, "fredholm_amd", "csrc", "Makefile")] +
+                   glob.glob(os.path.join(ROOT, "include", "fh_*.h")))
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def file_hash(rel):
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
+
+
+def issue_model():
+    """cycles a wave-level node test / triangle test costs a SIMD when nothing but issue limits it: the newest profiles/r*_issue_peak.json (written by tools/micro/issue_peak.bin --json on the GPU box,
+    which compiles fh_trace.h's own node8_test / tri_test) or, without one, the round-3 constants above.  `stale` = fh_trace.h has changed since the file was measured."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_peak.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+            return {"node": float(j["node8_test_simd_cycles"]), "tri": float(j["tri_test_simd_cycles"]), "source": os.path.relpath(f, ROOT) + " (tools/micro/issue_peak.hip, which includes fh_trace.h)",
+                    "stale": j.get("fh_trace_h_sha256_16") != file_hash("fredholm_amd/csrc/fh_trace.h")}
+        except Exception:
+            continue
+    return {"node": NODE_TEST_SIMD_CYCLES, "tri": TRI_TEST_SIMD_CYCLES, "source": ISSUE_MODEL_SOURCE, "stale": True}
+
+
+def traversal_roofline(cnt, timed, key, steps, launches, avg_ms, avg_alone_ms, bytes_per_launch, kernel_name, where, bw, traffic):
+    """bound: VALU issue.  `achieved` = SIMD issue cycles per second that went into the kernel's essential work -- its wave-level node tests and triangle tests (counted by the
+    instrumented replay), each at the cycles it costs a SIMD when nothing but issue limits it -- `peak` = the issue cycles the chip has: 1024 SIMDs x the nominal 2.4 GHz.  Everything
+    else the kernel spends cycles on (stack, queues, refill, waits; idle lanes are inside the wave-level counts) is below the line.  MODEL-DERIVED: the two per-test costs come from a
+    microbenchmark, not from this run.  The HBM view SURVEY.md 8(d) asks for stays under `algorithmic_*`: those bytes come from L2 / Infinity Cache, not from HBM."""
+    im = issue_model()
+    wn, wt = cnt[f"wave_node_steps_{key}"], cnt[f"wave_tri_steps_{key}"]
+    ck = "closest" if key == "closest" else "shadow"
+    rays, nodes, tris = cnt[f"rays_{ck}"], cnt[f"nodes_{ck}"], cnt[f"tris_{ck}"]
+    issue_cycles_per_launch = (wn * im["node"] + wt * im["tri"]) * steps / launches
+    achieved = issue_cycles_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    peak = N_SIMDS * NOMINAL_CLOCK_GHZ
+    alg_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    clock = timed[f"clk_cycles_{ck}"] / timed[f"clk_ticks_{ck}"] * 0.1 if timed.get(f"clk_ticks_{ck}") else None
+    bw_read, bw_copy = bw
+    return {"bound": "valu_issue", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "G SIMD issue cycles/s", "frac": round(achieved / peak, 5),
+            "frac_is": "model-derived: counted wave-level tests x microbenchmarked issue cycles per test (issue_model) / launch time measured in this run",
+            "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": int(launches), "avg_launch_ms_alone": round(avg_alone_ms, 4),
+            "frac_alone": round(issue_cycles_per_launch / (avg_alone_ms * 1e-3) / 1e9 / peak, 5) if avg_alone_ms > 0 else None,
+            "clock_ghz_in_kernel": round(clock, 4) if clock else None,
+            "frac_at_held_clock": round(achieved / (N_SIMDS * clock), 5) if clock else None,
+            "issue_model": {"node_test_simd_cycles": im["node"], "tri_test_simd_cycles": im["tri"], "wave_node_tests_per_launch": int(wn * steps / launches),
+                            "wave_tri_tests_per_launch": int(wt * steps / launches), "source": im["source"], "stale": im["stale"]},
+            "lane_utilisation": {"node_tests": round(nodes / max(64 * wn, 1), 4), "triangle_tests": round(tris / max(64 * wt, 1), 4)},
+            "per_ray": {"nodes": round(nodes / max(rays, 1), 2), "triangles": round(tris / max(rays, 1), 2), "bytes": round(bytes_per_launch * launches / steps / max(rays, 1), 1)},
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_gbs": round(alg_gbs, 1), "frac_algorithmic_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 5),
+            "measured_hbm_gbs": {"read": round(bw_read, 1), "copy": round(bw_copy, 1)},
+            "note": where + "; achieved = (wave-level node tests x %g + wave-level triangle tests x %g SIMD cycles)" % (im["node"], im["tri"]) + " per launch / launch time measured inside the timed region, where passes on the other "
+                    "streams share the GPU with the launch; *_alone: the same launch with the GPU to itself (one untimed step with serial passes); algorithmic_* = SURVEY.md 8(d) bytes per ray x rays, "
+                    "priced against HBM only for reference -- node and triangle arrays are served by L2 / Infinity Cache, see traffic"}
 
 
 def workload(cfg, tmpdir):
@@ -97,13 +163,13 @@ def checker_scene(w):
     import ctypes
     from oracle import pyoracle as O
 
-    if "scene" not in _CHECKER:
+    if w["name"] not in _CHECKER:
         S = O.Scene(w["scene"])
         apply_environment(S, w)
         if w["sun"] is not None and not w["dir_le"]:
             O.lib().orc_set_directional_light(S.h, 0, None, None, ctypes.c_float(0))  # ... without a directional light
-        _CHECKER["scene"] = S
-    return _CHECKER["scene"]
+        _CHECKER[w["name"]] = S
+    return _CHECKER[w["name"]]
 
 
 def cpu_baseline(w, seconds_target=12.0):
@@ -209,6 +275,107 @@ def pmc_file(cfg, pool_spp, width, height):
     return None
 
 
+def pass_size(r, torch, local_rank, n_owned, spp, pool_spp_arg=0):
+    """samples per pixel per pass of the path pool.  Big passes amortise what a pass pays once (its longest rays, the ends of the streaming launches): 64 / 96 / 128 spp of a 1080p
+    frame per pass measure 5874 / 6178 / 6312 Msamples/s on configs[2].  A step is split into equal passes of at most ~128 spp of a 1080p frame, of at most 3/4 of the device memory
+    still free for all pools together (minus 2 GiB for what RCCL and the bandwidth probe allocate later), and into at least three passes, so that the library's
+    three-passes-in-flight pipelining has something to overlap inside a step"""
+    slot_bytes, n_pools = r.path_pool_bytes()
+    if pool_spp_arg > 0:
+        return pool_spp_arg, slot_bytes, n_pools
+    try:
+        free_bytes = max(torch.cuda.mem_get_info(local_rank)[0] - (2 << 30), 1 << 30)
+    except Exception:  # (no memory query: the pass size of rounds 1-2, 64 spp of a 1080p frame, fits any MI355X)
+        free_bytes = int(1920 * 1080 * 64 * 1.02) * n_pools * slot_bytes / 0.75
+    cap = min(int(1920 * 1080 * 128 * 1.02), int(0.75 * free_bytes / (n_pools * slot_bytes)))  # 2 % slack: tile ownership is not perfectly even across ranks
+    passes = max(3, -(-n_owned * spp // cap))
+    return max(-(-spp // passes), 1), slot_bytes, n_pools
+
+
+def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1):
+    """The general-scene leg of the default run (outside the headline's timed region): BASELINE.json configs[3] -- the Sponza-class textured interior, where every camera ray
+    hits and a sample is 1.7 closest-hit + 4.6 secondary rays -- for `steps` frames of `spp` samples, plus the reference's own call pattern on it (1 and 16 samples per call,
+    app/controller.cpp:205-230, app/rtcamp8.cpp:183-189), the dominant traversal kernel's roofline record and a parity crop against the CPU checker.  configs[2], the headline,
+    sends 84 % of its camera rays past the scene; this is the number a user of the reference's GUI sees."""
+    import torch
+
+    import fredholm_amd as F
+    from fredholm_amd import native as N
+
+    w = workload(3, tmpdir)
+    W, H, D = w["width"], w["height"], w["depth"]
+    r = F.Renderer(local_rank)
+    r.load_scene(w["scene"])
+    r.build_ias()
+    apply_environment(r, w)
+    r.set_resolution(W, H)
+    cam = F.Camera(**w["camera"])
+    dev = torch.device("cuda", local_rank)
+    bufs = {n: torch.zeros((H, W) if n == "depth" else (H, W, 4), dtype=torch.float32, device=dev) for n in F.RenderLayer.NAMES}
+    layers = F.RenderLayer(r, W, H, pointers={n: t.data_ptr() for n, t in bufs.items()})
+    n_owned = r.owned_pixel_count()
+    pool_spp, slot_bytes, n_pools = pass_size(r, torch, local_rank, n_owned, spp)
+    r.set_path_pool(n_owned * pool_spp)
+    for _ in range(warmup):
+        r.render(cam, w["bg"], layers, spp, D)
+    r.wait_for_completion()
+    r.set_flags(N.FLAG_TIME_KERNELS)
+    r.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.render(cam, w["bg"], layers, spp, D)
+        r.wait_for_completion()
+    dt = time.perf_counter() - t0
+    timed = r.stats()
+    r.set_flags(N.FLAG_TIME_KERNELS | N.FLAG_SERIAL_PASSES)
+    r.reset_stats()
+    r.render(cam, w["bg"], layers, spp, D)
+    r.wait_for_completion()
+    alone = r.stats()
+    r.set_flags(N.FLAG_COUNT_TRAVERSAL)
+    r.reset_stats()
+    r.render(cam, w["bg"], layers, spp, D)
+    r.wait_for_completion()
+    cnt = r.stats()
+    r.set_flags(0)
+    node_bytes = timed["bvh_node_bytes"] / max(timed["bvh_nodes"], 1)
+    fam = {"closest": dict(kernel="k_trace_closest_stream", ms=timed["trace_closest_ms"], launches=timed["n_closest_launches"], alone=alone["trace_closest_ms"],
+                           bytes=cnt["rays_closest"] * (RAY_BYTES + HIT_BYTES) + cnt["nodes_closest"] * node_bytes + cnt["tris_closest"] * TRI_BYTES),
+           "shadow": dict(kernel="k_trace_secondary_stream", ms=timed["trace_shadow_ms"], launches=timed["n_shadow_launches"], alone=alone["trace_shadow_ms"],
+                          bytes=cnt["rays_shadow"] * (RAY_BYTES + HIT_BYTES) + cnt["nodes_shadow"] * node_bytes + cnt["tris_shadow"] * TRI_BYTES)}
+    key = max(fam, key=lambda k: fam[k]["alone"])
+    f = fam[key]
+    launches = max(f["launches"], 1)
+    pmc = pmc_file(3, pool_spp, W, H)
+    pmc_k = pmc if (pmc and pmc.get("kernel", "").startswith(f["kernel"])) else None
+    roof = traversal_roofline(cnt, timed, key, steps, launches, f["ms"] / launches, f["alone"] / max(launches / steps, 1), f["bytes"] * steps / launches, f["kernel"], "whole frame", bw,
+                              pmc_k.get("traffic_bytes_per_launch") if pmc_k else None)
+    roof["kernel_info"] = r.kernel_info(0 if key == "closest" else 1)
+    if pmc_k:
+        roof["counters_from"] = pmc_k.get("file")
+        roof["counters_stale"] = not (pmc_k.get("source_fingerprint") == source_fingerprint())
+        if pmc_k.get("traffic_bytes_per_launch") and f["alone"] > 0:
+            roof["frac_hbm_measured"] = round(pmc_k["traffic_bytes_per_launch"] / (f["alone"] / max(launches / steps, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    paths = max(cnt["paths"], 1)
+    out = {"workload": w["name"], "msamples_per_s": round(W * H * spp * steps / dt / 1e6, 2), "ms_per_step": round(dt / steps * 1e3, 3), "spp_per_step": spp, "spp_per_pass": pool_spp,
+           "steps": steps, "warmup": warmup, "triangles": int(w["scene"]["indices"].shape[0]),
+           "note": "BASELINE.json configs[3] at a shorter frame than its 4096 spp (throughput does not depend on the frame length beyond three passes: 512 / 4096 spp measure within 1 %)",
+           "roofline": roof,
+           "kernel_ms_per_step_alone": {"trace_closest": round(alone["trace_closest_ms"], 3), "trace_secondary": round(alone["trace_shadow_ms"], 3), "shade": round(alone["shade_ms"], 3),
+                                        "generate": round(alone["generate_ms"], 3), "route_and_sort": round(alone["queue_ms"], 3), "accumulate": round(alone["accumulate_ms"], 3),
+                                        "tail": round(alone["tail_ms"], 3), "render_total": round(alone["render_ms"], 3)},
+           "rates": {"closest_hit_grays_per_s": round(cnt["rays_closest"] / (alone["trace_closest_ms"] * 1e-3) / 1e9, 3) if alone["trace_closest_ms"] > 0 else None,
+                     "secondary_grays_per_s": round(cnt["rays_shadow"] / (alone["trace_shadow_ms"] * 1e-3) / 1e9, 3) if alone["trace_shadow_ms"] > 0 else None,
+                     "shaded_ghits_per_s": round(cnt["shaded_hits"] / (alone["shade_ms"] * 1e-3) / 1e9, 3) if alone["shade_ms"] > 0 else None,
+                     "per_sample": {"closest_rays": round(cnt["rays_closest"] / paths, 4), "secondary_rays": round(cnt["rays_shadow"] / paths, 4), "shaded_hits": round(cnt["shaded_hits"] / paths, 4)}},
+           "bvh": {"build_ms": round(timed["bvh_build_ms"], 2), "nodes": timed["bvh_nodes"], "depth": timed["bvh_depth"]}}
+    out["parity"] = parity_block(r, w, cam, layers, bufs, (H // 2 - 2, H // 2 + 2), 1)
+    out["latency"] = latency_block(r, w, cam, layers, frames=(100, 40))
+    r.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +386,7 @@ def main():
     ap.add_argument("--pool-spp", type=int, default=0, help="samples per pixel per pass of the path pool; 0 = equal passes of at most ~128 spp of a 1080p frame and 3/4 of the free device memory, at least three per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras of the N = 1 line (parity crop, small-launch latency)")
+    ap.add_argument("--no-general-scene", action="store_true", help="skip the configs[3] leg the default (configs[2], N = 1) run appends as `general_scene`")
     ap.add_argument("--check-frame", action="store_true", help="N > 1: rank 0 re-renders the whole frame unsharded and compares it bit for bit with the gathered one")
     args = ap.parse_args()
 
@@ -287,48 +455,42 @@ def main():
     pp_bufs = [torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev) for _ in range(3)] if post else None
     if world > 1:  # wrong device binding, unequal shard shapes, a rendezvous the environment does not describe: fail here, not in step 1 (tools/rccl_gather_probe.py runs the same check alone)
         D.preflight(dist, dev, pad)
-    # path-pool slots = owned pixels x samples per pass, one pool per pass in flight.  Big passes amortise what a pass pays once (its longest rays, the ends of the
-    # streaming launches): 64 / 96 / 128 spp of a 1080p frame per pass measure 5874 / 6178 / 6312 Msamples/s on configs[2].  By default a step is split into equal
-    # passes of at most ~128 spp of a 1080p frame, of at most 3/4 of the device memory still free for all pools together (minus 2 GiB for what RCCL and the
-    # bandwidth probe allocate later), and into at least three passes, so that the library's three-passes-in-flight pipelining has something to overlap inside a step
-    slot_bytes, n_pools = r.path_pool_bytes()
-    if args.pool_spp > 0:
-        pool_spp = args.pool_spp
-    else:
-        try:
-            free_bytes = max(torch.cuda.mem_get_info(local_rank)[0] - (2 << 30), 1 << 30)
-        except Exception:  # (no memory query: the pass size of rounds 1-2, 64 spp of a 1080p frame, fits any MI355X)
-            free_bytes = int(1920 * 1080 * 64 * 1.02) * n_pools * slot_bytes / 0.75
-        cap = min(int(1920 * 1080 * 128 * 1.02), int(0.75 * free_bytes / (n_pools * slot_bytes)))  # 2 % slack: tile ownership is not perfectly even across ranks
-        passes = max(3, -(-n_owned * spp // cap))
-        pool_spp = max(-(-spp // passes), 1)
+    # path-pool slots = owned pixels x samples per pass, one pool per pass in flight (pass_size above)
+    pool_spp, slot_bytes, n_pools = pass_size(r, torch, local_rank, n_owned, spp, args.pool_spp)
     r.set_path_pool(n_owned * pool_spp)
     bw_read, bw_copy = r.measure_bandwidth(1 << 30, 6) if rank == 0 else (0.0, 0.0)  # measured HBM roofline of this GPU
     torch.cuda.synchronize()
+
+    # N > 1: the collective runs on torch's stream, the renderer on the library's.  The two are ordered by events, never through the host: torch's stream waits for the
+    # pack, the library's stream waits for the gather (on every rank: the next pack must not overwrite `packed` under the collective), and fh_unpack_shard is one
+    # asynchronous launch -- a step has no host synchronisation between fh_render and the presented frame
+    lib_stream = torch.cuda.ExternalStream(r.stream(), device=dev) if world > 1 else None
+    ev_packed = torch.cuda.Event() if world > 1 else None
+    ev_gathered = torch.cuda.Event() if world > 1 else None
 
     def step():
         r.render(cam, w["bg"], layers, spp, MAX_DEPTH)
         presented = bufs["beauty"]
         if world > 1:
             r.pack_owned(bufs["beauty"].data_ptr(), 4, packed.data_ptr())
-            r.wait_for_completion()          # library stream -> host; the collective runs on torch's stream
+            ev_packed.record(lib_stream)
+            torch.cuda.current_stream().wait_event(ev_packed)
             if backend == "nccl":
                 dist.gather(packed, gathered, dst=0)
-            else:                            # test path: stage through host memory
+            else:                            # test path: stage through host memory (the .cpu() copy waits for torch's stream, which waits for the pack)
                 host = [torch.empty(packed.shape, dtype=packed.dtype) for _ in range(world)] if rank == 0 else None
                 dist.gather(packed.cpu(), host, dst=0)
                 if rank == 0:
                     for k in range(world):
-                        gathered[k].copy_(host[k])
-            torch.cuda.synchronize()         # the gathered shards are complete before the library's stream reads them
+                        gathered[k].copy_(host[k], non_blocking=False)
+            ev_gathered.record(torch.cuda.current_stream())
+            lib_stream.wait_event(ev_gathered)
             if rank == 0:
                 for k in range(world):       # present the assembled frame (fh_unpack_shard: the inverse of every rank's pack)
                     r.unpack_shard(k, world, gathered[k].data_ptr(), 4, frame.data_ptr())
                 presented = frame
-        if post and rank == 0:               # the post chain runs on the assembled frame (bloom has a 16-pixel halo)
+        if post and rank == 0:               # the post chain runs on the assembled frame (bloom has a 16-pixel halo), on the library's stream
             r.post_process(presented.data_ptr(), pp_bufs[0].data_ptr(), pp_bufs[1].data_ptr(), WIDTH, HEIGHT, post, pp_bufs[2].data_ptr())
-        if world > 1 or post:
-            r.wait_for_completion()          # the next step's pack must not overwrite `packed` under the collective
 
     def fence():
         r.wait_for_completion()
@@ -348,8 +510,7 @@ def main():
     for _ in range(steps):
         ts = time.perf_counter()
         step()
-        if world == 1:
-            r.wait_for_completion()      # per-step times for the min / median below (a step ends with a host sync anyway when N > 1 or post)
+        r.wait_for_completion()          # a presented frame ends with ONE host synchronisation on the library's stream (which, N > 1, has waited for the gather): per-step times for the min / median below
         step_ms.append((time.perf_counter() - ts) * 1e3)
     fence()
     dt = time.perf_counter() - t0
@@ -438,32 +599,7 @@ def main():
         kernel_name = dom.replace("_stream", "_coop") if dom.startswith("k_trace") and small_tree else dom
         where = ("rank 0 shard" if world > 1 else "whole frame")
         if dom.startswith("k_trace"):
-            # ---- bound: VALU issue.  `achieved` = SIMD issue cycles per second that went into the kernel's essential work -- its wave-level node tests and triangle
-            # tests (counted by the instrumented replay), each at the cycles it costs a SIMD when nothing but issue limits it (constants above) -- `peak` = the issue cycles
-            # the chip has: 1024 SIMDs x the nominal 2.4 GHz.  Everything else the kernel spends cycles on (stack, queues, refill, waits, idle lanes are inside the wave-level
-            # counts) is below the line.  The HBM view SURVEY.md 8(d) asks for is kept under `algorithmic_*`: those bytes come from L2 / Infinity Cache, not from HBM.
-            key = f["key"]
-            wn, wt = cnt[f"wave_node_steps_{key}"], cnt[f"wave_tri_steps_{key}"]
-            rays, nodes, tris = cnt[f"rays_{key}"], cnt[f"nodes_{key}"], cnt[f"tris_{key}"]
-            issue_cycles_per_launch = (wn * NODE_TEST_SIMD_CYCLES + wt * TRI_TEST_SIMD_CYCLES) * steps / launches
-            achieved = issue_cycles_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            peak = N_SIMDS * NOMINAL_CLOCK_GHZ
-            ck = "closest" if key == "closest" else "shadow"
-            clock = timed[f"clk_cycles_{ck}"] / timed[f"clk_ticks_{ck}"] * 0.1 if timed.get(f"clk_ticks_{ck}") else None
-            roof = {"bound": "valu_issue", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "G SIMD issue cycles/s", "frac": round(achieved / peak, 5),
-                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": int(f["launches"]), "avg_launch_ms_alone": round(avg_alone_ms, 4),
-                    "frac_alone": round(issue_cycles_per_launch / (avg_alone_ms * 1e-3) / 1e9 / peak, 5) if avg_alone_ms > 0 else None,
-                    "clock_ghz_in_kernel": round(clock, 4) if clock else None,
-                    "frac_at_held_clock": round(achieved / (N_SIMDS * clock), 5) if clock else None,
-                    "issue_model": {"node_test_simd_cycles": NODE_TEST_SIMD_CYCLES, "tri_test_simd_cycles": TRI_TEST_SIMD_CYCLES, "wave_node_tests_per_launch": int(wn * steps / launches),
-                                    "wave_tri_tests_per_launch": int(wt * steps / launches), "source": "tools/micro/issue_peak.hip -> profiles/r03_issue_peak.txt (operands in registers, 8 waves per SIMD, >= 60 ms per point, clock from s_memtime / s_memrealtime)"},
-                    "lane_utilisation": {"node_tests": round(nodes / max(64 * wn, 1), 4), "triangle_tests": round(tris / max(64 * wt, 1), 4)},
-                    "per_ray": {"nodes": round(nodes / max(rays, 1), 2), "triangles": round(tris / max(rays, 1), 2), "bytes": round(f["bytes"] / max(rays, 1), 1)},
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_gbs": round(alg_gbs, 1), "frac_algorithmic_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 5),
-                    "measured_hbm_gbs": {"read": round(bw_read, 1), "copy": round(bw_copy, 1)},
-                    "note": where + "; achieved = (wave-level node tests x %g + wave-level triangle tests x %g SIMD cycles)" % (NODE_TEST_SIMD_CYCLES, TRI_TEST_SIMD_CYCLES) + " per launch / launch time measured inside the timed region, where passes on the other "
-                            "streams share the GPU with the launch; *_alone: the same launch with the GPU to itself (one untimed step with serial passes); algorithmic_* = SURVEY.md 8(d) bytes per ray x rays, "
-                            "priced against HBM only for reference -- node and triangle arrays (80 MB) are served by L2 / Infinity Cache, see traffic"}
+            roof = traversal_roofline(cnt, timed, f["key"], steps, launches, avg_ms, avg_alone_ms, bytes_per_launch, kernel_name, where, (bw_read, bw_copy), traffic)
         elif pmc_k and pmc_k.get("valu_insts_per_launch") and dom in STATIC_FMA_SHARE and avg_ms > 0:
             # ---- the shade / generate kernels are VALU-issue-bound as well (software transcendentals, hashing, divisions): executed VALU instructions per launch (counter
             # run of the same launch size) x the issue cycles an instruction of the kernel's mix costs, against the issue cycles the chip has
@@ -488,9 +624,12 @@ def main():
                     "measured_hbm_gbs": {"read": round(bw_read, 1), "copy": round(bw_copy, 1)}, "frac_of_measured_copy": round(alg_gbs / bw_copy, 5) if bw_copy > 0 else None,
                     "note": where + "; achieved = algorithmic bytes (DESIGN.md 4) / kernel time inside the timed region; the kernel waits on scattered 16-byte accesses to path and face records and on VALU "
                             "(BSDF, software transcendentals), so the algorithmic figure is a lower bound of what moves"}
+        if dom.startswith("k_trace"):
+            roof["kernel_info"] = r.kernel_info(0 if f.get("key") == "closest" else 1)  # registers / LDS / scratch / workgroups per CU of the variant that ran
         if pmc_k and avg_alone_ms > 0:  # the counters are collected with the kernels serialised, so they are priced against the kernel's time alone
             if traffic:
-                roof["hbm_traffic_frac"] = round(traffic / (avg_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                # what the fabric-side counters saw of this kernel against the HBM peak (2 x FETCH_SIZE + WRITE_SIZE of the counter run over this run's launch time alone)
+                roof["frac_hbm_measured"] = roof["hbm_traffic_frac"] = round(traffic / (avg_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             if pmc_k.get("valu_insts_per_launch"):
                 per_cycle = pmc_k["valu_insts_per_launch"] / N_SIMDS / (avg_alone_ms * 1e-3) / 1e9 / (roof.get("clock_ghz_in_kernel") or NOMINAL_CLOCK_GHZ)
                 roof["valu"] = {"insts_per_launch": pmc_k["valu_insts_per_launch"], "insts_per_cycle_per_simd": round(per_cycle, 4),
@@ -501,6 +640,13 @@ def main():
                 # "global_load_dwordx4, 64 lanes in 64 L1-resident lines", holds the rate the L1 serves such loads at)
                 roof["vl1d"] = dict(pmc_k["vl1d"], note="TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / (GRBM_GUI_ACTIVE / 8 XCDs) and TA_TA_BUSY_sum likewise, kernels serialised")
             roof["counters_from"] = pmc_k.get("file")
+            # the counters were collected by another process, possibly from another build: they describe THIS library only if the device sources and the kernel's
+            # registers / LDS / scratch are what they were then (tools/collect_profile4.py stores both in the file)
+            now = {"source_fingerprint": source_fingerprint(), "kernel_info": r.kernel_info(0 if f.get("key") == "closest" else 1) if dom.startswith("k_trace") else None}
+            then = {"source_fingerprint": pmc_k.get("source_fingerprint"), "kernel_info": pmc_k.get("kernel_info")}
+            same_kernel = then["kernel_info"] is None or now["kernel_info"] is None or all(then["kernel_info"].get(k) == now["kernel_info"].get(k) for k in ("vgprs", "static_lds_bytes", "scratch_bytes"))
+            roof["counters_stale"] = not (then["source_fingerprint"] == now["source_fingerprint"] and same_kernel)
+            roof["counters_built_from"] = {"git_head": pmc_k.get("git_head"), "source_fingerprint": then["source_fingerprint"], "this_run": now["source_fingerprint"]}
         sec = lambda k: fam[k]["alone"] * 1e-3  # seconds per step with the kernel alone on the GPU
         rates = {"closest_hit_grays_per_s": round(cnt["rays_closest"] / sec("k_trace_closest_stream") / 1e9, 3) if sec("k_trace_closest_stream") > 0 else None,
                  "secondary_grays_per_s": round(cnt["rays_shadow"] / sec("k_trace_secondary_stream") / 1e9, 3) if sec("k_trace_secondary_stream") > 0 else None,
@@ -526,6 +672,7 @@ def main():
                        "gather": "RCCL gather of packed float4 beauty tiles to rank 0 + fh_unpack_shard, inside the timed region" if world > 1 else "none",
                        "post": "bloom + chromatic aberration + tone map on the whole frame, inside the timed region" if post else "none"},
             "step_ms": {"min": round(sm[0], 3), "median": round(sm[len(sm) // 2], 3), "max": round(sm[-1], 3)},
+            "source_fingerprint": source_fingerprint(),  # of the device sources this library was built from (what profiles/*_traffic_config*.json are checked against)
             "roofline": roof, "rates": rates, "whole_frame": whole,
             "kernel_ms_per_step": {"trace_closest": round(timed["trace_closest_ms"] / steps, 3), "trace_secondary": round(timed["trace_shadow_ms"] / steps, 3), "shade": round(timed["shade_ms"] / steps, 3),
                                    "tail": round(timed["tail_ms"] / steps, 3), "generate": round(timed["generate_ms"] / steps, 3), "accumulate": round(timed["accumulate_ms"] / steps, 3),
@@ -548,11 +695,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
             out["cpu_baseline_1t"] = cpu_baseline_1t()
+        if extras and args.config == 2 and not args.no_general_scene:
+            r.close()  # (the headline's path pools go back to the device first)
+            r = None
+            out["general_scene"] = general_scene_block(local_rank, tmp.name, (bw_read, bw_copy))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    r.close()
+    if r is not None:
+        r.close()
     tmp.cleanup()
 
 

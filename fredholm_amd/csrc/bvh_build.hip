@@ -673,14 +673,14 @@ __global__ void k_ploc_init(int n, const float4* leaf_lo, const float4* leaf_hi,
   chi[i] = leaf_hi[i];
 }
 
-__global__ void k_ploc_nearest(int n, const float4* clo, const float4* chi, int* nn)
+__global__ void k_ploc_nearest(int n, const float4* clo, const float4* chi, int* nn, int radius)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 lo = clo[i], hi = chi[i];
   float best = __builtin_inff();
   int bj = -1;  // the first neighbour is taken unconditionally, so a cluster whose merged areas are all inf / NaN still gets a partner
-  const int j0 = i - kPlocRadius < 0 ? 0 : i - kPlocRadius, j1 = i + kPlocRadius > n - 1 ? n - 1 : i + kPlocRadius;
+  const int j0 = i - radius < 0 ? 0 : i - radius, j1 = i + radius > n - 1 ? n - 1 : i + radius;
   for (int j = j0; j <= j1; ++j) {
     if (j == i) continue;
     const float4 l2 = clo[j], h2 = chi[j];
@@ -945,7 +945,8 @@ int bvh_build_device(fh_ctx* ctx)
     if (const char* e = getenv("FH_SPLIT")) splitting = splitting && e[0] != '0';
     if (splitting) {
       const float extent = fmaxf(fmaxf(ctx->scene_hi[0] - ctx->scene_lo[0], ctx->scene_hi[1] - ctx->scene_lo[1]), ctx->scene_hi[2] - ctx->scene_lo[2]);
-      float thr = extent / 32.0f;
+      float thr = extent / 32.0f;  // FH_SPLIT_DIV: the divisor
+      if (const char* e = getenv("FH_SPLIT_DIV")) { const float v = (float)atof(e); if (v >= 2.0f && v <= 4096.0f) thr = extent / v; }
       const float eps = extent * 1e-6f;
       FH_HIP(split_count.alloc(n)); FH_HIP(split_offset.alloc(n));
       size_t scan_bytes = 0;
@@ -953,6 +954,8 @@ int bvh_build_device(fh_ctx* ctx)
       DevBuf<char> scan_tmp;
       FH_HIP(scan_tmp.alloc(scan_bytes));
       uint32_t total = n;
+      double split_budget = 1.5;  // references per face the split may produce at most (FH_SPLIT_BUDGET)
+      if (const char* e = getenv("FH_SPLIT_BUDGET")) { const double v = atof(e); if (v >= 1.0 && v <= 8.0) split_budget = v; }
       for (int attempt = 0; attempt < 6; ++attempt, thr *= 2.0f) {  // a scene made of large triangles only: coarser cells until the references fit
         hipLaunchKernelGGL(k_split_count, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, face_lo.p, face_hi.p, n, thr, eps, split_count.p);
         FH_HIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, split_count.p, split_offset.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
@@ -961,7 +964,7 @@ int bvh_build_device(fh_ctx* ctx)
         FH_HIP(hipMemcpyAsync(&tail[1], split_count.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
         FH_HIP(hipStreamSynchronize(st));
         total = tail[0] + tail[1];
-        if ((unsigned long long)total <= (unsigned long long)n + n / 2 + 4096ull) break;
+        if ((unsigned long long)total <= (unsigned long long)((double)n * split_budget) + 4096ull) break;
         total = n;
       }
       if (total > n) {
@@ -1025,12 +1028,14 @@ int bvh_build_device(fh_ctx* ctx)
       FH_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, valid.p, offset.p, 0u, (size_t)nr, rocprim::plus<uint32_t>(), st));
       DevBuf<char> scan_tmp;
       FH_HIP(scan_tmp.alloc(scan_bytes));
+      int ploc_radius = kPlocRadius;  // FH_PLOC_RADIUS: neighbours searched to either side
+      if (const char* e = getenv("FH_PLOC_RADIUS")) { const int v = atoi(e); if (v >= 1 && v <= 256) ploc_radius = v; }
       int* cid = cid_a.p; int* cid_o = cid_b.p;
       float4 *clo = clo_a.p, *chi = chi_a.p, *clo_o = clo_b.p, *chi_o = chi_b.p;
       uint32_t count = nr;
       for (int round = 0; count > 1 && round < 4096; ++round) {
         const uint32_t b = (count + 255) / 256;
-        hipLaunchKernelGGL(k_ploc_nearest, dim3(b), dim3(256), 0, st, (int)count, clo, chi, nn.p);
+        hipLaunchKernelGGL(k_ploc_nearest, dim3(b), dim3(256), 0, st, (int)count, clo, chi, nn.p, ploc_radius);
         hipLaunchKernelGGL(k_ploc_merge, dim3(b), dim3(256), 0, st, (int)count, nn.p, cid, clo, chi, valid.p, p_children.p, p_ranges.p, p_node_lo.p, p_node_hi.p, node_counter.p);
         FH_HIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, valid.p, offset.p, 0u, (size_t)count, rocprim::plus<uint32_t>(), st));
         hipLaunchKernelGGL(k_ploc_compact, dim3(b), dim3(256), 0, st, (int)count, valid.p, offset.p, cid, clo, chi, cid_o, clo_o, chi_o);

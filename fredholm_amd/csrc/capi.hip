@@ -442,6 +442,8 @@ int fh_ctx_destroy(fh_ctx* ctx)
                   ctx->d_bvh8_box, ctx->d_denoise_tmp[0], ctx->d_denoise_tmp[1], ctx->d_hosek, ctx->d_owned_xy, ctx->d_stack_spill};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (fh_ctx::ShardList& c : ctx->shard_lists)
+    if (c.d_owned) (void)hipFree(c.d_owned);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto e : ctx->ev_bounce) (void)hipEventDestroy(e);
@@ -651,6 +653,7 @@ int fh_set_resolution(fh_ctx* ctx, uint32_t w, uint32_t h)
 {
   CTX_CHECK(ctx);
   if (w == 0 || h == 0) return fail(ctx, FH_E_INVALID, "zero resolution");
+  if (w > 65535u || h > 65535u) return fail(ctx, FH_E_UNSUPPORTED, "frames wider or higher than 65535 pixels are not supported");  // (before anything is changed: the context keeps its resolution)
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_sample_count) { (void)hipFree(ctx->d_sample_count); ctx->d_sample_count = nullptr; }
   if (ctx->d_sample_issued) { (void)hipFree(ctx->d_sample_issued); ctx->d_sample_issued = nullptr; }
@@ -692,15 +695,27 @@ int fh_unpack_shard(fh_ctx* ctx, uint32_t rank, uint32_t world, const float* pac
 {
   CTX_CHECK(ctx);
   if (!layer || !packed || fpp == 0 || world == 0 || rank >= world) return FH_E_INVALID;
-  // ownership list of (rank, world) with this context's tile size and resolution
-  fh_ctx tmp;
-  tmp.device = ctx->device; tmp.width = ctx->width; tmp.height = ctx->height; tmp.tile_w = ctx->tile_w; tmp.tile_h = ctx->tile_h; tmp.shard_rank = rank; tmp.shard_world = world;
-  const int rc = rebuild_ownership(&tmp);
-  if (rc) { ctx->err = tmp.err; return rc; }
-  if (tmp.n_owned) hipLaunchKernelGGL(k_unpack, dim3((tmp.n_owned * fpp + 255) / 256), dim3(256), 0, ctx->stream, packed, tmp.d_owned, tmp.n_owned, fpp, layer);
-  (void)hipStreamSynchronize(ctx->stream);
-  if (tmp.d_owned) (void)hipFree(tmp.d_owned);
-  if (tmp.d_owned_xy) (void)hipFree(tmp.d_owned_xy);
+  if (ctx->width > 65535u || ctx->height > 65535u) return fail(ctx, FH_E_UNSUPPORTED, "frames wider or higher than 65535 pixels are not supported");
+  // ownership list of (rank, world) with this context's tile size and resolution: built once and kept (a presented frame unpacks every rank's shard), so that the call
+  // is one asynchronous launch on the context stream -- no allocation, no host copy, no synchronisation per frame
+  fh_ctx::ShardList* sl = nullptr;
+  for (fh_ctx::ShardList& c : ctx->shard_lists)
+    if (c.rank == rank && c.world == world && c.width == ctx->width && c.height == ctx->height && c.tile_w == ctx->tile_w && c.tile_h == ctx->tile_h) sl = &c;
+  if (!sl) {
+    fh_ctx tmp;
+    tmp.device = ctx->device; tmp.width = ctx->width; tmp.height = ctx->height; tmp.tile_w = ctx->tile_w; tmp.tile_h = ctx->tile_h; tmp.shard_rank = rank; tmp.shard_world = world;
+    const int rc = rebuild_ownership(&tmp);
+    if (rc) { ctx->err = tmp.err; return rc; }
+    if (tmp.d_owned_xy) (void)hipFree(tmp.d_owned_xy);
+    if (ctx->shard_lists.size() >= 64u) {  // (a caller cycling through many splits: drop the oldest)
+      (void)hipStreamSynchronize(ctx->stream);
+      if (ctx->shard_lists.front().d_owned) (void)hipFree(ctx->shard_lists.front().d_owned);
+      ctx->shard_lists.erase(ctx->shard_lists.begin());
+    }
+    ctx->shard_lists.push_back(fh_ctx::ShardList{rank, world, ctx->width, ctx->height, ctx->tile_w, ctx->tile_h, tmp.d_owned, tmp.n_owned});
+    sl = &ctx->shard_lists.back();
+  }
+  if (sl->n_owned) hipLaunchKernelGGL(k_unpack, dim3((sl->n_owned * fpp + 255) / 256), dim3(256), 0, ctx->stream, packed, sl->d_owned, sl->n_owned, fpp, layer);
   FH_HIP(hipGetLastError());
   return FH_OK;
 }
@@ -762,6 +777,12 @@ int fh_get_stats(fh_ctx* ctx, fh_stats* out)
   if (!out) return FH_E_INVALID;
   *out = ctx->stats;
   return FH_OK;
+}
+int fh_kernel_info(fh_ctx* ctx, int which, uint32_t out[6])
+{
+  CTX_CHECK(ctx);
+  if (!out || which < 0 || which > 1) return fail(ctx, FH_E_INVALID, "fh_kernel_info: which must be 0 (closest hit) or 1 (secondary rays)");
+  return kernel_info(ctx, which, out);
 }
 int fh_reset_stats(fh_ctx* ctx)
 {

@@ -76,7 +76,7 @@ struct fh_ctx {
   uint32_t bvh8_depth = 0;            // levels of the wide tree = most entries a traversal stack can hold
   uint32_t occupancy_key = 0xffffffffu, occupancy_blocks = 0, occupancy_blocks_secondary = 0;  // resident workgroups per CU of the streaming kernels, as the runtime reports them (render.hip)
   uint32_t lds_configured_bytes = 0;  // dynamic-LDS size the traversal kernels were last configured for (render.hip)
-  uint32_t stream_lds_entries = 0;    // stack levels the streaming kernels keep in LDS (the rest spills to d_stack_spill)
+  uint32_t stream_lds_entries = 0, stream_lds_entries_secondary = 0;    // stack levels the closest-hit / secondary streaming kernel keeps in LDS (the rest spills to d_stack_spill)
   uint2* d_stack_spill = nullptr;     // [6 launches in flight][entry beyond the LDS part][thread of the launch]
   size_t stack_spill_capacity = 0;    // in uint2
   uint32_t lds_static_max = 0;        // largest static LDS of a kernel that keeps its traversal stack in dynamic LDS (hipFuncGetAttributes; render.hip: configure_traversal_lds)
@@ -93,6 +93,8 @@ struct fh_ctx {
   uint32_t* d_owned = nullptr;  // image indices of owned pixels, in tile order
   uint32_t* d_owned_xy = nullptr;  // the same pixels as x | y << 16
   uint32_t n_owned = 0;
+  struct ShardList { uint32_t rank, world, width, height, tile_w, tile_h; uint32_t* d_owned; uint32_t n_owned; };
+  std::vector<ShardList> shard_lists;  // ownership lists of other ranks' shards, built on first use by fh_unpack_shard and kept (freed with the context)
 
   // environment (renderer.h:819-827)
   bool has_dir = false;
@@ -110,8 +112,8 @@ struct fh_ctx {
   std::vector<void*> pool_allocs[3];
   // 32 Mi path slots per pool: 16 samples per pixel per pass at 1080p.  Three pools (one per pass in flight) of 284-436 bytes per path are 27-42 GB when a call brings enough
   // samples to fill them; unless the caller chose the size (fh_set_path_pool), fh_render keeps all pools together within half of the device memory that is free when the first one is made
-  uint32_t pool_target = 1u << 25;
-  bool pool_target_by_caller = false, pool_target_capped = false;
+  uint32_t pool_target_default = 1u << 25, pool_target = 1u << 25;  // (pool_target: the default as capped by the free device memory whenever a pool is (re)allocated, or the caller's size)
+  bool pool_target_by_caller = false;
   uint32_t tail_depth = 0;          // bounces run as wavefront kernels before k_tail finishes the survivors; 0 = adaptive
   uint32_t auto_wave_depth = 2;     // adaptive choice, updated from the per-bounce survivor counts of earlier passes
   uint32_t* h_counters[3] = {nullptr, nullptr, nullptr};  // pinned snapshots of the per-bounce counters of a finished pass
@@ -190,6 +192,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
 int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity);   // render.hip
 uint64_t pool_bytes_per_path(const fh_ctx* ctx);            // capi.hip
 void pool_release(fh_ctx* ctx);
+int kernel_info(fh_ctx* ctx, int which, uint32_t out[6]);   // render.hip
 int post_process_submit(fh_ctx* ctx, const float* in, float* hi, float* tmp, int w, int h, const fh_post_params* pp, float* out);  // post.hip
 int denoise_submit(fh_ctx* ctx, int w, int h, const float* beauty, const float* normal, const float* albedo, float* out, int upscale);  // post.hip
 }  // namespace fh

@@ -595,6 +595,34 @@ FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float t
   return traverse_bvh8_coop_mode<ANY_HIT ? 1 : 0, COUNT, LDS, ALPHA>(bvh, valid, ANY_HIT, o, d, tmax, best, n_nodes, n_tris, ws, cl, flush, lds_column, lds_stride, sc);
 }
 
+#ifndef FH_HANDOVER_SCAN
+#define FH_HANDOVER_SCAN 1
+#endif
+#ifndef FH_HANDOVER_SCAN_ALPHA
+#define FH_HANDOVER_SCAN_ALPHA 1  // (0: the kernels with the any-hit test keep the ballot rounds -- the scan's registers can push them into scratch)
+#endif
+// inclusive prefix sum over the 64 lanes of a wave (all lanes active): four row_shr steps inside the rows of 16, then the row totals across the rows (row_bcast:15 / :31).
+// Written as v_add_u32 with a DPP operand -- six instructions; from __builtin_amdgcn_update_dpp the compiler makes a v_mov_b32_dpp AND an add per step.  A DPP operand
+// written by the VALU instruction before needs two wait states on gfx9 (the assembler does not add them inside an asm block): s_nop 1.
+FH_D uint32_t wave_inclusive_sum(uint32_t v)
+{
+  asm volatile("s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v));
+  return v;
+}
+
 // A wave's share of a work queue: chunks of `chunk` consecutive entries taken from a global cursor.  All members are wave-uniform.
 struct ChunkFeed {
   uint32_t* cursor;   // global, zeroed per pass (one word per bounce and kernel)
@@ -722,7 +750,30 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
       node8_visit(bvh, r, ni, best_t, group, tg);
     }
-    for (;;) {
+    if (FH_HANDOVER_SCAN && (!ALPHA || FH_HANDOVER_SCAN_ALPHA)) {
+    // one wave prefix sum of the lanes' candidate counts (six DPP adds) and a single scatter, instead of one ballot round per candidate of the fullest lane (~15 instructions
+    // per round, 2-3 rounds per visit): secondary 842 -> 825 ms per 512 spp of configs[3], 112.6 -> 110.3 ms per configs[2] frame (profiles/README.md r4-1).  The ring holds 128
+    // entries, so a visit that would overfill it -- more than 64 candidates on top of a queue below 64 -- falls back to the rounds
+    const uint32_t n_cand = (uint32_t)__popc(tg.y);
+    const uint32_t incl = wave_inclusive_sum(n_cand);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total != 0u && q_count + total <= kCoopQueue) {
+      uint32_t pos = q_head + q_count + incl - n_cand;
+      while (tg.y) {
+        const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
+        tg.y &= tg.y - 1u;
+        cl.queue[pos & (kCoopQueue - 1u)] = ((tg.x + b) << 6) | lane;
+        ++pos;
+      }
+      q_count += total;
+      while (q_count >= 64u) {
+        coop_test<MIXED, COUNT, ALPHA>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
+        q_head = (q_head + 64u) & (kCoopQueue - 1u);
+        q_count -= 64u;
+      }
+    }
+    }
+    for (;;) {  // (what the scatter above did not take: everything without it, the rare overfull visit with it)
       const bool has = tg.y != 0u;
       const unsigned long long m = __ballot(has);
       if (m == 0ull) break;

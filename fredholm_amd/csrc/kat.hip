@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../include/fredholm_hip_test.h"
 #include "context.h"
 #include "fh_bsdf.h"
 #include "fh_tonemap.h"

@@ -46,6 +46,17 @@ constexpr uint32_t kMatLds = 32;  // material records staged in LDS by the shade
 #ifndef FH_SECONDARY_BLOCKS_HEAVY
 #define FH_SECONDARY_BLOCKS_HEAVY 5  // resident workgroups per CU the secondary streaming kernel is compiled for when it carries the emitter / any-hit code
 #endif
+#ifndef FH_STREAM_BLOCKS
+#define FH_STREAM_BLOCKS 7  // resident workgroups per CU (= waves per SIMD) the streaming traversal kernels are compiled and launched for: 512 / that registers per lane (72 at seven), 160 KB / that of LDS
+                            // (seven stack levels next to the cooperative-test records; deeper levels spill).  Six / seven / eight measured on the same box (profiles/README.md r4-1): configs[3] 542 / 598 / 539
+                            // Msamples/s, configs[2] 6552 / 6702 / 6017 -- at eight the secondary kernel spills registers and keeps four stack levels in LDS
+#endif
+#ifndef FH_STREAM_BLOCKS_ALPHA
+#define FH_STREAM_BLOCKS_ALPHA FH_STREAM_BLOCKS  // the same for the secondary-ray kernel with the any-hit test compiled in
+#endif
+#ifndef FH_STREAM_BLOCKS_CLOSEST
+#define FH_STREAM_BLOCKS_CLOSEST FH_STREAM_BLOCKS  // the same for the closest-hit kernel, which needs fewer registers than the secondary-ray kernel
+#endif
 #ifndef FH_SHADE_BLOCKS
 #define FH_SHADE_BLOCKS 2  // resident workgroups per CU the specialised shade kernels are compiled for (register budget = 512 / that per lane): they take 159-182 registers
 #endif                     // since their products go to memory as they are made (PoolSink); the generic seven-lobe kernel keeps one wave per SIMD (350 registers).
@@ -301,7 +312,7 @@ struct ClosestStream {
 };
 
 template <bool COUNT, bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays,
+__global__ void __launch_bounds__(kBlock, COUNT ? 1 : FH_STREAM_BLOCKS_CLOSEST) k_trace_closest_stream(SceneDev sc, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays,
                                                                  StackSpill spill)
 {
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
@@ -1004,7 +1015,7 @@ struct SecondaryStream {
 };
 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
-__global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : 6)) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays, StackSpill spill)
+__global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : (ALPHA ? FH_STREAM_BLOCKS_ALPHA : FH_STREAM_BLOCKS))) k_trace_secondary_stream(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays, StackSpill spill)
 {
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // [entry][thread], sized by the launcher for the depth of the BVH
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
@@ -1360,6 +1371,27 @@ SceneDev scene_dev(const fh_ctx* ctx)
   return s;
 }
 
+// fh_kernel_info: registers / static LDS / scratch of the streaming kernel variant this scene is traced by, and how it is launched
+int kernel_info(fh_ctx* ctx, int which, uint32_t out[6])
+{
+  for (int k = 0; k < 6; ++k) out[k] = 0u;
+  const bool alpha = (ctx->has_alpha && !ctx->tun.ignore_alpha) || ctx->tun.force_alpha;
+  hipFuncAttributes at{};
+  hipError_t e = hipSuccess;
+  with_bool(alpha, [&](auto A) {
+    if (which == 0) e = hipFuncGetAttributes(&at, (const void*)k_trace_closest_stream<false, decltype(A)::value>);
+    else with_bool(ctx->n_lights > 0, [&](auto Li) { e = hipFuncGetAttributes(&at, (const void*)k_trace_secondary_stream<false, decltype(Li)::value, decltype(A)::value>); });
+  });
+  if (e != hipSuccess) return fail(ctx, FH_E_HIP, std::string("hipFuncGetAttributes: ") + hipGetErrorString(e));
+  out[0] = (uint32_t)at.numRegs;
+  out[1] = (uint32_t)at.sharedSizeBytes;
+  out[2] = (uint32_t)at.localSizeBytes;
+  out[3] = which == 0 ? ctx->occupancy_blocks : ctx->occupancy_blocks_secondary;
+  out[4] = which == 0 ? ctx->stream_lds_entries : ctx->stream_lds_entries_secondary;
+  out[5] = stack_entries_for(ctx->bvh8_depth);
+  return FH_OK;
+}
+
 void pool_release(fh_ctx* ctx)
 {
   (void)hipStreamSynchronize(ctx->stream);  // nothing may still be running out of the buffers (the counter snapshots trail the accumulate)
@@ -1388,7 +1420,7 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
     for (int k = 0; k < 2; ++k) FH_HIP(hipStreamSynchronize(ctx->aux_stream[k]));
     for (void* p : ctx->pool_allocs[slot]) (void)hipFree(p);
     ctx->pool_allocs[slot].clear();
-    if (ctx->pool[slot].capacity > capacity) capacity = ctx->pool[slot].capacity;
+    if (ctx->pool_target_by_caller && ctx->pool[slot].capacity > capacity) capacity = ctx->pool[slot].capacity;  // (a default-sized pool is re-made at the size the memory cap of this call allows)
     need.dir = need.dir || have.dir; need.lights = need.lights || have.lights; need.classes = need.classes > have.classes ? need.classes : have.classes;
     ctx->pool[slot] = PoolDev{};
     have = fh_ctx::PoolShape{};
@@ -1481,13 +1513,25 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (ctx->width == 0 || ctx->height == 0 || !ctx->d_sample_count) return fail(ctx, FH_E_INVALID, "fh_render: resolution not set");
   if (max_depth > 64) return fail(ctx, FH_E_INVALID, "fh_render: max_depth > 64 is not supported");
   if (ctx->n_owned == 0 || n_samples == 0) return FH_OK;
-  if (!ctx->pool_target_by_caller && !ctx->pool_target_capped) {  // the default pool size is a wish: all pools together stay within half of what the device has free now
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const unsigned long long cap = (unsigned long long)free_b / 2ull / ((unsigned long long)ctx->n_slots * pool_bytes_per_path(ctx));
-      if (cap < ctx->pool_target) ctx->pool_target = cap > ctx->n_owned ? (uint32_t)cap : ctx->n_owned;
+  // The default pool size (32 Mi paths per pool) is a wish: whenever a pool has to be allocated -- the first frame, after fh_scene_upload changed what a path record
+  // holds, after a release -- all pools together are kept within half of what the device has free at that moment, counting what the pools already hold as free.
+  if (!ctx->pool_target_by_caller) {
+    bool allocating = false;
+    unsigned long long held = 0;
+    for (int k = 0; k < (((ctx->flags & FH_FLAG_SERIAL_PASSES) != 0) ? 1 : ctx->n_slots); ++k) {
+      const fh_ctx::PoolShape& have = ctx->pool_shape[k];
+      if (ctx->pool[k].capacity == 0 || (ctx->has_dir && !have.dir) || (ctx->n_lights > 0 && !have.lights) || have.classes < (ctx->n_classes < 1u ? 1u : ctx->n_classes)) allocating = true;
+      held += (unsigned long long)ctx->pool[k].capacity * pool_bytes_per_path(ctx);
     }
-    ctx->pool_target_capped = true;
+    if (allocating) {
+      size_t free_b = 0, total_b = 0;
+      ctx->pool_target = ctx->pool_target_default;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const unsigned long long cap = ((unsigned long long)free_b + held) / 2ull / ((unsigned long long)ctx->n_slots * pool_bytes_per_path(ctx));
+        if (cap < ctx->pool_target) ctx->pool_target = cap > ctx->n_owned ? (uint32_t)cap : ctx->n_owned;
+      }
+      // (pools that exist already keep their size unless they have to be re-made: pool_ensure only grows)
+    }
   }
   uint32_t target = ctx->pool_target > ctx->n_owned ? ctx->pool_target : ctx->n_owned;
   uint32_t batch = target / ctx->n_owned;
@@ -1593,53 +1637,62 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (stream) {  // what the runtime says really fits (LDS granularity, registers of the variant in use): a grid above it would leave blocks queued behind the resident ones
     const uint32_t key = stack_bytes | (count ? 1u : 0u) | (sc.has_alpha ? 2u : 0u) | (sc.n_lights > 0 ? 4u : 0u) | (tun.stack_lds_entries << 20);
     if (ctx->occupancy_key != key) {
-      auto occupancy = [&](uint32_t entries, int& a, int& b) {
+      auto occupancy = [&](bool secondary, uint32_t entries) {
         const uint32_t bytes = lds_stack_bytes(entries);
+        int r = 0;
         with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
-          (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest_stream<decltype(C)::value, decltype(A)::value>, kBlock, bytes);
-          with_bool(sc.n_lights > 0, [&](auto Li) {
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>, kBlock, bytes);
+          if (!secondary) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, k_trace_closest_stream<decltype(C)::value, decltype(A)::value>, kBlock, bytes);
+          else with_bool(sc.n_lights > 0, [&](auto Li) {
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>, kBlock, bytes);
           });
         }); });
+        return r;
       };
-      // A deep tree's stack would cost a workgroup per CU (15 levels: five instead of six), and its deep entries are rarely reached: the streaming kernels keep the
-      // first levels in LDS and spill the rest to global memory (GroupStack<true>).  As many levels stay in LDS as still give the workgroups a tree of
-      // kStackLdsMin levels would have; FH_STACK_LDS=n fixes the number, FH_STACK_LDS=99 keeps everything in LDS.
-      constexpr uint32_t kStackLdsMin = 8;
-      uint32_t entries = stack_entries;
-      int a = 0, b = 0;
-      occupancy(entries, a, b);
-      if (tun.stack_lds_entries) entries = tun.stack_lds_entries < stack_entries ? tun.stack_lds_entries : stack_entries;
-      else if (stack_entries > kStackLdsMin) {
-        int a_best = 0, b_best = 0;
-        occupancy(kStackLdsMin, a_best, b_best);
-        while (entries > kStackLdsMin && (a < a_best || b < b_best)) { --entries; occupancy(entries, a, b); }
-      }
-      if (entries != stack_entries) occupancy(entries, a, b);
+      // The stack costs LDS, and LDS costs resident workgroups.  Each of the two kernels keeps as many stack levels in LDS as still give it the workgroups per CU it is compiled
+      // for (FH_STREAM_BLOCKS_CLOSEST / FH_STREAM_BLOCKS: at n workgroups per CU one has lds_per_cu / n bytes, and what the cooperative-test records leave is the stack's) and spills
+      // the deeper levels, which are rarely reached, to global memory (GroupStack<true>).  FH_STACK_LDS=n fixes the number for both, FH_STACK_LDS=99 keeps everything in LDS.
+      auto pick = [&](bool secondary, uint32_t blocks_wanted, uint32_t& entries_out, uint32_t& blocks_out) {
+        const uint32_t lds_share = tun.lds_per_cu / blocks_wanted;
+        const uint32_t fit = lds_share > kCoopLdsBytesPerBlock + 1280u ? (lds_share - kCoopLdsBytesPerBlock) / 1280u : 1u;
+        const uint32_t floor_entries = fit < 8u ? fit : 8u;
+        uint32_t entries = stack_entries;
+        int got = occupancy(secondary, entries);
+        if (tun.stack_lds_entries) entries = tun.stack_lds_entries < stack_entries ? tun.stack_lds_entries : stack_entries;
+        else if (stack_entries > floor_entries) {
+          const int best = occupancy(secondary, floor_entries);
+          while (entries > floor_entries && got < best) { --entries; got = occupancy(secondary, entries); }
+        }
+        if (entries != stack_entries) got = occupancy(secondary, entries);
+        entries_out = entries;
+        blocks_out = got > 0 ? (uint32_t)got : 0u;
+      };
+      pick(false, FH_STREAM_BLOCKS_CLOSEST, ctx->stream_lds_entries, ctx->occupancy_blocks);
+      pick(true, sc.n_lights > 0 ? FH_SECONDARY_BLOCKS_HEAVY : (sc.has_alpha ? FH_STREAM_BLOCKS_ALPHA : FH_STREAM_BLOCKS), ctx->stream_lds_entries_secondary, ctx->occupancy_blocks_secondary);
       ctx->occupancy_key = key;
-      ctx->stream_lds_entries = entries;
-      ctx->occupancy_blocks = a > 0 ? (uint32_t)a : 0u;
-      ctx->occupancy_blocks_secondary = b > 0 ? (uint32_t)b : 0u;
       if (getenv("FH_DEBUG_BVH"))
-        fprintf(stderr, "[trace] stack of %u entries, %u of them in LDS (%u B + %u B per workgroup): %d / %d resident workgroups per CU (closest / secondary)\n", stack_entries, entries, lds_stack_bytes(entries),
-                kCoopLdsBytesPerBlock, a, b);
+        fprintf(stderr, "[trace] stack of %u entries; in LDS: closest %u (%u B + %u B per workgroup, %u resident workgroups per CU), secondary %u (%u B + %u B, %u workgroups)\n", stack_entries,
+                ctx->stream_lds_entries, lds_stack_bytes(ctx->stream_lds_entries), kCoopLdsBytesPerBlock, ctx->occupancy_blocks, ctx->stream_lds_entries_secondary,
+                lds_stack_bytes(ctx->stream_lds_entries_secondary), kCoopLdsBytesPerBlock, ctx->occupancy_blocks_secondary);
     }
   }
-  const uint32_t stream_entries = stream ? ctx->stream_lds_entries : stack_entries;
-  const uint32_t stream_stack_bytes = lds_stack_bytes(stream_entries);
-  uint32_t wgs_per_cu = tun.lds_per_cu / (stream_stack_bytes + kCoopLdsBytesPerBlock);
-  wgs_per_cu = wgs_per_cu > 6u ? 6u : (wgs_per_cu < 1u ? 1u : wgs_per_cu);
-  uint32_t wgs_closest = wgs_per_cu, wgs_secondary = wgs_per_cu;
-  if (stream && ctx->occupancy_blocks && ctx->occupancy_blocks < wgs_closest) wgs_closest = ctx->occupancy_blocks;
-  if (stream && ctx->occupancy_blocks_secondary && ctx->occupancy_blocks_secondary < wgs_secondary) wgs_secondary = ctx->occupancy_blocks_secondary;
-  if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < wgs_closest) wgs_closest = tun.stream_wgs_per_cu;
-  if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < wgs_secondary) wgs_secondary = tun.stream_wgs_per_cu;
+  const uint32_t stream_entries = stream ? ctx->stream_lds_entries : stack_entries, stream_entries_secondary = stream ? ctx->stream_lds_entries_secondary : stack_entries;
+  const uint32_t stream_stack_bytes = lds_stack_bytes(stream_entries), stream_stack_bytes_secondary = lds_stack_bytes(stream_entries_secondary);
+  auto wgs_for = [&](uint32_t bytes, uint32_t compiled_for, uint32_t reported) {
+    uint32_t w = tun.lds_per_cu / (bytes + kCoopLdsBytesPerBlock);
+    w = w > compiled_for ? compiled_for : (w < 1u ? 1u : w);
+    if (stream && reported && reported < w) w = reported;
+    if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < w) w = tun.stream_wgs_per_cu;
+    return w;
+  };
+  const uint32_t wgs_closest = wgs_for(stream_stack_bytes, FH_STREAM_BLOCKS_CLOSEST, ctx->occupancy_blocks);
+  const uint32_t wgs_secondary = wgs_for(stream_stack_bytes_secondary, FH_STREAM_BLOCKS > FH_SECONDARY_BLOCKS_HEAVY ? FH_STREAM_BLOCKS : FH_SECONDARY_BLOCKS_HEAVY, ctx->occupancy_blocks_secondary);
   const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_closest;
   const uint32_t stream_grid_secondary = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_secondary;
   // spill area of the streaming launches: [launch in flight: pass slot x (closest, secondary)][entry beyond the LDS part][thread of the launch]
   const uint32_t spill_entries = stream_entries < stack_entries ? stack_entries - stream_entries : 0u;
+  const uint32_t spill_entries_secondary = stream_entries_secondary < stack_entries ? stack_entries - stream_entries_secondary : 0u;
   const size_t spill_threads = (size_t)(stream_grid > stream_grid_secondary ? stream_grid : stream_grid_secondary) * kBlock;
-  const size_t spill_region = (size_t)spill_entries * spill_threads;  // uint2 each
+  const size_t spill_region = (size_t)(spill_entries > spill_entries_secondary ? spill_entries : spill_entries_secondary) * spill_threads;  // uint2 each
   if (spill_region * 6u > ctx->stack_spill_capacity) {
     FH_HIP(hipDeviceSynchronize());  // (launches of earlier calls may still use the old area)
     if (ctx->d_stack_spill) FH_HIP(hipFree(ctx->d_stack_spill));
@@ -1792,9 +1845,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         Span sp(ctx, sb, 1);
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
-            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stream_stack_bytes, sb, sc,
+            hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stream_stack_bytes_secondary, sb, sc,
                                fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk, tun.stream_min_rays,
-                               StackSpill{spill_entries ? ctx->d_stack_spill + (size_t)(2 * slot + 1) * spill_region : nullptr, stream_entries});
+                               StackSpill{spill_entries_secondary ? ctx->d_stack_spill + (size_t)(2 * slot + 1) * spill_region : nullptr, stream_entries_secondary});
           }); }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {

@@ -352,6 +352,13 @@ class Renderer:
         self._ck(N.lib().fh_get_stats(self._ctx, C.byref(s)), "fh_get_stats")
         return s.as_dict()
 
+    def kernel_info(self, which):
+        """fh_kernel_info: what the runtime reports for the streaming traversal kernel of the current scene (0: closest hit, 1: secondary rays)"""
+        out = (C.c_uint32 * 6)()
+        self._ck(N.lib().fh_kernel_info(self._ctx, int(which), out), "fh_kernel_info")
+        return {"vgprs": int(out[0]), "static_lds_bytes": int(out[1]), "scratch_bytes": int(out[2]), "workgroups_per_cu": int(out[3]), "stack_levels_in_lds": int(out[4]),
+                "stack_levels": int(out[5])}
+
     def reset_stats(self):
         self._ck(N.lib().fh_reset_stats(self._ctx), "fh_reset_stats")
 

@@ -116,7 +116,7 @@ typedef struct fh_stats {
   double generate_ms, accumulate_ms, queue_ms; /* k_generate + k_bump_issued ; k_accumulate ; k_route + the cell sorts of the bounce queues */
   uint64_t n_generate_launches, n_accumulate_launches, n_shade_launches, n_tail_launches;
   uint64_t shaded_hits; /* surface hits shaded by the k_shade kernels (only when FH_FLAG_COUNT_TRAVERSAL) */
-  uint64_t bvh_depth;   /* levels of the wide BVH = entries of the LDS traversal stack */
+  uint64_t bvh_depth;   /* node levels of the wide BVH; a traversal stack needs levels - 1 entries, of which the streaming kernels may keep only the first in LDS (fh_kernel_info) */
   double post_ms;       /* summed HIP-event time of the fh_post_process chains (threshold + blur + tone map) */
   uint64_t n_post_launches;
   /* FH_FLAG_TIME_KERNELS, streaming traversal kernels: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) summed over their waves;
@@ -142,8 +142,9 @@ const char* fh_last_error(fh_ctx* ctx); /* ctx may be NULL for creation errors *
 int fh_set_flags(fh_ctx* ctx, uint32_t flags);
 int fh_get_flags(fh_ctx* ctx, uint32_t* flags); /* (a caller that wants to change one flag reads, edits and sets) */
 /* target number of camera paths in flight per pass (path-pool slots); a pass starts floor(target / owned pixels) >= 1
- * samples per pixel.  Results do not depend on it.  Default 32 Mi paths per pool, three pools (one per pass in flight), 284-436 bytes per path; the
- * default is lowered when the pools would take more than half of the free device memory, a size set here is taken as given. */
+ * samples per pixel.  Results do not depend on it.  Default 32 Mi paths per pool, three pools (one per pass in flight), 284-436 bytes per path.  Whenever a
+ * default-sized pool has to be allocated (first frame, after fh_scene_upload changed what a path record holds) the default is lowered so that all pools together
+ * stay within half of the device memory that is free at that moment (memory the pools already hold counts as free); a size set here is taken as given. */
 int fh_set_path_pool(fh_ctx* ctx, uint32_t target_paths);
 /* device memory of the path pools with the scene and lights as they are now: bytes per path slot and the number of pools (one per pass in flight);
  * a caller that sizes the pools for a frame (bench.py) multiplies: pools x target_paths x bytes_per_path */
@@ -218,41 +219,14 @@ void fh_image_free(uint8_t* rgba8);
 int fh_copy_on_device(fh_ctx* ctx, void* dst, const void* src, uint64_t bytes); /* asynchronous, ordered on the context stream (cwl::CUDABuffer device-to-device copies) */
 void* fh_stream(fh_ctx* ctx); /* hipStream_t of the context */
 
-/* -- batch queries used by the parity tests (device evaluation of the same code the kernels run) */
-/* rays7: o.xyz d.xyz tmax per ray (host memory).  tuv: 3 floats, prim: face id or 0xffffffff (host memory). */
+/* -- batch ray queries over the built BVH (closest hit, or any hit): rays7 = o.xyz d.xyz tmax per ray (host memory); tuv: 3 floats, prim: face id or
+ * 0xffffffff (host memory).  The same traversal code the render kernels run; what a caller without a renderer (picking, visibility probes) uses. */
 int fh_trace_rays(fh_ctx* ctx, uint32_t n, const float* rays7, int any_hit, float* tuv, uint32_t* prim);
-/* kind 0: xxhash32(a) ; 1: xxhash32(a,b,c) ; 2: xxhash32(a,b,c,d) ; 3: cmj_permute(a,b,c); in: uint32[4] per item */
-int fh_kat_hash(fh_ctx* ctx, int kind, uint32_t n, const uint32_t* in4, uint32_t* out);
-/* CMJ 2-D draws: in = (n_spp, image_idx, slot, seed) per item, out 2 floats */
-int fh_kat_cmj(fh_ctx* ctx, uint32_t n, const uint32_t* in4, float* out2);
-/* Owen-Sobol draws: in = (index32, dimension, seed_hash, unused) per item, out 1 float */
-int fh_kat_sobol(fh_ctx* ctx, uint32_t n, const uint32_t* in4, float* out);
-/* elementary functions of include/fh_elementary.h evaluated on the device; fn as in the checker */
-int fh_kat_elementary(fh_ctx* ctx, int fn, uint32_t n, const float* x, const float* y, float* out);
-/* warps: kind 0 disk, 1 cosine hemisphere, 2 triangle, 3 vndf(wo, alpha) */
-int fh_kat_warp(fh_ctx* ctx, int kind, uint32_t n, const float* u2, const float* wo3, const float* alpha2, float* out);
-/* BSDF: 18 floats per item {eval.rgb, pdf, sample.wi, sample.f, sample.pdf, lobe weights-as-pmf[7]} */
-int fh_kat_bsdf(fh_ctx* ctx, const fh_material* material, int entering, uint32_t lobes_mask, uint32_t n, const float* wo3, const float* wi3, const float* u1, const float* u2, float* out18);
-int fh_kat_sky(fh_ctx* ctx, uint32_t n, const float* dirs3, float* out3);          /* uses the context's Hosek state */
-int fh_kat_hosek_state(fh_ctx* ctx, float* out30);                                  /* cooked cfg[3][9] + rad[3] */
-int fh_kat_camera(fh_ctx* ctx, const fh_camera* cam, uint32_t width, uint32_t height, uint32_t seed, uint32_t n, const uint32_t* pixel_idx, const uint32_t* n_spp, float* out6);
-int fh_kat_offset_origin(fh_ctx* ctx, uint32_t n, const float* p3, const float* n3, float* out3);
-/* small math blocks that have a reference-built counterpart (oracle/_ref/libref_lut_math_post.so); floats in / out per item:
-   ALBEDO_REFLECTION (w.y, roughness, F0) -> 1  lut.cu:985-992     ALBEDO_SHEEN (w.y, roughness) -> 1  lut.cu:1075-1081
-   ONB n.xyz -> tangent.xyz bitangent.xyz  math.cu:7-17            TO_LOCAL / TO_WORLD (v, t, n, b) -> 3  math.cu:19-35
-   SPHERICAL w.xyz -> (theta, phi)  math.cu:111-118                LUMINANCE rgb -> 1  math.cu:90-93
-   UCHIMURA rgb -> 3  post-process.h:78-111                        LINEAR_TO_SRGB rgb -> 3  post-process.h:19-29
-   EXPOSURE (aperture, shutter, ISO) -> (EV100, exposure)  post-process.h:114-125
-   TONE_MAP_TAIL (r, g, b, ISO) -> 3  post-process.cu:139-152      POST_LUMINANCE rgb -> 1  post-process.h:13-16 */
-enum { FH_MATH_ALBEDO_REFLECTION = 0, FH_MATH_ALBEDO_SHEEN, FH_MATH_ONB, FH_MATH_TO_LOCAL, FH_MATH_TO_WORLD, FH_MATH_SPHERICAL, FH_MATH_LUMINANCE,
-       FH_MATH_UCHIMURA, FH_MATH_LINEAR_TO_SRGB, FH_MATH_EXPOSURE, FH_MATH_TONE_MAP_TAIL, FH_MATH_POST_LUMINANCE, FH_MATH_COUNT };
-int fh_kat_math(fh_ctx* ctx, int kind, uint32_t n, const float* in, float* out);
-/* tex2D<float4>() of the software texture unit (include/fh_texture_unit.h: cwl/texture.h:35-47 semantics) evaluated on the device for n (u, v)
-   pairs on an RGBA8 texture (rgba8, optionally sRGB) or a float4 texture (rgba32f); exactly one of the two texel pointers is non-NULL */
-/* the device's short correctly rounded square root (include/fh_elementary.h: fhe_sqrt) against the compiler's IEEE sqrtf over all 2^32 float bit patterns
- * (number of disagreeing inputs; 0 expected), plus its results on `n_sample` given inputs for a comparison with the host's sqrtf */
-int fh_kat_sqrt(fh_ctx* ctx, unsigned long long* mismatches_over_all_inputs, uint32_t n_sample, const float* sample_in, float* sample_out);
-int fh_kat_tex2d(fh_ctx* ctx, const uint8_t* rgba8, const float* rgba32f, uint32_t width, uint32_t height, int srgb, uint32_t n, const float* uv2, float* out4);
+/* what the runtime reports for the streaming traversal kernel the current scene would be traced by (which = 0: closest hit, 1: secondary rays):
+ * out[0] = vector registers per lane, out[1] = static LDS bytes per workgroup, out[2] = scratch bytes per lane, out[3] = workgroups per CU the kernel is
+ * launched with, out[4] = stack levels it keeps in LDS (the deeper ones spill to global memory), out[5] = stack levels the BVH needs.  Valid after a
+ * BVH build; out[3..4] after the first fh_render of the scene (0 before).  Lets a profile be tied to the code object that produced it (bench.py). */
+int fh_kernel_info(fh_ctx* ctx, int which, uint32_t out[6]);
 /* measured HBM bandwidth of this GPU (GB/s): a streaming float4 read and a float4 copy (read + written bytes) over `bytes`-sized buffers,
    `iters` launches each.  The "measured HBM roofline" SURVEY.md 8(d) asks for; use buffers well beyond the 256 MiB Infinity Cache. */
 int fh_measure_bandwidth(fh_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gbs, double* copy_gbs);

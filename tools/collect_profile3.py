@@ -53,6 +53,14 @@ d = {"kernel": k["name"], "config": cfg, "spp_per_pass": pmc_pass_spp,
      "frame_traffic_bytes_per_spp": frame / (renders * pspp),
      "frame_note": f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every kernel of the run / ({renders} renders x {pspp} spp): fabric-side bytes one sample per pixel of the whole frame costs",
      "note": "fabric-side bytes (L2 misses; Infinity-Cache hits are counted)."}
+# what the counters belong to (bench.py: roofline.counters_stale): the device sources and the kernel's registers / LDS / scratch of the run that was profiled, and the commit it was collected at
+import subprocess
+d["source_fingerprint"] = b.get("source_fingerprint")
+d["kernel_info"] = b["roofline"].get("kernel_info")
+try:
+    d["git_head"] = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True).strip() + (" + uncommitted changes" if subprocess.check_output(["git", "status", "--porcelain", "--", "fredholm_amd/csrc", "include"], text=True).strip() else "")
+except Exception:
+    d["git_head"] = None
 json.dump(d, open(f"profiles/{tag}_traffic_config{cfg}.json", "w"), indent=1)
 print(b["value"], b["step_ms"], {x: b["roofline"][x] for x in ("bound", "kernel", "achieved", "peak", "frac") if x in b["roofline"]}, b["kernel_ms_per_step_alone"], b["rates"], b.get("cpu_baseline", {}).get("value"))
 print({x: d[x] for x in ("kernel", "traffic_bytes_per_launch", "tcc_hit_rate", "valu_insts_per_launch", "valu_lane_utilisation", "wait_any_frac_of_wave_cycles", "waves_per_launch", "frame_traffic_bytes_per_spp")})

@@ -235,11 +235,14 @@ Result run_point(int n_cus, int wps, double target_ms, double instr_per_iter, fl
   return r;
 }
 
+static double g_last_cycles = 0.0, g_last_clock = 0.0;  // of the last point run (for --json)
+
 template <int KIND>
 void run_kind(int n_cus, double target_ms, float* sink, Stamp* stamps, const std::vector<int>& occ, double instr_per_iter, const char* unit)
 {
   for (int wps : occ) {
     const Result r = run_point<KIND>(n_cus, wps, target_ms, instr_per_iter, sink, stamps);
+    g_last_cycles = 1.0 / r.per_cycle_simd; g_last_clock = r.clock_ghz;
     printf("%-34s waves/SIMD %d: launch %6.1f ms  clock %.3f GHz  %.4f G%s/s/SIMD = %.4f %s/cycle/SIMD = %7.2f SIMD cycles per %s", kNames[KIND], wps, r.ms, r.clock_ghz, r.g_per_s_simd, unit,
            r.per_cycle_simd, unit, 1.0 / r.per_cycle_simd, unit);
     if (wps == 1) printf("  (one wave alone: %.2f cycles per %s)", r.cycles_one_wave, unit);
@@ -252,7 +255,14 @@ int main(int argc, char** argv)
 {
   double target_ms = 60.0;
   bool quick = false;
-  for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "--quick")) quick = true; else target_ms = atof(argv[i]); }
+  // --json <path> <sha>: only the node / triangle test points at 8 waves per SIMD, written as the JSON bench.py prices the traversal kernels with
+  // (profiles/r*_issue_peak.json; <sha> = first 16 hex digits of sha256(fredholm_amd/csrc/fh_trace.h), whose node8_test / tri_test this binary was compiled from)
+  const char* json_path = nullptr; const char* sha = "";
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--quick")) quick = true;
+    else if (!strcmp(argv[i], "--json") && i + 2 < argc) { json_path = argv[i + 1]; sha = argv[i + 2]; i += 2; }
+    else target_ms = atof(argv[i]);
+  }
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int n_cus = prop.multiProcessorCount;
@@ -278,6 +288,19 @@ int main(int argc, char** argv)
   }
   const std::vector<int> all = {1, 2, 4, 6, 8}, few = {1, 6, 8}, two = {6, 8};
   verify_node();
+  if (json_path) {
+    const std::vector<int> eight = {7, 8};
+    run_kind<NODE_TEST>(n_cus, target_ms, sink, stamps, eight, 4.0, "test");
+    const double node = g_last_cycles, node_clock = g_last_clock;
+    run_kind<TRI_TEST>(n_cus, target_ms, sink, stamps, eight, 4.0, "test");
+    FILE* f = fopen(json_path, "w");
+    if (!f) { fprintf(stderr, "cannot write %s\n", json_path); return 1; }
+    fprintf(f, "{\"node8_test_simd_cycles\": %.1f, \"tri_test_simd_cycles\": %.1f, \"waves_per_simd\": 8, \"clock_ghz\": %.3f, \"launch_ms\": %.0f, \"fh_trace_h_sha256_16\": \"%s\", "
+               "\"source\": \"tools/micro/issue_peak.bin --json: node8_test / tri_test of fh_trace.h, operands in registers, one launch per point, clock from s_memtime / s_memrealtime\"}\n",
+            node, g_last_cycles, node_clock, target_ms, sha);
+    fclose(f);
+    return 0;
+  }
   run_kind<FMA>(n_cus, target_ms, sink, stamps, all, 64.0, "instr");
   run_kind<NODE_TEST>(n_cus, target_ms, sink, stamps, all, 4.0, "test");
   run_kind<TRI_TEST>(n_cus, target_ms, sink, stamps, few, 4.0, "test");
