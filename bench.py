@@ -99,7 +99,7 @@ def traversal_roofline(cnt, timed, key, steps, launches, avg_ms, avg_alone_ms, b
     clock = timed[f"clk_cycles_{ck}"] / timed[f"clk_ticks_{ck}"] * 0.1 if timed.get(f"clk_ticks_{ck}") else None
     bw_read, bw_copy = bw
     return {"bound": "valu_issue", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "G SIMD issue cycles/s", "frac": round(achieved / peak, 5),
-            "frac_is": "model-derived: counted wave-level tests x microbenchmarked issue cycles per test (issue_model) / launch time measured in this run",
+            "model_note": "frac is model-derived: counted wave-level tests x microbenchmarked issue cycles per test (issue_model) / launch time measured in this run",
             "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": int(launches), "avg_launch_ms_alone": round(avg_alone_ms, 4),
             "frac_alone": round(issue_cycles_per_launch / (avg_alone_ms * 1e-3) / 1e9 / peak, 5) if avg_alone_ms > 0 else None,
             "clock_ghz_in_kernel": round(clock, 4) if clock else None,

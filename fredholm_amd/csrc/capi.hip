@@ -356,7 +356,14 @@ int fh_ctx_create(int device, fh_ctx** out)
   fh_ctx* ctx = new fh_ctx;
   ctx->device = device;
   auto bail = [&](const char* what) { g_create_error = what; delete ctx; return FH_E_HIP; };
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+  // FH_TRACE_CUS=k (experiment, with FH_SHADE_STREAM): the pass streams -- traversal, generate, accumulate -- may use only k of every 32 compute units, so that the shade
+  // side of the other passes always finds room; the streaming launches size their grids for 8 k CUs
+  uint32_t cu_words[8];
+  int trace_cus = 0;
+  if (const char* e = getenv("FH_TRACE_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 31) trace_cus = v; }
+  for (int k = 0; k < 8; ++k) cu_words[k] = trace_cus ? ((1u << trace_cus) - 1u) : 0xffffffffu;
+  auto make_stream = [&](hipStream_t* s) { return trace_cus ? hipExtStreamCreateWithCUMask(s, 8, cu_words) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); };
+  if (make_stream(&ctx->stream) != hipSuccess) return bail("hipStreamCreate failed");
   if (hipMalloc((void**)&ctx->d_sobol, kSobolMatricesBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_refl, kLutReflectionBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_sheen, kLutSheenBytes) != hipSuccess) return bail("hipMalloc failed");
@@ -381,7 +388,7 @@ int fh_ctx_create(int device, fh_ctx** out)
   (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
   (void)hipMemset(ctx->d_trace_counters, 0, 32 * sizeof(unsigned long long));
   for (int k = 0; k < 2; ++k)
-    if (hipStreamCreateWithFlags(&ctx->aux_stream[k], hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+    if (make_stream(&ctx->aux_stream[k]) != hipSuccess) return bail("hipStreamCreate failed");
   for (int k = 0; k < 3; ++k) {
     (void)hipHostMalloc((void**)&ctx->h_counters[k], sizeof(uint32_t) * fh::kCounterStride * 66);
     (void)hipEventCreate(&ctx->ev_counters[k]);
@@ -394,6 +401,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     fh_ctx::Tunables& t = ctx->tun;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) t.n_cus = (uint32_t)prop.multiProcessorCount;
+    if (trace_cus) t.n_cus = t.n_cus * (uint32_t)trace_cus / 32u;
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && v >= 64 * 1024) t.lds_per_cu = (uint32_t)v;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && v >= 64 * 1024) t.lds_per_block = (uint32_t)v;
@@ -411,6 +419,14 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_STREAM_MIN_RAYS", 0, 65535, t.stream_min_rays);
     env_off("FH_SORT_SMALL", t.sort_small);
     env_off("FH_OVERLAP", t.overlap_secondary);
+    env_off("FH_MERGE", t.merge_trace);
+    env_uint("FH_SHADE_STREAM", 0, 2, t.shade_stream);
+    if (t.shade_stream) {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      for (int k = 0; k < 3; ++k)
+        if (hipStreamCreateWithPriority(&ctx->shade_stream[k], hipStreamNonBlocking, t.shade_stream == 2 ? greatest : least) != hipSuccess) return bail("hipStreamCreateWithPriority failed");
+    }
     env_uint("FH_STACK_LDS", 1, 99, t.stack_lds_entries);
     env_uint("FH_SHADE_WGS", 2, 3, t.shade_wgs);
     env_uint("FH_STREAM_CHUNK", 16, 65535, t.stream_chunk);
@@ -447,6 +463,10 @@ int fh_ctx_destroy(fh_ctx* ctx)
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto e : ctx->ev_bounce) (void)hipEventDestroy(e);
+  for (int k = 0; k < 3; ++k) {
+    for (auto e : ctx->ev_shade[k]) (void)hipEventDestroy(e);
+    if (ctx->shade_stream[k]) (void)hipStreamDestroy(ctx->shade_stream[k]);
+  }
   for (int k = 0; k < 3; ++k) {
     if (ctx->h_counters[k]) (void)hipHostFree(ctx->h_counters[k]);
     (void)hipEventDestroy(ctx->ev_counters[k]);

@@ -14,6 +14,8 @@ struct fh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;   // main stream: everything the caller can observe is ordered on it
   hipStream_t aux_stream[2] = {nullptr, nullptr};  // passes j % n_slots != 0 of fh_render run here, overlapping the latency-bound ends of the passes before
+  hipStream_t shade_stream[3] = {nullptr, nullptr, nullptr};  // FH_SHADE_STREAM (experiment): route / shade / sort launches of pass slot k on a stream of their own (=2: of high priority)
+  std::vector<hipEvent_t> ev_shade[3];                          // (traced, shaded) per bounce of the pass in slot k
   std::string err;
   uint32_t flags = 0;
 
@@ -144,6 +146,8 @@ struct fh_ctx {
     uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill
     uint32_t stream_min_rays = 64;  // FH_STREAM_MIN_RAYS: queue entries per wave below which workgroups of a streaming launch stay out (render.hip: stream_block_idle); 0 = all take part
     bool overlap_secondary = true;  // FH_OVERLAP=0: single-pass calls keep every launch on one stream
+    bool merge_trace = true;        // FH_MERGE=0: single-pass calls trace secondary rays and the next bounce's closest-hit rays in two launches (two streams) instead of one
+    uint32_t shade_stream = 0;      // FH_SHADE_STREAM=1|2 (experiment, profiles/README.md r4): the shade-side launches of a pass on their own stream, 2: of high priority
     uint32_t shade_wgs = 0;         // FH_SHADE_WGS=2|3: workgroups per CU the shade kernels are compiled for (0: three for textured scenes that stream)
     uint32_t stack_lds_entries = 0; // FH_STACK_LDS=n: stack levels the streaming kernels keep in LDS (0: as many as cost no workgroup; 99: all)
     bool sort_small = false;        // FH_SORT_SMALL=1: cell-order the bounce queues of trees the fixed-batch kernels trace as well

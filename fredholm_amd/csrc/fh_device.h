@@ -194,6 +194,32 @@ FH_D void queue_push_keyed(uint32_t* counter, uint32_t* queue, uint16_t* keys, b
   }
 }
 
+// ---- block-aggregated queue append: ONE returning atomic per workgroup and call instead of one per wave.  A counter is one address, and the chip serves a bounded
+// number of returning atomics per address and second: with one per wave, kernels whose waves are short (k_generate: all camera rays of an interior enter the scene) or
+// that append to two queues per wave (k_shade) waited for their queue positions.  N appends at once (one ballot each), all 256 threads of the workgroup call together;
+// `scratch` is N x (4 wave counts + 1 base) words of LDS that the NEXT call may reuse only after a workgroup barrier (the callers' loops have one, or alternate two areas).
+template <int N>
+FH_D void block_queue_reserve(uint32_t* const (&counter)[N], const bool (&active)[N], uint32_t (&pos)[N], uint32_t* scratch)
+{
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned long long m[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    m[k] = __ballot(active[k]);
+    if (lane == 0u) scratch[5 * k + wave] = (uint32_t)__popcll(m[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x < (uint32_t)N) {
+    uint32_t* c = scratch + 5 * threadIdx.x;
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < 4u; ++w) { const uint32_t v = c[w]; c[w] = total; total += v; }
+    c[4] = total ? atomicAdd(counter[threadIdx.x], total) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) pos[k] = scratch[5 * k + 4] + scratch[5 * k + wave] + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull));
+}
+
 FH_D void queue_push(uint32_t* counter, uint32_t* queue, bool active, uint32_t value)
 {
   const unsigned long long mask = __ballot(active);

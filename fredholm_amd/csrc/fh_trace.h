@@ -310,8 +310,58 @@ FH_D Ray8 ray8_prepare(const RayPre& rp, f3 d)
   return r;
 }
 
+#ifndef FH_NODE_FETCH_PAIR
+#define FH_NODE_FETCH_PAIR 0
+#endif
+// Node fetch by PAIRS of lanes (streaming kernels, FH_NODE_FETCH_PAIR=1; measured, see tools/micro/node_visit.hip and profiles/README.md).  Every lane of a node load asks the
+// vector L1 for its own line, four times per node; here the two lanes of a pair read BOTH their nodes together, 32 contiguous bytes each, so a load instruction touches one line
+// per pair and a node visit 128 lines per wave instead of 256, and one butterfly of v_cndmask_b32 with a DPP operand (16 instructions) hands every lane the halves its partner
+// read for it.  Called by all 64 lanes together (a DPP operand of a lane that is switched off is not read): a lane without a visit lends its loads to its partner's node.
+FH_D void node8_fetch_pair(const Bvh8Dev& bvh, bool visit, uint32_t ni, uint4& n0, uint4& n1, uint4& n2, uint4& n3)
+{
+  const uint32_t lane = __lane_id();
+  const bool odd = (lane & 1u) != 0u;
+  const uint32_t mine = visit ? ni : 0xffffffffu;
+  const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xb1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]: the partner's node
+  uint32_t i_even = odd ? other : mine, i_odd = odd ? mine : other;
+  i_even = i_even == 0xffffffffu ? i_odd : i_even;
+  i_odd = i_odd == 0xffffffffu ? i_even : i_odd;
+  if (i_even == 0xffffffffu) i_even = i_odd = 0u;  // neither lane visits a node: any line will do
+  const uint32_t half = odd ? 32u : 0u;
+  const uint4* pe = (const uint4*)((const char*)bvh.nodes + ((i_even << 6) + half));
+  const uint4* po = (const uint4*)((const char*)bvh.nodes + ((i_odd << 6) + half));
+  const uint4 e0 = pe[0], e1 = pe[1], o0 = po[0], o1 = po[1];  // my half of the even lane's node, my half of the odd lane's node
+  // even lane: pieces 0, 1 are its own e0, e1 and pieces 2, 3 the partner's e0, e1; odd lane: pieces 2, 3 are its own o0, o1 and pieces 0, 1 the partner's o0, o1
+  const unsigned long long even_mask = 0x5555555555555555ull, odd_mask = 0xaaaaaaaaaaaaaaaaull;
+#define FH_PAIR_BUTTERFLY(A, B, OA, OB)                                                                                                                 \
+  asm volatile("s_mov_b64 vcc, %16\n\t"                                                                                                                 \
+               "v_cndmask_b32_dpp %0, %12, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                  \
+               "v_cndmask_b32_dpp %1, %13, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                  \
+               "v_cndmask_b32_dpp %2, %14, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                 \
+               "v_cndmask_b32_dpp %3, %15, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                 \
+               "s_mov_b64 vcc, %17\n\t"                                                                                                                 \
+               "v_cndmask_b32_dpp %4, %8, %12, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                  \
+               "v_cndmask_b32_dpp %5, %9, %13, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                  \
+               "v_cndmask_b32_dpp %6, %10, %14, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                 \
+               "v_cndmask_b32_dpp %7, %11, %15, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"                                                       \
+               : "=&v"(OA.x), "=&v"(OA.y), "=&v"(OA.z), "=&v"(OA.w), "=&v"(OB.x), "=&v"(OB.y), "=&v"(OB.z), "=&v"(OB.w)                                 \
+               : "v"(A.x), "v"(A.y), "v"(A.z), "v"(A.w), "v"(B.x), "v"(B.y), "v"(B.z), "v"(B.w), "s"(even_mask), "s"(odd_mask)                          \
+               : "vcc")
+  // OA = even ? A : partner's B,  OB = odd ? B : partner's A   (v_cndmask_b32_dpp D, S0, S1, vcc: D = vcc ? S1 : dpp(S0))
+  FH_PAIR_BUTTERFLY(e0, o0, n0, n2);
+  FH_PAIR_BUTTERFLY(e1, o1, n1, n3);
+#undef FH_PAIR_BUTTERFLY
+}
+
 // one visited node: the group of its inner children the ray enters (first-child node index, octant-ordered hit bits << 24 | imask)
 // and the group of its candidate triangles (first triangle slot, one bit per slot)
+FH_D void node8_eval(const Ray8& r, uint32_t ni, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, float tmax, uint2& group, uint2& tg)
+{
+  const uint32_t hm = node8_test(r, n0, n1, n2, n3, tmax);
+  const uint32_t imask = n0.w & 0xffu;
+  group = make_uint2(n0.w >> 8, (octant_permute(hm & imask, r.oct) << 24) | imask);
+  tg = make_uint2(8u * ni, hm & ~imask);
+}
 FH_D void node8_visit(const Bvh8Dev& bvh, const Ray8& r, uint32_t ni, float tmax, uint2& group, uint2& tg)
 {
   // (a 32-bit byte offset -- the builder refuses trees of 2^23 nodes -- lets the four loads share the base in scalar registers)
@@ -740,6 +790,23 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       best_t = __uint_as_float((uint32_t)(k >> 32));
       if (MIXED && any && (uint32_t)k != 0xffffffffu) busy = false;
     }
+#if FH_NODE_FETCH_PAIR
+    uint32_t ni = 0u;
+    if (busy) {
+      const uint32_t hits_imask = group.y;
+      const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
+      group.y &= ~(1u << bit);
+      if (group.y & 0xff000000u) stack.push(group);
+      const uint32_t slot = (bit - 24u) ^ r.oct;
+      ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+      if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
+    }
+    {
+      uint4 n0, n1, n2, n3;
+      node8_fetch_pair(bvh, busy, ni, n0, n1, n2, n3);  // (all 64 lanes)
+      if (busy) node8_eval(r, ni, n0, n1, n2, n3, best_t, group, tg);
+    }
+#else
     if (busy) {
       const uint32_t hits_imask = group.y;
       const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
@@ -750,6 +817,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
       node8_visit(bvh, r, ni, best_t, group, tg);
     }
+#endif
     if (FH_HANDOVER_SCAN && (!ALPHA || FH_HANDOVER_SCAN_ALPHA)) {
     // one wave prefix sum of the lanes' candidate counts (six DPP adds) and a single scatter, instead of one ballot round per candidate of the fullest lane (~15 instructions
     // per round, 2-3 rounds per visit): secondary 842 -> 825 ms per 512 spp of configs[3], 112.6 -> 110.3 ms per configs[2] frame (profiles/README.md r4-1).  The ring holds 128

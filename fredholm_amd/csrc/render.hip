@@ -57,6 +57,9 @@ constexpr uint32_t kMatLds = 32;  // material records staged in LDS by the shade
 #ifndef FH_STREAM_BLOCKS_CLOSEST
 #define FH_STREAM_BLOCKS_CLOSEST FH_STREAM_BLOCKS  // the same for the closest-hit kernel, which needs fewer registers than the secondary-ray kernel
 #endif
+#ifndef FH_BLOCK_PUSH
+#define FH_BLOCK_PUSH 1  // (0, A/B only: k_generate and k_shade append to their queues with one returning atomic per wave instead of one per workgroup)
+#endif
 #ifndef FH_SHADE_BLOCKS
 #define FH_SHADE_BLOCKS 2  // resident workgroups per CU the specialised shade kernels are compiled for (register budget = 512 / that per lane): they take 159-182 registers
 #endif                     // since their products go to memory as they are made (PoolSink); the generic seven-lobe kernel keeps one wave per SIMD (350 registers).
@@ -107,6 +110,7 @@ FH_D f3 env_radiance(const FrameDev& fr, f3 d)
 // grid: x over the owned pixels (grid-stride), y = sample of the pass -- slot p = sample * n_owned + pixel without a division per path, and the pixel's
 // coordinates come packed from the ownership list instead of from image_idx / width and % width (four integer divisions by run-time values were ~60 of the
 // kernel's ~1070 non-FMA instructions per path)
+constexpr int kGenChunks = 4;
 __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, const uint32_t* issued, const uint32_t* owned, const uint32_t* owned_xy, uint32_t n_owned)
 {
   __shared__ SobolRows<1> rows;
@@ -114,10 +118,18 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
   stage_sky(fr, s_sky);
   const uint32_t dims[1] = {1u};
   load_sobol_rows<1>(rows, fr.sobol_bytes, dims);
-  const uint32_t stride = gridDim.x * blockDim.x;
+  // A workgroup takes kGenChunks x 256 consecutive pixels per round and appends the paths that enter the scene with ONE returning atomic (block_queue_reserve): with one per
+  // wave, an interior -- every camera ray enters -- spent most of the kernel waiting for queue positions (configs[3]: 188 -> see profiles/README.md r4)
+  const uint32_t stride = gridDim.x * blockDim.x * kGenChunks;
   const uint32_t k = blockIdx.y;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < n_owned; base += stride) {
-    const uint32_t i = base + threadIdx.x;
+  __shared__ uint32_t s_reserve[2][5 * kGenChunks];
+  uint32_t iter = 0;
+  for (uint32_t base = blockIdx.x * blockDim.x * kGenChunks; base < n_owned; base += stride) {
+   uint32_t packed = 0u;  // per chunk one byte: bit 7 = this lane's path enters the scene, bits 0-5 = its rank among the entering lanes of its wave
+   uint32_t* const scratch = s_reserve[iter & 1u];
+#pragma unroll 1
+   for (int c = 0; c < kGenChunks; ++c) {  // (a loop, not four copies: the body is 18 KB of code)
+    const uint32_t i = base + (uint32_t)c * blockDim.x + threadIdx.x;
     const bool valid = i < n_owned;
     const uint32_t p = k * n_owned + i;  // slot p = sample-major: lanes of a wave hold neighbouring pixels of one sample index
     bool enter = false;
@@ -170,7 +182,29 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
         pool.flags[p] = 2u;  // finished here and in no queue: only k_accumulate reads the slot again (radiance and flags)
       }
     }
-    queue_push(&pool.counters[CNT_RAD], pool.q_rad[0], enter, p);
+#if !FH_BLOCK_PUSH
+    queue_push(&pool.counters[CNT_RAD], pool.q_rad[0], enter, p);  // (A/B: one atomic per wave, as before round 4)
+#else
+    const unsigned long long m = __ballot(enter);
+    if ((threadIdx.x & 63u) == 0u) scratch[4 * c + (threadIdx.x >> 6)] = (uint32_t)__popcll(m);
+    packed |= ((enter ? 0x80u : 0u) | (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull))) << (8 * c);
+#endif
+   }
+#if !FH_BLOCK_PUSH
+   continue;
+#endif
+   __syncthreads();
+   if (threadIdx.x == 0u) {
+     uint32_t total = 0;
+     for (uint32_t c = 0; c < 4u * kGenChunks; ++c) { const uint32_t v = scratch[c]; scratch[c] = total; total += v; }
+     scratch[4 * kGenChunks] = total ? atomicAdd(&pool.counters[CNT_RAD], total) : 0u;
+   }
+   __syncthreads();
+   ++iter;  // (the next round writes the other scratch area: a lane may still be reading this one)
+#pragma unroll
+   for (int c = 0; c < kGenChunks; ++c)
+     if ((packed >> (8 * c)) & 0x80u)
+       pool.q_rad[0][scratch[4 * kGenChunks] + scratch[4 * c + (threadIdx.x >> 6)] + ((packed >> (8 * c)) & 63u)] = k * n_owned + base + (uint32_t)c * blockDim.x + threadIdx.x;
   }
 }
 
@@ -789,6 +823,8 @@ __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : BLOCKS)) k_shade
   const uint32_t* q = pool.q_cls + (size_t)cls * pool.capacity;
   const uint32_t qnext = (depth + 1u) & 1u;
   const uint32_t stride = gridDim.x * blockDim.x;
+  __shared__ uint32_t s_reserve[2][10];  // (two areas, used alternately: block_queue_reserve)
+  uint32_t iter = 0;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
     const uint32_t i = base + threadIdx.x;
     const bool valid = i < count;
@@ -805,8 +841,19 @@ __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : BLOCKS)) k_shade
       cont = o.cont;
       if (shaded || cont) cell = cell_of(fr, o.origin);
     }
+#if !FH_BLOCK_PUSH
     queue_push_keyed(&cnt[CNT_SEC], pool.q_sec, pool.key_sec, shaded, p, cell);
     queue_push_keyed(&cnt_next[CNT_RAD], pool.q_rad[qnext], pool.key_rad, cont, p, cell);
+    continue;
+#endif
+    // queue positions of both appends: one returning atomic per workgroup and queue (fh_device.h: block_queue_reserve)
+    uint32_t* const counters2[2] = {&cnt[CNT_SEC], &cnt_next[CNT_RAD]};
+    const bool act[2] = {shaded, cont};
+    uint32_t pos[2];
+    block_queue_reserve<2>(counters2, act, pos, s_reserve[iter & 1u]);
+    ++iter;
+    if (shaded) { pool.q_sec[pos[0]] = p; pool.key_sec[pos[0]] = (uint16_t)cell; }
+    if (cont) { pool.q_rad[qnext][pos[1]] = p; pool.key_rad[pos[1]] = (uint16_t)cell; }
   }
 }
 
@@ -991,6 +1038,10 @@ struct SecondaryStream {
   FH_D bool take(uint32_t i, f3& o, f3& d, float& tmax, bool& any)
   {
     if (i >= feed.end) return false;
+    return take_item(i, o, d, tmax, any);
+  }
+  FH_D bool take_item(uint32_t i, f3& o, f3& d, float& tmax, bool& any)
+  {
     p = pool.q_sec[i];
     L = mk3(pool.rad[p]);
     active = true;
@@ -1039,6 +1090,61 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
     if (ws.node) atomicAdd(tc.wave_nodes, (unsigned long long)ws.node);
     if (ws.tri) atomicAdd(tc.wave_tris, (unsigned long long)ws.tri);
   }
+}
+
+// One launch for the secondary rays of bounce b AND the closest-hit rays of bounce b + 1 (calls of ONE pass: the reference's 1- and 16-sample calls).  The two do not
+// depend on each other -- the secondary rays read the secondary-ray records and add to the radiance, the closest-hit rays read the path's ray and write its hit -- and as two
+// launches each of them ends in its own few long rays with most of the chip idle.  Here the wave's work queue is the secondary queue followed by the next bounce's radiance
+// queue (one cursor over both): a lane holds either a path with its secondary rays or one closest-hit ray, every ray stops at its first hit or not as its kind says
+// (traverse_stream's per-lane flag), and the launch has ONE end.  Same device functions, same per-path order of operations: the bits do not change.
+template <bool LIGHTS>
+struct MergedStream {
+  SecondaryStream<false, LIGHTS> sec;
+  const PoolDev& next;        // the view whose radiance queue of bounce b + 1 is traced
+  const uint32_t* q_closest;
+  uint32_t n_sec;
+  ChunkFeed feed;
+  uint32_t pc = 0;
+  bool closest = false;       // the lane's current item is a closest-hit ray
+  FH_D MergedStream(const SceneDev& s, const FrameDev& f, const PoolDev& ps, const PoolDev& pn, const uint32_t* qc, uint32_t ns, const ChunkFeed& cf)
+      : sec(s, f, ps, cf, nullptr), next(pn), q_closest(qc), n_sec(ns), feed(cf) {}
+  FH_D bool advance(f3& o, f3& d, float& tmax, bool& any) { return closest ? false : sec.advance(o, d, tmax, any); }
+  FH_D bool take(uint32_t i, f3& o, f3& d, float& tmax, bool& any)
+  {
+    if (i >= feed.end) return false;
+    if (i < n_sec) { closest = false; return sec.take_item(i, o, d, tmax, any); }
+    closest = true;
+    pc = q_closest[i - n_sec];
+    const float4 o4 = next.ray_o[pc], d4 = next.ray_d[pc];
+    o = mk3(o4); d = mk3(d4); tmax = o4.w; any = false;
+    return true;
+  }
+  FH_D void commit(bool hit, const HitRec& h, uint32_t nodes)
+  {
+    if (closest) next.hit[pc] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+    else sec.commit(hit, h, nodes);
+  }
+  FH_D bool drained() const { return feed.drained(); }
+  FH_D bool followup() const { return !closest && sec.followup(); }
+};
+
+template <bool LIGHTS, bool ALPHA>
+__global__ void __launch_bounds__(kBlock, LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : (ALPHA ? FH_STREAM_BLOCKS_ALPHA : FH_STREAM_BLOCKS)) k_trace_merged_stream(SceneDev sc, FrameDev fr, PoolDev ps, PoolDev pn, uint32_t depth, TraceCounters tc, uint32_t flush, uint32_t refill, uint32_t chunk, uint32_t min_rays, StackSpill spill)
+{
+  extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(kBlock / 64) * kCoopLdsBytesPerWave];
+  const uint32_t n_sec = ps.counters[depth * kCounterStride + CNT_SEC], n_closest = ps.counters[(depth + 1u) * kCounterStride + CNT_RAD];
+  const uint32_t count = n_sec + n_closest;
+  if (stream_block_idle(count, min_rays)) return;
+  __shared__ HosekSky s_sky;
+  if (LIGHTS) { stage_sky(fr, s_sky); __syncthreads(); }
+  const ClockStamp stamp;
+  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  uint32_t nn = 0, nt = 0;
+  MergedStream<LIGHTS> pol(sc, fr, ps, pn, pn.q_rad[(depth + 1u) & 1u], n_sec, ChunkFeed(ps.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)));
+  traverse_stream<true, false, true, ALPHA>(sc.bvh8, pol, nn, nt, nullptr, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill);
+  pol.sec.finish();
+  stamp.commit(tc.clk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1396,6 +1502,7 @@ void pool_release(fh_ctx* ctx)
 {
   (void)hipStreamSynchronize(ctx->stream);  // nothing may still be running out of the buffers (the counter snapshots trail the accumulate)
   for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(ctx->aux_stream[k]);
+  for (int k = 0; k < 3; ++k) if (ctx->shade_stream[k]) (void)hipStreamSynchronize(ctx->shade_stream[k]);
   for (int k = 0; k < 3; ++k) {
     for (void* p : ctx->pool_allocs[k]) (void)hipFree(p);
     ctx->pool_allocs[k].clear();
@@ -1492,6 +1599,7 @@ int configure_traversal_lds(fh_ctx* ctx, uint32_t stack_bytes)
         for (int l = 0; l < 2; ++l)
           with_bool(l != 0, [&](auto Li) {
             set((const void*)k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
+            set((const void*)k_trace_merged_stream<decltype(Li)::value, decltype(A)::value>);
             set((const void*)k_trace_secondary_coop<decltype(C)::value, decltype(Li)::value, decltype(A)::value>);
             set((const void*)k_trace_secondary_static<decltype(C)::value, true, decltype(Li)::value, decltype(A)::value>);
             set((const void*)k_trace_secondary_static<decltype(C)::value, false, decltype(Li)::value, decltype(A)::value>);
@@ -1733,7 +1841,10 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     // each end in a few long rays.  The secondary rays of bounce b and the closest-hit launch of bounce b + 1 do not depend on each other -- the secondary launch reads the
     // secondary-ray records and adds to the radiance, the closest-hit launch and the routing read rays and write hits -- so the secondary launch goes to a second stream;
     // the shade kernels of bounce b + 1, which overwrite the records it reads, wait for it.  (Calls of several passes overlap whole passes instead.)
-    const bool overlap = !serial && tun.overlap_secondary && batch >= n_samples && n_samples == nb;
+    const bool single_pass = !serial && batch >= n_samples && n_samples == nb;
+    // ... or, where the streaming kernels trace the scene, both in ONE launch (k_trace_merged_stream): one end instead of two, no second stream (FH_MERGE=0: the two-stream form)
+    const bool merge = single_pass && stream && !count && tun.merge_trace;
+    const bool overlap = single_pass && tun.overlap_secondary && !merge;
     hipStream_t sb = st;
     if (overlap) {
       sb = (st == ctx->aux_stream[0]) ? ctx->aux_stream[1] : ctx->aux_stream[0];
@@ -1743,13 +1854,23 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         ctx->ev_bounce.push_back(e);
       }
     }
+    // FH_SHADE_STREAM (experiment): the shade side of every bounce -- routing, shade kernels, queue sorts -- on a stream of its own (optionally of high priority), ordered
+    // against the pass's traversal launches by events
+    const bool shade_sep = !serial && !overlap && tun.shade_stream != 0 && ctx->shade_stream[slot] != nullptr;
+    hipStream_t sh = shade_sep ? ctx->shade_stream[slot] : st;
+    if (shade_sep)
+      while (ctx->ev_shade[slot].size() < 2u * (max_depth + 1u)) {
+        hipEvent_t e = nullptr;
+        FH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ev_shade[slot].push_back(e);
+      }
     { const int rc = pool_ensure(ctx, slot, ctx->n_owned * batch); if (rc) return rc; }
     const PoolDev& pool = ctx->pool[slot];
     FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
     if (prev != slot && ctx->gen_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_gen[prev], 0));
     {
       Span sp(ctx, st, 4);
-      hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx->n_owned), nb), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, ctx->d_owned, ctx->d_owned_xy, ctx->n_owned);
+      hipLaunchKernelGGL(k_generate, dim3(grid_for((ctx->n_owned + kGenChunks - 1) / kGenChunks), nb), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, ctx->d_owned, ctx->d_owned_xy, ctx->n_owned);
       hipLaunchKernelGGL(k_bump_issued, dim3((ctx->n_owned + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, nb);
       ctx->stats.n_generate_launches++;
     }
@@ -1794,7 +1915,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     uint32_t* q_spare = pool.q_tmp;
     const uint32_t sort_blocks = n_paths / 16384u < 1u ? 1u : (n_paths / 16384u > 512u ? 512u : n_paths / 16384u);
     for (uint32_t depth = 0; depth < wave_depth; ++depth) {
-      {
+      if (!(merge && depth > 0)) {  // (merged launches: the closest-hit rays of this bounce were traced next to the secondary rays of the bounce before)
         Span sp(ctx, st, 0);
         if (stream) {
           with_bool(count, [&](auto C) { with_bool(sc.has_alpha != 0, [&](auto A) {
@@ -1813,26 +1934,27 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         ctx->stats.n_closest_launches++;
       }
       if (quirk && depth == 0) hipLaunchKernelGGL(k_firsthit_scan, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pd, ctx->d_owned, ctx->n_owned, nb, ctx->d_quirk_seen);
+      if (shade_sep) { FH_HIP(hipEventRecord(ctx->ev_shade[slot][2u * depth], st)); FH_HIP(hipStreamWaitEvent(sh, ctx->ev_shade[slot][2u * depth], 0)); }
       {
-        Span sp(ctx, st, 6);
-        hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, st, sc, pd, depth, ctx->n_classes, count ? ctx->d_trace_counters + 26 : nullptr);
+        Span sp(ctx, sh, 6);
+        hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, sh, sc, pd, depth, ctx->n_classes, count ? ctx->d_trace_counters + 26 : nullptr);
       }
       if (overlap && depth > 0) FH_HIP(hipStreamWaitEvent(st, ctx->ev_bounce[2u * (depth - 1u) + 1u], 0));  // the secondary launch of the bounce before reads what the shade kernels and the sorts below overwrite
       {
-        Span sp(ctx, st, 2);
-        for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(st, grid, ctx->class_lobes[c], sc, fr, pd, c, depth, shade_three);
-        if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, st, fr, pd);
+        Span sp(ctx, sh, 2);
+        for (uint32_t c = 0; c < ctx->n_classes; ++c) dispatch_shade(sh, grid, ctx->class_lobes[c], sc, fr, pd, c, depth, shade_three);
+        if (depth == 0) hipLaunchKernelGGL(k_miss_primary, dim3(grid), dim3(kBlock), 0, sh, fr, pd);
         ctx->stats.n_shade_launches += ctx->n_classes;
       }
       {
-        Span sp(ctx, st, 6);
+        Span sp(ctx, sh, 6);
         if (sort_queues) {
           // secondary rays of this bounce and the radiance rays of the next one, each into cell order
-          sort_queue_by_cell(st, sort_blocks, pool.counters + depth * kCounterStride + CNT_SEC, pool.q_sec, pool.key_sec, pool.bins, pool.q_sec_sorted);
+          sort_queue_by_cell(sh, sort_blocks, pool.counters + depth * kCounterStride + CNT_SEC, pool.q_sec, pool.key_sec, pool.bins, pool.q_sec_sorted);
           ps = pd;
           ps.q_sec = pool.q_sec_sorted;
           const uint32_t nxt = (depth + 1u) & 1u;
-          sort_queue_by_cell(st, sort_blocks, pool.counters + (depth + 1u) * kCounterStride + CNT_RAD, pd.q_rad[nxt], pool.key_rad, pool.bins, q_spare);
+          sort_queue_by_cell(sh, sort_blocks, pool.counters + (depth + 1u) * kCounterStride + CNT_RAD, pd.q_rad[nxt], pool.key_rad, pool.bins, q_spare);
           uint32_t* const unsorted = pd.q_rad[nxt];
           pd.q_rad[nxt] = q_spare;  // the next bounce reads the sorted queue ...
           q_spare = unsorted;       // ... and the buffer it came from is the next scratch target
@@ -1840,7 +1962,17 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
           ps = pd;
         }
       }
-      {
+      if (shade_sep) { FH_HIP(hipEventRecord(ctx->ev_shade[slot][2u * depth + 1u], sh)); FH_HIP(hipStreamWaitEvent(st, ctx->ev_shade[slot][2u * depth + 1u], 0)); }
+      if (merge && depth + 1u < wave_depth) {
+        Span sp(ctx, st, 1);
+        with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
+          hipLaunchKernelGGL((k_trace_merged_stream<decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stream_stack_bytes_secondary, st, sc,
+                             fr, ps, pd, depth, tc_shadow, coop_flush, stream_refill, stream_chunk, tun.stream_min_rays,
+                             StackSpill{spill_entries_secondary ? ctx->d_stack_spill + (size_t)(2 * slot + 1) * spill_region : nullptr, stream_entries_secondary});
+        }); });
+        ctx->stats.n_shadow_launches++;
+        ctx->stats.n_closest_launches++;
+      } else {
         if (overlap) { FH_HIP(hipEventRecord(ctx->ev_bounce[2u * depth], st)); FH_HIP(hipStreamWaitEvent(sb, ctx->ev_bounce[2u * depth], 0)); }
         Span sp(ctx, sb, 1);
         if (stream) {

@@ -258,6 +258,12 @@ def test_bench_line_contract(tmp_path, cfg, spp):
     assert p["rmse"] == 0.0 and p["bit_identical_pixels"] == 1.0 and p["pixels"] == 8 * 1920
     lat = out["latency"]
     assert 0.0 < lat["spp1"]["min_ms"] <= lat["spp1"]["median_ms"] < lat["spp16"]["median_ms"] * 4
+    if cfg == 2:  # the default configuration appends the general-scene leg (configs[3]) outside the headline's timed region
+        g = out["general_scene"]
+        assert g["workload"].startswith("configs[3]") and g["msamples_per_s"] > 0 and g["parity"]["bit_identical_pixels"] == 1.0 and g["parity"]["rmse"] == 0.0
+        assert g["roofline"]["kernel"].startswith("k_trace") and 0.0 < g["roofline"]["frac"] <= 1.0 and g["roofline"]["kernel_info"]["vgprs"] > 0
+        assert 0.0 < g["latency"]["spp1"]["median_ms"] < g["latency"]["spp16"]["median_ms"]
+        assert r["issue_model"]["stale"] in (True, False) and "counters_stale" in r or r.get("traffic") is None
 
 
 def test_rccl_leg_on_two_gpus(tmp_path):
