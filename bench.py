@@ -668,7 +668,9 @@ def main():
             "metric": "Msamples/s at 1920x1080, max_depth=8" if args.config in (1, 2, 3) else f"Msamples/s at {WIDTH}x{HEIGHT}, max_depth={MAX_DEPTH}", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": w["name"], "spp_per_step": spp, "spp_per_pass": pool_spp, "path_pools": {"pools": n_pools, "bytes_per_path": slot_bytes, "gb": round(n_pools * slot_bytes * n_owned * pool_spp / 1e9, 1)}, "triangles": int(sc["indices"].shape[0]), "parallelism": f"pixel-tile x{world}" if world > 1 else "single GPU",
+            "config": {"workload": w["name"], "spp_per_step": spp, "spp_per_pass": pool_spp, "passes_per_step": round(timed["n_passes"] / max(steps, 1), 2),
+                       "sky_pixel_sample_share": round(timed["sky_pixel_samples"] / max(timed["paths"], 1), 4),  # samples of pixels no ray of which can reach the scene bounds: rendered by k_sky_pixels, outside the passes (the path pools hold the other pixels only, so a pass takes more samples of them than spp_per_pass)
+                       "path_pools": {"pools": n_pools, "bytes_per_path": slot_bytes, "gb": round(n_pools * slot_bytes * n_owned * pool_spp / 1e9, 1)}, "triangles": int(sc["indices"].shape[0]), "parallelism": f"pixel-tile x{world}" if world > 1 else "single GPU",
                        "gather": "RCCL gather of packed float4 beauty tiles to rank 0 + fh_unpack_shard, inside the timed region" if world > 1 else "none",
                        "post": "bloom + chromatic aberration + tone map on the whole frame, inside the timed region" if post else "none"},
             "step_ms": {"min": round(sm[0], 3), "median": round(sm[len(sm) // 2], 3), "max": round(sm[-1], 3)},

@@ -368,7 +368,7 @@ int fh_ctx_create(int device, fh_ctx** out)
   if (hipMalloc((void**)&ctx->d_lut_refl, kLutReflectionBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_sheen, kLutSheenBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_trace_counters, 32 * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc failed");
-  if (hipMalloc((void**)&ctx->d_hosek, sizeof(fh::HosekSky)) != hipSuccess || hipMemset(ctx->d_hosek, 0, sizeof(fh::HosekSky)) != hipSuccess) return bail("hipMalloc failed");
+  if (hipMalloc((void**)&ctx->d_hosek, sizeof(fh::HosekSky)) != hipSuccess || hipMemsetAsync(ctx->d_hosek, 0, sizeof(fh::HosekSky), ctx->stream) != hipSuccess) return bail("hipMalloc failed");
   if (hipMemcpy(ctx->d_sobol, kSobolMatrices, kSobolMatricesBytes, hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
   {
     // byte-indexed form of the generator matrices: entry [dim][k][b] = XOR of the columns 8k + j selected by the bits j of b, so that the XOR over the 32 index
@@ -386,7 +386,7 @@ int fh_ctx_create(int device, fh_ctx** out)
   }
   (void)hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
-  (void)hipMemset(ctx->d_trace_counters, 0, 32 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(ctx->d_trace_counters, 0, 32 * sizeof(unsigned long long), ctx->stream);  // (never hipMemset: it is asynchronous and ordered with nothing on a non-blocking stream)
   for (int k = 0; k < 2; ++k)
     if (make_stream(&ctx->aux_stream[k]) != hipSuccess) return bail("hipStreamCreate failed");
   for (int k = 0; k < 3; ++k) {
@@ -420,6 +420,9 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_off("FH_SORT_SMALL", t.sort_small);
     env_off("FH_OVERLAP", t.overlap_secondary);
     env_off("FH_MERGE", t.merge_trace);
+    if (const char* e = getenv("FH_POISON")) t.poison_pools = e[0] == '1';
+    env_off("FH_SKY_SPLIT", t.sky_split);
+    env_uint("FH_SKY_SPLIT_MIN_LOG2", 0, 40, t.sky_split_min_log2);
     env_uint("FH_SHADE_STREAM", 0, 2, t.shade_stream);
     if (t.shade_stream) {
       int least = 0, greatest = 0;
@@ -440,8 +443,13 @@ int fh_ctx_create(int device, fh_ctx** out)
     if (const char* e = getenv("FH_NO_ALPHA")) t.ignore_alpha = e[0] == '1';
     if (const char* e = getenv("FH_FORCE_ALPHA")) t.force_alpha = e[0] == '1';
   }
+  if (hipStreamCreateWithFlags(&ctx->sky_stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+  (void)hipEventCreateWithFlags(&ctx->ev_sky, hipEventDisableTiming);
+  if (hipMalloc((void**)&ctx->d_split_counters, 16) != hipSuccess) return bail("hipMalloc failed");
+  (void)hipMemsetAsync(ctx->d_split_counters, 0, 16, ctx->stream);
   (void)hipEventCreate(&ctx->ev_render_begin);
   (void)hipEventCreate(&ctx->ev_render_end);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail("hipStreamSynchronize failed");  // the fills above are done before any upload (synchronous copies, ordered with no stream) touches what they cleared
   *out = ctx;
   return FH_OK;
 }
@@ -460,6 +468,10 @@ int fh_ctx_destroy(fh_ctx* ctx)
     if (p) (void)hipFree(p);
   for (fh_ctx::ShardList& c : ctx->shard_lists)
     if (c.d_owned) (void)hipFree(c.d_owned);
+  for (int k = 0; k < 4; ++k) if (ctx->d_split[k]) (void)hipFree(ctx->d_split[k]);
+  if (ctx->d_split_counters) (void)hipFree(ctx->d_split_counters);
+  if (ctx->sky_stream) { (void)hipStreamSynchronize(ctx->sky_stream); (void)hipStreamDestroy(ctx->sky_stream); }
+  if (ctx->ev_sky) (void)hipEventDestroy(ctx->ev_sky);
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto e : ctx->ev_bounce) (void)hipEventDestroy(e);
@@ -774,6 +786,14 @@ int fh_sync(fh_ctx* ctx)
     ctx->event_pool.push_back(s.b);
   }
   ctx->spans.clear();
+  if (ctx->stats.sky_pixel_samples && ctx->d_split_counters) {  // k_sky_pixels re-runs the scene-bounds test of every sample it renders: a hit there means the conservative split was wrong
+    uint32_t violations = 0;
+    FH_HIP(hipMemcpy(&violations, ctx->d_split_counters + 2, 4, hipMemcpyDeviceToHost));
+    if (violations) {
+      (void)hipMemsetAsync(ctx->d_split_counters + 2, 0, 4, ctx->stream);
+      return fail(ctx, FH_E_HIP, "sky-pixel split: " + std::to_string(violations) + " pixels classified as sky have rays that reach the scene bounds (set FH_SKY_SPLIT=0 and report)");
+    }
+  }
   if (ctx->flags & FH_FLAG_TIME_KERNELS) {  // shader cycles and 100 MHz ticks the waves of the streaming traversal kernels have summed up (fh_device.h: ClockStamp)
     unsigned long long c[4];
     FH_HIP(hipMemcpy(c, ctx->d_trace_counters + 27, sizeof c, hipMemcpyDeviceToHost));

@@ -75,7 +75,7 @@ struct fh_ctx {
   bool refit_ok = false;                    // topology unchanged since the last full build, no split references
   double bvh8_area_built = 0.0;             // sum of the node areas right after the full build (quality reference for refits)
   uint32_t n_refits = 0;
-  uint32_t bvh8_depth = 0;            // levels of the wide tree = most entries a traversal stack can hold
+  uint32_t bvh8_depth = 0;            // node LEVELS of the wide tree; a traversal stack needs levels - 1 entries (fh_trace.h: stack_entries_for), of which the streaming kernels keep the first in LDS
   uint32_t occupancy_key = 0xffffffffu, occupancy_blocks = 0, occupancy_blocks_secondary = 0;  // resident workgroups per CU of the streaming kernels, as the runtime reports them (render.hip)
   uint32_t lds_configured_bytes = 0;  // dynamic-LDS size the traversal kernels were last configured for (render.hip)
   uint32_t stream_lds_entries = 0, stream_lds_entries_secondary = 0;    // stack levels the closest-hit / secondary streaming kernel keeps in LDS (the rest spills to d_stack_spill)
@@ -95,6 +95,14 @@ struct fh_ctx {
   uint32_t* d_owned = nullptr;  // image indices of owned pixels, in tile order
   uint32_t* d_owned_xy = nullptr;  // the same pixels as x | y << 16
   uint32_t n_owned = 0;
+  // pixels that cannot see the scene (render.hip: k_split_pixels / k_sky_pixels): [0] / [1] image indices and x | y << 16 of the pixels the passes render, [2] / [3] of the sky pixels
+  uint32_t* d_split[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t split_capacity = 0, n_wave_px = 0, n_sky_px = 0;
+  uint32_t* d_split_counters = nullptr;  // wave pixels, sky pixels, bounds-test violations seen by k_sky_pixels, pad
+  bool split_valid = false;
+  float split_key[32] = {};              // camera, scene bounds, resolution and ownership the lists were made for
+  hipStream_t sky_stream = nullptr;
+  hipEvent_t ev_sky = nullptr;
   struct ShardList { uint32_t rank, world, width, height, tile_w, tile_h; uint32_t* d_owned; uint32_t n_owned; };
   std::vector<ShardList> shard_lists;  // ownership lists of other ranks' shards, built on first use by fh_unpack_shard and kept (freed with the context)
 
@@ -146,6 +154,9 @@ struct fh_ctx {
     uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill
     uint32_t stream_min_rays = 64;  // FH_STREAM_MIN_RAYS: queue entries per wave below which workgroups of a streaming launch stay out (render.hip: stream_block_idle); 0 = all take part
     bool overlap_secondary = true;  // FH_OVERLAP=0: single-pass calls keep every launch on one stream
+    bool sky_split = true;          // FH_SKY_SPLIT=0: every pixel goes through the passes (no k_sky_pixels)
+    uint32_t sky_split_min_log2 = 27; // FH_SKY_SPLIT_MIN_LOG2: a call splits its pixels from 2^n camera paths on (27: 64 spp of a 1080p frame; tests lower it)
+    bool poison_pools = false;      // FH_POISON=1: new path pools are filled with 0xa5 before their first use (tests: nothing may read what nobody wrote)
     bool merge_trace = true;        // FH_MERGE=0: single-pass calls trace secondary rays and the next bounce's closest-hit rays in two launches (two streams) instead of one
     uint32_t shade_stream = 0;      // FH_SHADE_STREAM=1|2 (experiment, profiles/README.md r4): the shade-side launches of a pass on their own stream, 2: of high priority
     uint32_t shade_wgs = 0;         // FH_SHADE_WGS=2|3: workgroups per CU the shade kernels are compiled for (0: three for textured scenes that stream)

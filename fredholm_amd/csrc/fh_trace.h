@@ -237,7 +237,7 @@ FH_D uint32_t octant_permute(uint32_t m, uint32_t oct)
 // near < far.  A box the ray really enters has near' < far' by what the build's padding and the slack below put between them, and 1 / tmax is rounded
 // down by two units (v_rcp_f32 is good to one), so a box that starts just before tmax is never cut off.  tmax < 0: every scaled interval is reversed, so no child with a proper box is hit, as with the unscaled
 // comparison (an empty slot's inverted box can be flagged then: its triangle slot holds the degenerate triangle no ray hits); tmax = 0: the scale is infinite and children may be flagged, but no triangle is accepted (the ray's hit record starts at its tmax); a NaN tmax
-// counts as no limit in v_min_f32, as it did in the minimum of the unscaled form.
+// counts as no limit in v_min_f32, as it did in the minimum of the unscaled form.  (tmax = +0 no longer reaches the division: see the floor in node8_test.)
 #ifndef FH_NODE_SLACK
 #define FH_NODE_SLACK 1
 #endif
@@ -263,8 +263,13 @@ FH_D void node8_child(uint32_t& hits, uint32_t nearx, uint32_t farx, uint32_t ne
 // one bit per child slot whose (conservative) box the ray enters before tmax
 FH_D uint32_t node8_test(const Ray8& r, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, float tmax)
 {
+  // The unit: tmax kept inside [1e-12, 1e30].  The upper end gives a ray without a limit a finite unit.  The lower end is for a ray whose best hit so far is AT its origin
+  // (t = +0: an origin on a triangle): another triangle at t = 0 with a lower face id still has to be found -- the closest-hit order breaks ties by face id, whatever the
+  // shape of the tree -- but 1 / 0 is infinite and an infinite scale turns plane distances into NaN; with the floor every box that holds the origin is entered (near 0,
+  // far 1) and every box that starts later is not.  Taken as an UNSIGNED maximum of the bit patterns: for tmax >= +0 that is the float maximum, a negative tmax (a shadow
+  // ray shorter than its epsilon) and NaN keep their bits, so the one still flags nothing and the other still counts as no limit.
   float tl;
-  asm("v_min_f32 %0, 0x7149f2ca, %1" : "=v"(tl) : "v"(tmax));  // min(tmax, 1e30): a ray without a limit still has a finite unit
+  asm("v_max_u32 %0, 0x2b8cbccc, %1\n\tv_min_f32 %0, 0x7149f2ca, %0" : "=v"(tl) : "v"(tmax));
   const float rt = __builtin_amdgcn_rcpf(tl) * 0.99999976158142090f;
   const float ix = r.inv.x * rt, iy = r.inv.y * rt, iz = r.inv.z * rt;
   const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
@@ -362,6 +367,10 @@ FH_D void node8_eval(const Ray8& r, uint32_t ni, const uint4 n0, const uint4 n1,
   group = make_uint2(n0.w >> 8, (octant_permute(hm & imask, r.oct) << 24) | imask);
   tg = make_uint2(8u * ni, hm & ~imask);
 }
+#ifndef FH_ANYHIT_UNORDERED
+#define FH_ANYHIT_UNORDERED 0  // (experiment: a streaming launch whose rays ALL stop at their first hit visits the children in slot order and saves the octant permutation)
+#endif
+template <bool ORDERED = true>
 FH_D void node8_visit(const Bvh8Dev& bvh, const Ray8& r, uint32_t ni, float tmax, uint2& group, uint2& tg)
 {
   // (a 32-bit byte offset -- the builder refuses trees of 2^23 nodes -- lets the four loads share the base in scalar registers)
@@ -369,6 +378,11 @@ FH_D void node8_visit(const Bvh8Dev& bvh, const Ray8& r, uint32_t ni, float tmax
   const uint4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
   const uint32_t hm = node8_test(r, n0, n1, n2, n3, tmax);
   const uint32_t imask = n0.w & 0xffu;
+  if (!ORDERED) {
+    group = make_uint2(n0.w >> 8, ((hm & imask) << 24) | imask);
+    tg = make_uint2(8u * ni, hm & ~imask);
+    return;
+  }
   // (the permutation is 15 instructions; reading it from a 2 KB table in global memory instead -- one instruction and a byte load -- made the streaming kernels
   // 4-7 % SLOWER, configs[2] closest 71.4 -> 74.7 ms, secondary 111 -> 118.5 ms: a fifth load per node visit costs more in the memory pipeline than 14 instructions
   // cost in the VALU; LDS has no room for the table without giving up a workgroup per CU)
@@ -812,10 +826,11 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
       group.y &= ~(1u << bit);
       if (group.y & 0xff000000u) stack.push(group);
-      const uint32_t slot = (bit - 24u) ^ r.oct;
+      constexpr bool ordered = !(FH_ANYHIT_UNORDERED && Policy::all_any);
+      const uint32_t slot = ordered ? (bit - 24u) ^ r.oct : bit - 24u;
       const uint32_t ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
-      node8_visit(bvh, r, ni, best_t, group, tg);
+      node8_visit<ordered>(bvh, r, ni, best_t, group, tg);
     }
 #endif
     if (FH_HANDOVER_SCAN && (!ALPHA || FH_HANDOVER_SCAN_ALPHA)) {

@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "context.h"
@@ -106,6 +107,32 @@ FH_D f3 env_radiance(const FrameDev& fr, f3 d)
   return fr.has_hosek ? hosek_radiance(*fr.hosek, fr.sun_dir, fr.sky_intensity, d) : fr.bg;
 }
 
+// sample n_spp of pixel (px, py): CMJ slots 0 / 1 -> thin-lens camera ray (pt.cu:433-454, camera.cu:24-53) and the Russian roulette of bounce 0, which has probability 1 but
+// still consumes (and can fail on) a draw (pt.cu:457-461).  Returns whether the path is alive.
+FH_D bool camera_sample(const FrameDev& fr, const uint32_t* sobol_dim1, uint32_t image_idx, uint32_t px, uint32_t py, uint32_t n_spp, f3& org, f3& dir)
+{
+  f2 u = cmj_draw(n_spp, image_idx, 0u, fr.seed_hash);
+  float uvx = (2.0f * (px + u.x) - fr.width) / fr.height;
+  const float uvy = (2.0f * (py + u.y) - fr.height) / fr.height;
+  uvx = -uvx;
+  u = cmj_draw(n_spp, image_idx, 1u, fr.seed_hash);
+  // thin lens (camera.cu:24-53); a + b and the lens radius are the same for every ray: computed once on the host, in fp32 with the reference's operations
+  const float f = fr.cam_inv_tan;
+  const f3 p_sensor = mk3(uvx, uvy, 0.0f);
+  const f3 p_lens_center = mk3(0.0f, 0.0f, f);
+  const f2 pd = fr.cam_lens_radius * concentric_disk(u);
+  const f3 p_lens = p_lens_center + mk3(pd.x, pd.y, 0.0f);
+  const f3 s2c = normalize(p_lens_center - p_sensor);
+  const f3 p_object = p_sensor + (fr.cam_a_plus_b / s2c.z) * s2c;
+  org = xform_point(fr.cam_xf, p_lens);
+  f3 d = normalize(p_object - p_lens);
+  d.z *= -1.0f;
+  dir = xform_dir(fr.cam_xf, d);
+  const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
+  const float rr = sobol_draw_bytes(sobol_dim1, sidx, 1u, fr.seed_hash);
+  return fr.max_depth > 0 && !(rr >= 1.0f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // grid: x over the owned pixels (grid-stride), y = sample of the pass -- slot p = sample * n_owned + pixel without a division per path, and the pixel's
 // coordinates come packed from the ownership list instead of from image_idx / width and % width (four integer divisions by run-time values were ~60 of the
@@ -134,32 +161,11 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
     const uint32_t p = k * n_owned + i;  // slot p = sample-major: lanes of a wave hold neighbouring pixels of one sample index
     bool enter = false;
     if (valid) {
-      bool alive = false;
       const uint32_t image_idx = owned[i];
       const uint32_t n_spp = issued[image_idx] + k;  // sample index = samples started on this pixel so far (pt.cu:423: params.sample_count)
       const uint32_t xy = owned_xy[i];
-      const uint32_t px = xy & 0xffffu, py = xy >> 16;
-      f2 u = cmj_draw(n_spp, image_idx, 0u, fr.seed_hash);
-      float uvx = (2.0f * (px + u.x) - fr.width) / fr.height;
-      const float uvy = (2.0f * (py + u.y) - fr.height) / fr.height;
-      uvx = -uvx;
-      u = cmj_draw(n_spp, image_idx, 1u, fr.seed_hash);
-      // thin lens (camera.cu:24-53); a + b and the lens radius are the same for every ray: computed once on the host, in fp32 with the reference's operations
-      const float f = fr.cam_inv_tan;
-      const f3 p_sensor = mk3(uvx, uvy, 0.0f);
-      const f3 p_lens_center = mk3(0.0f, 0.0f, f);
-      const f2 pd = fr.cam_lens_radius * concentric_disk(u);
-      const f3 p_lens = p_lens_center + mk3(pd.x, pd.y, 0.0f);
-      const f3 s2c = normalize(p_lens_center - p_sensor);
-      const f3 p_object = p_sensor + (fr.cam_a_plus_b / s2c.z) * s2c;
-      const f3 org = xform_point(fr.cam_xf, p_lens);
-      f3 d = normalize(p_object - p_lens);
-      d.z *= -1.0f;
-      const f3 dir = xform_dir(fr.cam_xf, d);
-      // Russian roulette of bounce 0 has probability 1 but still consumes (and can fail on) a draw, pt.cu:457-461
-      const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
-      const float rr = sobol_draw_bytes(rows.m[0], sidx, 1u, fr.seed_hash);
-      alive = fr.max_depth > 0 && !(rr >= 1.0f);
+      f3 org, dir;
+      const bool alive = camera_sample(fr, rows.m[0], image_idx, xy & 0xffffu, xy >> 16, n_spp, org, dir);
       // camera rays that miss the (padded) scene bounds cannot hit anything: they are finished right here
       // (radiance = 0 + 1 * environment, pt.cu:504-523) and never enter the traversal queue, so the waves of
       // bounce 0 only hold rays that enter the scene and no path state is written for the others
@@ -213,6 +219,114 @@ __global__ void __launch_bounds__(kBlock) k_bump_issued(uint32_t* issued, const 
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_owned) issued[owned[i]] += n_batch;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pixels that cannot see the scene.  On the bench's soup 79 % of the pixels are sky from corner to corner: not one ray of their footprint, through any point of
+// the lens, reaches the scene's bounds.  Every sample of such a pixel is a camera ray plus an environment lookup; sent through the wavefront machinery it costs a
+// path slot of 284 bytes, a radiance record written by k_generate and read back by k_accumulate, and it makes a pass hold a fifth of the paths that do work.  So
+// a call that brings enough samples splits its owned pixels once per camera: k_split_pixels sorts them into the pixels the passes render (`wave`) and the sky
+// pixels, and k_sky_pixels renders ALL samples of the call for a sky pixel in one go -- camera sample, environment, NaN guard, running means -- with the same
+// device functions in the same order as k_generate / k_accumulate, i.e. the same bits, no pool memory and one read and one write of the six layers per call.
+//
+// The test is conservative.  In camera space every ray of pixel (px, py) starts on the lens disk (centre A0 = (0, 0, f), radius R) and runs through the
+// z-mirrored image B of its focus point, B = (k uvx, k uvy, 2 f - (a + b)) with k = 1 - (a + b) / f and (uvx, uvy) inside the pixel, so the rays are the lines
+// through a disk of radius R around A0 and a square of half-diagonal rho = sqrt(2) |k| / H around B0.  A point of such a line at parameter s (A + s (B - A))
+// is at most R |1 - s| + rho |s| <= R + (R + rho) |s| away from the centre line's point at s; with d0 the distance of the sphere's centre from the centre line,
+// tau the position of its foot along it and L = |B0 - A0|, no line of the family comes nearer than d0 sqrt(1 - (m / L)^2) - R - m |tau| / L, m = R + rho.  The
+// pixel is sky when that exceeds the bounding sphere of the padded scene bounds with a margin (0.1 % of the radius and of the distance, far above the rounding
+// of these few operations).  k_sky_pixels still runs k_generate's own bounds test per sample and counts a violation (fh_sync reports it): the split can only
+// lose speed, never a ray that hits.
+struct SplitDev {
+  f3 centre;      // bounding sphere of the padded scene bounds, camera space
+  float radius;
+  uint32_t* wave_px; uint32_t* wave_xy; uint32_t* sky_px; uint32_t* sky_xy;
+  uint32_t* counters;  // [0] wave pixels, [1] sky pixels, [2] bounds-test violations seen by k_sky_pixels
+};
+__global__ void __launch_bounds__(kBlock) k_split_pixels(FrameDev fr, SplitDev sp, const uint32_t* owned, const uint32_t* owned_xy, uint32_t n_owned)
+{
+  __shared__ uint32_t s_reserve[2][10];
+  uint32_t iter = 0;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n_owned; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    bool sky = false, wave = false;
+    uint32_t px = 0, xy = 0;
+    if (i < n_owned) {
+      px = owned[i]; xy = owned_xy[i];
+      const float x = (float)(xy & 0xffffu) + 0.5f, y = (float)(xy >> 16) + 0.5f;
+      const float uvx = -(2.0f * x - (float)fr.width) / (float)fr.height, uvy = (2.0f * y - (float)fr.height) / (float)fr.height;
+      const float f = fr.cam_inv_tan, k = 1.0f - fr.cam_a_plus_b / f;
+      const f3 a0 = mk3(0.0f, 0.0f, f), b0 = mk3(k * uvx, k * uvy, 2.0f * f - fr.cam_a_plus_b);
+      const f3 ab = b0 - a0;
+      const float L = length(ab);
+      const float m = fabsf(fr.cam_lens_radius) + 1.41421357f * fabsf(k) / (float)fr.height * 1.001f;
+      const f3 w = sp.centre - a0;
+      const float tau = dot(w, ab) / L;
+      const float d0 = sqrt_cr(fmaxf(dot(w, w) - tau * tau, 0.0f));
+      const float q = 1.0f - (m / L) * (m / L);
+      const float nearest = d0 * sqrt_cr(fmaxf(q, 0.0f)) - fabsf(fr.cam_lens_radius) - m * fabsf(tau) / L;
+      sky = L > 0.0f && q > 0.0f && nearest > sp.radius * 1.001f + 1e-3f * (length(w) + 1.0f);  // (NaN anywhere: not sky)
+      wave = !sky;
+    }
+    uint32_t* const counters2[2] = {sp.counters, sp.counters + 1};
+    const bool act[2] = {wave, sky};
+    uint32_t pos[2];
+    block_queue_reserve<2>(counters2, act, pos, s_reserve[iter & 1u]);
+    ++iter;
+    if (wave) { sp.wave_px[pos[0]] = px; sp.wave_xy[pos[0]] = xy; }
+    if (sky) { sp.sky_px[pos[1]] = px; sp.sky_xy[pos[1]] = xy; }
+  }
+}
+
+// all `n_samples` samples of this call for the sky pixels: k_generate's path for a ray that misses the scene bounds and k_accumulate's update of the running means, fused
+__global__ void __launch_bounds__(kBlock) k_sky_pixels(FrameDev fr, LayersDev layers, uint32_t* issued, const uint32_t* sky_px, const uint32_t* sky_xy, uint32_t n_sky, uint32_t n_samples,
+                                                     uint32_t* violations)
+{
+  __shared__ SobolRows<1> rows;
+  __shared__ HosekSky s_sky;
+  stage_sky(fr, s_sky);
+  const uint32_t dims[1] = {1u};
+  load_sobol_rows<1>(rows, fr.sobol_bytes, dims);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sky; i += gridDim.x * blockDim.x) {
+    const uint32_t image_idx = sky_px[i], xy = sky_xy[i];
+    const uint32_t first = issued[image_idx];
+    uint32_t n_spp = layers.sample_count[image_idx];
+    f3 beauty = mk3(layers.beauty[image_idx]), position = mk3(layers.position[image_idx]), normal = mk3(layers.normal[image_idx]), albedo = mk3(layers.albedo[image_idx]);
+    float depth = layers.depth[image_idx];
+    const float4 tc4 = layers.texcoord[image_idx];
+    float tcx = tc4.x, tcy = tc4.y;
+    bool violated = false;
+    for (uint32_t k = 0; k < n_samples; ++k) {
+      f3 org, dir;
+      const bool alive = camera_sample(fr, rows.m[0], image_idx, xy & 0xffffu, xy >> 16, first + k, org, dir);
+      RayPre rp;
+      rp.o = org;
+      rp.inv = safe_reciprocal(dir);
+      float tn;
+      violated = violated || (alive && slab_test(rp, fr.scene_lo.x, fr.scene_lo.y, fr.scene_lo.z, fr.scene_hi.x, fr.scene_hi.y, fr.scene_hi.z, 1e9f, tn));
+      const f3 L = alive ? mk3(0.0f) + mk3(1.0f) * env_radiance(fr, dir) : mk3(0.0f);  // (k_generate: radiance of a path that ends at the scene bounds)
+      const f3 radiance = bad3(L) ? mk3(0.0f) : L;                                      // (k_accumulate: NaN guard, then the running means; a sky sample has no AOVs)
+      const float coef = 1.0f / (n_spp + 1.0f);
+      const float fn = (float)n_spp;
+      beauty = coef * (fn * beauty + radiance);
+      position = coef * (fn * position + mk3(0.0f));
+      normal = coef * (fn * normal + mk3(0.0f));
+      depth = coef * (fn * depth + 0.0f);
+      tcx = coef * (fn * tcx + 0.0f);
+      tcy = coef * (fn * tcy + 0.0f);
+      albedo = coef * (fn * albedo + mk3(0.0f));
+      n_spp++;
+    }
+    if (violated) atomicAdd(violations, 1u);
+    issued[image_idx] = first + n_samples;
+    layers.sample_count[image_idx] = n_spp;
+    layers.beauty[image_idx] = mk4(beauty, 1.0f);
+    layers.position[image_idx] = mk4(position, 1.0f);
+    layers.normal[image_idx] = mk4(normal, 1.0f);
+    layers.depth[image_idx] = depth;
+    layers.texcoord[image_idx] = make_float4(tcx, tcy, 0.0f, 1.0f);
+    layers.albedo[image_idx] = mk4(albedo, 1.0f);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -318,6 +432,7 @@ FH_D bool stream_block_idle(uint32_t count, uint32_t min_rays) { return blockIdx
 
 template <bool COUNT>
 struct ClosestStream {
+  static constexpr bool all_any = false;
   const PoolDev& pool;
   const uint32_t* q;
   ChunkFeed feed;
@@ -998,6 +1113,7 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? 5 : 6)) k_trace_
 // same lane, so the additions into the path's radiance keep the reference's order (directional, sky, area, BSDF-sampled)
 template <bool COUNT, bool LIGHTS>
 struct SecondaryStream {
+  static constexpr bool all_any = !LIGHTS;  // without emitters every secondary ray stops at its first hit
   const SceneDev& sc;
   const FrameDev& fr;
   const PoolDev& pool;
@@ -1099,6 +1215,7 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
 // (traverse_stream's per-lane flag), and the launch has ONE end.  Same device functions, same per-path order of operations: the bits do not change.
 template <bool LIGHTS>
 struct MergedStream {
+  static constexpr bool all_any = false;
   SecondaryStream<false, LIGHTS> sec;
   const PoolDev& next;        // the view whose radiance queue of bounce b + 1 is traced
   const uint32_t* q_closest;
@@ -1503,6 +1620,7 @@ void pool_release(fh_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);  // nothing may still be running out of the buffers (the counter snapshots trail the accumulate)
   for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(ctx->aux_stream[k]);
   for (int k = 0; k < 3; ++k) if (ctx->shade_stream[k]) (void)hipStreamSynchronize(ctx->shade_stream[k]);
+  if (ctx->sky_stream) (void)hipStreamSynchronize(ctx->sky_stream);
   for (int k = 0; k < 3; ++k) {
     for (void* p : ctx->pool_allocs[k]) (void)hipFree(p);
     ctx->pool_allocs[k].clear();
@@ -1536,8 +1654,10 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
   PoolDev& P = ctx->pool[slot];
   auto alloc = [&](auto*& ptr, size_t count) -> hipError_t {
     void* raw = nullptr;
-    const hipError_t e = hipMalloc(&raw, count * sizeof(*ptr));
+    hipError_t e = hipMalloc(&raw, count * sizeof(*ptr));
     if (e == hipSuccess) { ctx->pool_allocs[slot].push_back(raw); ptr = (decltype(ptr))raw; }
+    // FH_POISON=1 (tests): a new pool starts out full of 0xa5 instead of whatever the allocation held, so a kernel that reads a record or a queue entry nobody wrote shows at once
+    if (e == hipSuccess && ctx->tun.poison_pools) e = hipMemsetAsync(raw, 0xa5, count * sizeof(*ptr), slot ? ctx->aux_stream[slot - 1] : ctx->stream);
     return e;
   };
   const size_t n = capacity;
@@ -1562,7 +1682,10 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
     FH_POOL(P.key_sec, n); FH_POOL(P.key_rad, n); FH_POOL(P.q_tmp, n); FH_POOL(P.q_sec_sorted, n);
     FH_POOL(P.bins, (size_t)2 * kCells);
 #undef FH_POOL
-    return hipMemset(P.bins, 0, sizeof(uint32_t) * 2 * kCells);
+    // (on the stream this slot's passes run on, where the sorts that use the bins follow it: hipMemset on the null stream returns before the fill has run and is ordered
+    // with NOTHING on a non-blocking stream -- a pass whose first sort overtook the fill counted into whatever the allocation held, turned that into scatter cursors and wrote
+    // queue entries gigabytes away: the memory fault of profiles/README.md r4-10)
+    return hipMemsetAsync(P.bins, 0, sizeof(uint32_t) * 2 * kCells, slot ? ctx->aux_stream[slot - 1] : ctx->stream);
   };
   const hipError_t e = all();
   if (e != hipSuccess) {  // leave the slot empty rather than half allocated: the next call starts from scratch
@@ -1615,6 +1738,59 @@ int configure_traversal_lds(fh_ctx* ctx, uint32_t stack_bytes)
   return FH_OK;
 }
 
+// classify the owned pixels for this camera (k_split_pixels); cached until camera, resolution, ownership or scene bounds change
+static int split_pixels(fh_ctx* ctx, const fh_camera* cam, const FrameDev& fr)
+{
+  float key[32] = {};
+  for (int i = 0; i < 12; ++i) key[i] = cam->transform[i];
+  key[12] = cam->fov; key[13] = cam->F; key[14] = cam->focus;
+  for (int i = 0; i < 3; ++i) { key[15 + i] = ctx->scene_lo[i]; key[18 + i] = ctx->scene_hi[i]; }
+  key[21] = (float)ctx->width; key[22] = (float)ctx->height; key[23] = (float)ctx->n_owned; key[24] = (float)ctx->shard_rank; key[25] = (float)ctx->shard_world;
+  key[26] = (float)ctx->tile_w; key[27] = (float)ctx->tile_h;
+  if (ctx->split_valid && std::memcmp(key, ctx->split_key, sizeof key) == 0) return FH_OK;
+  ctx->split_valid = false;
+  // the bound is derived for a rigid camera transform (rotation + translation): anything else renders every pixel through the passes
+  const float* t = cam->transform;
+  float dev = 0.0f;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      const float d = t[a] * t[b] + t[4 + a] * t[4 + b] + t[8 + a] * t[8 + b];  // columns of the 3x3 block
+      dev = fmaxf(dev, fabsf(d - (a == b ? 1.0f : 0.0f)));
+    }
+  std::memcpy(ctx->split_key, key, sizeof key);
+  ctx->n_wave_px = ctx->n_owned; ctx->n_sky_px = 0;
+  if (!(dev < 1e-4f)) { ctx->split_valid = true; return FH_OK; }  // (valid: "no sky pixels" for this key)
+  if (ctx->split_capacity < ctx->n_owned) {
+    FH_HIP(hipDeviceSynchronize());
+    for (int k = 0; k < 4; ++k) { if (ctx->d_split[k]) (void)hipFree(ctx->d_split[k]); ctx->d_split[k] = nullptr; }
+    ctx->split_capacity = 0;
+    for (int k = 0; k < 4; ++k) FH_HIP(hipMalloc((void**)&ctx->d_split[k], 4ull * ctx->n_owned));
+    ctx->split_capacity = ctx->n_owned;
+  }
+  // no launch of an earlier call may still read the lists that are rewritten here
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 2; ++k) FH_HIP(hipStreamSynchronize(ctx->aux_stream[k]));
+  FH_HIP(hipStreamSynchronize(ctx->sky_stream));
+  SplitDev sp{};
+  const float c[3] = {0.5f * (ctx->scene_lo[0] + ctx->scene_hi[0]), 0.5f * (ctx->scene_lo[1] + ctx->scene_hi[1]), 0.5f * (ctx->scene_lo[2] + ctx->scene_hi[2])};
+  const float w[3] = {c[0] - t[3], c[1] - t[7], c[2] - t[11]};
+  sp.centre = mk3(t[0] * w[0] + t[4] * w[1] + t[8] * w[2], t[1] * w[0] + t[5] * w[1] + t[9] * w[2], t[2] * w[0] + t[6] * w[1] + t[10] * w[2]);  // R^T (C - T)
+  const float e[3] = {ctx->scene_hi[0] - ctx->scene_lo[0], ctx->scene_hi[1] - ctx->scene_lo[1], ctx->scene_hi[2] - ctx->scene_lo[2]};
+  sp.radius = 0.5f * sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  sp.wave_px = ctx->d_split[0]; sp.wave_xy = ctx->d_split[1]; sp.sky_px = ctx->d_split[2]; sp.sky_xy = ctx->d_split[3];
+  sp.counters = ctx->d_split_counters;
+  FH_HIP(hipMemsetAsync(ctx->d_split_counters, 0, 8, ctx->stream));  // (the violation counter, word 2, keeps counting)
+  hipLaunchKernelGGL(k_split_pixels, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, ctx->stream, fr, sp, ctx->d_owned, ctx->d_owned_xy, ctx->n_owned);
+  uint32_t n[2] = {0, 0};
+  FH_HIP(hipMemcpyAsync(n, ctx->d_split_counters, 8, hipMemcpyDeviceToHost, ctx->stream));
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  if (n[0] + n[1] != ctx->n_owned) return fail(ctx, FH_E_HIP, "k_split_pixels lost pixels");
+  ctx->n_wave_px = n[0]; ctx->n_sky_px = n[1];
+  ctx->split_valid = true;
+  if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[split] %u of %u owned pixels cannot see the scene (bounding sphere radius %.4f at camera-space (%.3f, %.3f, %.3f))\n", n[1], ctx->n_owned, sp.radius, sp.centre.x, sp.centre.y, sp.centre.z);
+  return FH_OK;
+}
+
 int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_render_layers* layers, uint32_t n_samples, uint32_t max_depth, uint32_t seed)
 {
   if (!ctx->scene_loaded || !ctx->bvh_valid) return fail(ctx, FH_E_INVALID, "fh_render: scene not uploaded or BVH not built");
@@ -1641,11 +1817,6 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       // (pools that exist already keep their size unless they have to be re-made: pool_ensure only grows)
     }
   }
-  uint32_t target = ctx->pool_target > ctx->n_owned ? ctx->pool_target : ctx->n_owned;
-  uint32_t batch = target / ctx->n_owned;
-  if (batch > n_samples) batch = n_samples;
-  if (batch > 65535u) batch = 65535u;  // (k_generate's grid has one row per sample of the pass)
-  if (batch < 1) batch = 1;
 
   FrameDev fr{};
   fr.width = ctx->width; fr.height = ctx->height;
@@ -1697,6 +1868,28 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   L.normal = (float4*)layers->normal; L.texcoord = (float4*)layers->texcoord; L.albedo = (float4*)layers->albedo;
   L.sample_count = ctx->d_sample_count;
 
+  // ---- pixels that cannot see the scene are rendered by k_sky_pixels, the others by the passes below (see k_split_pixels).  Worth its fixed cost -- one small launch and a
+  // host synchronisation whenever camera, resolution or scene bounds change -- for calls of many samples only: 2^27 camera paths, 64 spp of a 1080p frame
+  const uint32_t* px_list = ctx->d_owned;
+  const uint32_t* xy_list = ctx->d_owned_xy;
+  uint32_t n_px = ctx->n_owned, n_sky = 0;
+  const bool quirk_call = (ctx->flags & FH_FLAG_REFERENCE_FIRSTHIT) != 0 && n_samples > 1;
+  if (ctx->tun.sky_split && !quirk_call && (unsigned long long)n_samples * ctx->n_owned >= (1ull << ctx->tun.sky_split_min_log2)) {
+    const int rc = split_pixels(ctx, cam, fr);
+    if (rc) return rc;
+    if (ctx->split_valid && ctx->n_sky_px >= ctx->n_owned / 8u) {  // (a handful of sky pixels is not worth a second kernel)
+      px_list = ctx->d_split[0]; xy_list = ctx->d_split[1];
+      n_px = ctx->n_wave_px; n_sky = ctx->n_sky_px;
+    }
+  }
+  uint32_t target = ctx->pool_target > ctx->n_owned ? ctx->pool_target : ctx->n_owned;
+  uint32_t batch = n_px ? target / n_px : n_samples;
+  if (batch > n_samples) batch = n_samples;
+  if (batch > 65535u) batch = 65535u;  // (k_generate's grid has one row per sample of the pass)
+  if (batch < 1) batch = 1;
+  // (the passes of a call overlap, three in flight: a big call that would fit two passes is cut into three of the same size)
+  if (n_sky && batch < n_samples && (n_samples + batch - 1u) / batch < (uint32_t)ctx->n_slots && (unsigned long long)n_samples * n_px >= 3ull << 24) batch = (n_samples + (uint32_t)ctx->n_slots - 1u) / (uint32_t)ctx->n_slots;
+
   const SceneDev sc = scene_dev(ctx);
   const bool count = (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) != 0;
   const bool clocks = (ctx->flags & FH_FLAG_TIME_KERNELS) != 0;
@@ -1725,6 +1918,13 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   FH_HIP(hipEventRecord(ctx->ev_enter, ctx->stream));
   for (int k = 0; k + 1 < ctx->n_slots; ++k) FH_HIP(hipStreamWaitEvent(ctx->aux_stream[k], ctx->ev_enter, 0));
   int last_slot = 0;
+  if (n_sky) {  // the sky pixels of this call, all samples at once, on a stream of their own next to the passes (they share no pixel with them)
+    FH_HIP(hipStreamWaitEvent(ctx->sky_stream, ctx->ev_enter, 0));
+    Span sp(ctx, ctx->sky_stream, 4);
+    hipLaunchKernelGGL(k_sky_pixels, dim3(grid_for(n_sky)), dim3(kBlock), 0, ctx->sky_stream, fr, L, ctx->d_sample_issued, ctx->d_split[2], ctx->d_split[3], n_sky, n_samples, ctx->d_split_counters + 2);
+    ctx->stats.paths += (uint64_t)n_sky * n_samples;
+    ctx->stats.sky_pixel_samples += (uint64_t)n_sky * n_samples;
+  }
 
   // device facts and developer switches were read once at fh_ctx_create (context.h: Tunables)
   const fh_ctx::Tunables& tun = ctx->tun;
@@ -1821,11 +2021,11 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const bool sort_queues = tun.sort_queues && (stream || tun.sort_small);
   const bool shade_three = tun.shade_wgs ? tun.shade_wgs == 3u : (stream && sc.n_textures > 0);  // (above, FH_SHADE_BLOCKS)
 
-  for (uint32_t done = 0; done < n_samples; done += batch) {
+  for (uint32_t done = 0; done < n_samples && n_px; done += batch) {
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
-    const uint32_t n_paths = ctx->n_owned * nb;
+    const uint32_t n_paths = n_px * nb;
     const uint32_t grid = grid_for(n_paths);
-    // n_slots passes in flight (two by default): pass j lives in pool j % n_slots on the stream of that slot.  Only two things order consecutive passes: the sample
+    // n_slots passes in flight (three by default, FH_PIPELINE): pass j lives in pool j % n_slots on the stream of that slot.  Only two things order consecutive passes: the sample
     // indices (k_generate reads what k_bump_issued of the pass before wrote) and the running means (k_accumulate of pass j
     // follows k_accumulate of pass j - 1, so the floating-point result is that of a serial run)
     // (the bug-compat mode keeps every pass on the main stream: a pass needs the first-hit state the pass before it left)
@@ -1834,6 +2034,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     const int n_slots = serial ? 1 : ctx->n_slots;
     const int slot = serial ? 0 : (int)(ctx->pass_seq % (unsigned long long)n_slots), prev = serial ? ctx->last_slot_used : (slot + n_slots - 1) % n_slots;
     ctx->pass_seq++;
+    ctx->stats.n_passes++;
     ctx->last_slot_used = slot;
     hipStream_t st = slot ? ctx->aux_stream[slot - 1] : ctx->stream;
     last_slot = slot;
@@ -1864,14 +2065,14 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         FH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->ev_shade[slot].push_back(e);
       }
-    { const int rc = pool_ensure(ctx, slot, ctx->n_owned * batch); if (rc) return rc; }
+    { const int rc = pool_ensure(ctx, slot, n_px * batch); if (rc) return rc; }
     const PoolDev& pool = ctx->pool[slot];
     FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
     if (prev != slot && ctx->gen_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_gen[prev], 0));
     {
       Span sp(ctx, st, 4);
-      hipLaunchKernelGGL(k_generate, dim3(grid_for((ctx->n_owned + kGenChunks - 1) / kGenChunks), nb), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, ctx->d_owned, ctx->d_owned_xy, ctx->n_owned);
-      hipLaunchKernelGGL(k_bump_issued, dim3((ctx->n_owned + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ctx->d_sample_issued, ctx->d_owned, ctx->n_owned, nb);
+      hipLaunchKernelGGL(k_generate, dim3(grid_for((n_px + kGenChunks - 1) / kGenChunks), nb), dim3(kBlock), 0, st, fr, pool, ctx->d_sample_issued, px_list, xy_list, n_px);
+      hipLaunchKernelGGL(k_bump_issued, dim3((n_px + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ctx->d_sample_issued, px_list, n_px, nb);
       ctx->stats.n_generate_launches++;
     }
     FH_HIP(hipEventRecord(ctx->ev_gen[slot], st));
@@ -1933,7 +2134,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         }
         ctx->stats.n_closest_launches++;
       }
-      if (quirk && depth == 0) hipLaunchKernelGGL(k_firsthit_scan, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pd, ctx->d_owned, ctx->n_owned, nb, ctx->d_quirk_seen);
+      if (quirk && depth == 0) hipLaunchKernelGGL(k_firsthit_scan, dim3(grid_for(n_px)), dim3(kBlock), 0, st, pd, px_list, n_px, nb, ctx->d_quirk_seen);
       if (shade_sep) { FH_HIP(hipEventRecord(ctx->ev_shade[slot][2u * depth], st)); FH_HIP(hipStreamWaitEvent(sh, ctx->ev_shade[slot][2u * depth], 0)); }
       {
         Span sp(ctx, sh, 6);
@@ -2012,8 +2213,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     if (prev != slot && ctx->acc_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_acc[prev], 0));
     {
       Span sp(ctx, st, 5);
-      if (quirk) hipLaunchKernelGGL(k_accumulate<true>, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb, ctx->d_quirk_aov);
-      else hipLaunchKernelGGL(k_accumulate<false>, dim3(grid_for(ctx->n_owned)), dim3(kBlock), 0, st, pool, L, ctx->d_owned, ctx->n_owned, nb, (float4*)nullptr);
+      if (quirk) hipLaunchKernelGGL(k_accumulate<true>, dim3(grid_for(n_px)), dim3(kBlock), 0, st, pool, L, px_list, n_px, nb, ctx->d_quirk_aov);
+      else hipLaunchKernelGGL(k_accumulate<false>, dim3(grid_for(n_px)), dim3(kBlock), 0, st, pool, L, px_list, n_px, nb, (float4*)nullptr);
       ctx->stats.n_accumulate_launches++;
     }
     FH_HIP(hipEventRecord(ctx->ev_acc[slot], st));
@@ -2027,7 +2228,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   }
   // join: later work on the main stream (pack, post-process, copies, the caller's clears) sees every pass of this call
   // (the accumulates form a chain across the streams, so the last one implies all the others)
-  if (last_slot != 0) FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_acc[last_slot], 0));
+  if (last_slot != 0 && n_px) FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_acc[last_slot], 0));
+  if (n_sky) { FH_HIP(hipEventRecord(ctx->ev_sky, ctx->sky_stream)); FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_sky, 0)); }
   FH_HIP(hipGetLastError());
   return FH_OK;
 }

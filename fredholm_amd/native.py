@@ -87,7 +87,8 @@ class StatsC(C.Structure):
                 ("generate_ms", C.c_double), ("accumulate_ms", C.c_double), ("queue_ms", C.c_double),
                 ("n_generate_launches", C.c_uint64), ("n_accumulate_launches", C.c_uint64), ("n_shade_launches", C.c_uint64), ("n_tail_launches", C.c_uint64),
                 ("shaded_hits", C.c_uint64), ("bvh_depth", C.c_uint64), ("post_ms", C.c_double), ("n_post_launches", C.c_uint64),
-                ("clk_cycles_closest", C.c_uint64), ("clk_ticks_closest", C.c_uint64), ("clk_cycles_shadow", C.c_uint64), ("clk_ticks_shadow", C.c_uint64)]
+                ("clk_cycles_closest", C.c_uint64), ("clk_ticks_closest", C.c_uint64), ("clk_cycles_shadow", C.c_uint64), ("clk_ticks_shadow", C.c_uint64),
+                ("n_passes", C.c_uint64), ("sky_pixel_samples", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}

@@ -8,11 +8,15 @@
  * definition built only from IEEE-754 +,-,*,/,sqrt,fma and integer bit operations, which round
  * identically on x86-64 and gfx950 (HIP's default fp32 divide/sqrt are correctly rounded and
  * both sides are compiled with -ffp-contract=off).  Accuracy is <= 2 ulp over the argument
- * ranges the integrator uses (checked against float64 libm in tests/test_elementary.py).
+ * ranges the integrator uses (checked against float64 libm in tests/test_oracle_anchors.py:
+ * test_elementary_accuracy).
  *
- * It is a numerical spec, not part of the integrator: the HIP kernels (fredholm_amd/csrc) and
- * the CPU checker (oracle/) both include it so that their images can be compared pixel by
- * pixel instead of statistically.
+ * It is the PRODUCT's implementation of that numerical specification (host + device).  The CPU
+ * checker has its own (oracle/oelementary.h: coefficient tables, one Horner routine, its own
+ * special-case handling) and includes nothing from here; tests/test_oracle_anchors.py compiles this
+ * header for the host and requires the two to agree bit for bit over millions of arguments, and
+ * fh_kat_elementary does the same for the device build -- which is what lets images be compared
+ * pixel by pixel instead of statistically.
  */
 #ifndef FH_ELEMENTARY_H
 #define FH_ELEMENTARY_H

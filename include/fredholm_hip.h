@@ -122,6 +122,8 @@ typedef struct fh_stats {
   /* FH_FLAG_TIME_KERNELS, streaming traversal kernels: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) summed over their waves;
    * the clock the chip held while they ran = cycles / ticks x 100 MHz */
   uint64_t clk_cycles_closest, clk_ticks_closest, clk_cycles_shadow, clk_ticks_shadow;
+  uint64_t n_passes;          /* passes of the path pools submitted */
+  uint64_t sky_pixel_samples; /* camera samples (counted in `paths`) rendered by the sky-pixel kernel: samples of pixels no ray of which can reach the scene's bounds */
 } fh_stats;
 
 #define FH_FLAG_TIME_KERNELS 1u    /* bracket traversal/shade launches with HIP events (fh_stats *_ms) */

@@ -561,7 +561,7 @@ static void closest_hit_radiance(const Scene& s, const Frame& fr, const Hit& h, 
         pl.radiance += regularize(pl.throughput * w * f * abs_cos(wi) / pdf) * s.dir.le;
       }
     }
-    {  // sky / constant background NEE, pt.cu:817-857 (IBL branch :796-816 not supported by the checker)
+    {  // sky / constant background / IBL NEE, pt.cu:796-857 (the three branches differ only in the radiance looked up along sd: env_radiance above)
       const V3 wi = cosine_hemisphere(sample_2d(pl.sampler));
       const V3 sd = to_world(wi, tangent, normal, bitangent);
       if (shadow_visible(s, so, sd, 1e9f)) {

@@ -772,3 +772,53 @@ def test_every_bench_configuration_has_a_counter_file_the_bench_line_can_quote()
         assert 0.0 < v["accesses_per_cycle_per_cu"] <= v["peak_accesses_per_cycle_per_cu"] == 1.0
         assert 0.0 < v["ta_busy_frac"] <= 1.0
         assert os.path.exists(os.path.join(ROOT, v["source"].split(";")[0]))
+
+
+def test_counter_files_and_issue_model_are_tied_to_the_sources(tmp_path, monkeypatch):
+    """What bench.py quotes from files -- hardware counters (profiles/*_traffic_config*.json) and the issue cycles of the node / triangle test
+    (profiles/r*_issue_peak.json) -- carries a hash of the sources it was measured on; the line says `counters_stale` / `issue_model.stale` when the sources have
+    changed since.  The fingerprint covers every file the device code is compiled from and changes with any of them."""
+    sys.path.insert(0, ROOT)
+    import json
+    import shutil
+    import bench
+
+    fp = bench.source_fingerprint()
+    assert len(fp) == 16 and fp == bench.source_fingerprint()
+    # a copy of the tree with one byte more in a device header has another fingerprint
+    fake = tmp_path / "repo"
+    for sub in ("fredholm_amd/csrc", "include", "profiles"):
+        (fake / sub).mkdir(parents=True)
+    for f in os.listdir(os.path.join(ROOT, "fredholm_amd", "csrc")):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            shutil.copy(os.path.join(ROOT, "fredholm_amd", "csrc", f), fake / "fredholm_amd" / "csrc" / f)
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        if f.startswith("fh_") and f.endswith(".h"):
+            shutil.copy(os.path.join(ROOT, "include", f), fake / "include" / f)
+    monkeypatch.setattr(bench, "ROOT", str(fake))
+    assert bench.source_fingerprint() == fp
+    with open(fake / "fredholm_amd" / "csrc" / "fh_trace.h", "a") as f:
+        f.write("\n")
+    assert bench.source_fingerprint() != fp
+    # the issue model: taken from the newest profiles/r*_issue_peak.json, stale when fh_trace.h is not the file it was measured with
+    sha = bench.file_hash("fredholm_amd/csrc/fh_trace.h")
+    json.dump({"node8_test_simd_cycles": 500.0, "tri_test_simd_cycles": 170.0, "fh_trace_h_sha256_16": sha}, open(fake / "profiles" / "r99_issue_peak.json", "w"))
+    im = bench.issue_model()
+    assert im["node"] == 500.0 and im["tri"] == 170.0 and im["stale"] is False and "r99_issue_peak.json" in im["source"]
+    with open(fake / "fredholm_amd" / "csrc" / "fh_trace.h", "a") as f:
+        f.write("// changed\n")
+    assert bench.issue_model()["stale"] is True
+    # without a file: the round-3 constants, flagged
+    os.remove(fake / "profiles" / "r99_issue_peak.json")
+    im = bench.issue_model()
+    assert im["node"] == bench.NODE_TEST_SIMD_CYCLES and im["stale"] is True
+
+
+def test_committed_issue_model_file_is_well_formed():
+    sys.path.insert(0, ROOT)
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_peak.json")))
+    assert files, "no profiles/r*_issue_peak.json (tools/micro/issue_peak.bin --json)"
+    j = json.load(open(files[-1]))
+    assert 300.0 < j["node8_test_simd_cycles"] < 900.0 and 100.0 < j["tri_test_simd_cycles"] < 400.0 and len(j["fh_trace_h_sha256_16"]) == 16

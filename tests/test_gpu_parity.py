@@ -732,6 +732,28 @@ def test_small_path_pool_and_batching_do_not_change_results(oracle):
     _assert_image_parity(a["beauty"], ref["beauty"])
 
 
+@pytest.mark.parametrize("scene_name", ["soup_sky", "textured_cornell"])
+def test_new_path_pools_full_of_garbage_do_not_change_results(oracle, monkeypatch, scene_name):
+    """FH_POISON=1 fills every new path pool with 0xa5 bytes before its first use, standing in for whatever a recycled allocation holds.  Calls of several passes over
+    a small pool then bring three pools into use one after the other, on three streams: every record, queue entry, sort bin and counter a kernel reads has to have been
+    written by the pass itself.  (Round 4: the sort bins of a new pool were cleared by hipMemset, which is asynchronous and ordered with nothing on a non-blocking
+    stream; a sort that overtook the fill scattered queue entries through cursors made of garbage -- a memory fault gigabytes away from the pool.)"""
+    monkeypatch.setenv("FH_POISON", "1")
+    w, h = 48, 40
+    if scene_name == "soup_sky":
+        sc, cam = scenes.triangle_soup(20000, 0.08), F.Camera(**scenes.SOUP_CAMERA)
+
+        def setup(x):
+            x.set_directional_light((0, 0, 0), scenes.SOUP_SUN, 0.0)
+            x.load_arhosek_sky(3.0, 0.3)
+    else:
+        sc, cam = scenes.textured_cornell_box(), F.Camera(**scenes.CORNELL_CAMERA)
+        setup = None
+    gpu, ref = _render_pair(oracle, sc, cam, w, h, launches=2, spp_per_launch=7, depth=4, setup=setup, bg=(0.1, 0.2, 0.4), pool=w * h * 2)  # passes of 2, 2, 2, 1 over three pools
+    for name in F.RenderLayer.NAMES:
+        _assert_image_parity(gpu[name], ref[name])
+
+
 @pytest.mark.parametrize("lds_levels", ["1", "3", "99"])
 def test_spilled_traversal_stack_does_not_change_results(oracle, monkeypatch, lds_levels):
     """The streaming kernels keep the first levels of the traversal stack in LDS and spill deeper entries to global memory (render.hip: StackSpill; on its own only
@@ -746,6 +768,65 @@ def test_spilled_traversal_stack_does_not_change_results(oracle, monkeypatch, ld
     gpu, ref = _render_pair(oracle, scenes.triangle_soup(30000, 0.08), cam, 96, 54, launches=2, spp_per_launch=2, depth=6, setup=setup)
     _assert_image_parity(gpu["beauty"], ref["beauty"])
     _assert_image_parity(gpu["position"], ref["position"])
+
+
+@pytest.mark.parametrize("sky,lens", [("hosek", 100.0), ("hosek", 16.0), ("constant", 100.0), ("ibl", 32.0)])
+def test_sky_pixel_split_does_not_change_results(oracle, monkeypatch, sky, lens):
+    """Pixels no ray of which can reach the scene's bounds are rendered by k_sky_pixels -- all samples of a call at once -- instead of the passes (render.hip:
+    k_split_pixels; on its own only for calls of 2^27 camera paths and more).  Forced here for small calls: every layer and the sample counts are bit-identical to
+    a context that sends every pixel through the passes (FH_SKY_SPLIT=0) and to the checker, over several calls (progressive accumulation), with a wide lens too
+    (the conservative bound grows with the aperture), and the split really happened (sky_pixel_samples > 0) without one bounds-test violation (fh_sync would raise)."""
+    sc = scenes.triangle_soup(3000, 0.1)
+    cam = F.Camera(origin=(0.4, 0.2, 4.0), fov=1.2, F=lens, focus=4.0, forward=(-0.15, -0.05, -1.0))
+    w, h = 160, 90
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = F.Renderer(0)
+        for k in env:
+            monkeypatch.delenv(k)
+        r.load_scene(sc)
+        r.build_ias()
+        if sky == "hosek":
+            r.set_directional_light((0.0, 0.0, 0.0), scenes.SOUP_SUN, 0.0)
+            r.clear_directional_light()
+            r.load_arhosek_sky(3.0, 0.3)
+        elif sky == "ibl":
+            r.load_ibl(scenes.gradient_ibl(16, 8))
+        r.set_resolution(w, h)
+        return r
+
+    def run(r):
+        L = F.RenderLayer(r, w, h)
+        r.reset_stats()
+        for n in (3, 1, 5):  # three calls: the running means continue where the call before left them
+            r.render(cam, (0.05, 0.1, 0.2), L, n, 5)
+        r.wait_for_completion()
+        out = {name: L.download(name) for name in F.RenderLayer.NAMES}
+        st = r.stats()
+        L.free()
+        r.close()
+        return out, st
+
+    monkeypatch.delenv("FH_SKY_SPLIT", raising=False)  # (the suite may run under either switch: this test sets both itself)
+    monkeypatch.delenv("FH_SKY_SPLIT_MIN_LOG2", raising=False)
+    a, sa = run(make({"FH_SKY_SPLIT_MIN_LOG2": "0"}))
+    b, sb = run(make({"FH_SKY_SPLIT": "0"}))
+    assert sa["sky_pixel_samples"] > 0.2 * 9 * w * h and sb["sky_pixel_samples"] == 0 and sa["paths"] == sb["paths"] == 9 * w * h
+    for name in F.RenderLayer.NAMES:
+        assert np.array_equal(_bits(a[name]), _bits(b[name])), name
+    S = oracle.Scene(sc)
+    if sky == "hosek":
+        S.set_directional_light((0.0, 0.0, 0.0), scenes.SOUP_SUN, 0.0)
+        oracle.lib().orc_set_directional_light(S.h, 0, None, None, C.c_float(0))
+        S.load_arhosek_sky(3.0, 0.3)
+    elif sky == "ibl":
+        S.load_ibl(scenes.gradient_ibl(16, 8))
+    Lo = S.new_layers(w, h)
+    for _ in range(9):
+        S.render(cam.params(), w, h, Lo, 1, 5, bg=(0.05, 0.1, 0.2), n_threads=8)
+    _assert_image_parity(a["beauty"], Lo["beauty"])
 
 
 def test_fused_tail_depth_does_not_change_results(oracle):

@@ -30,7 +30,8 @@ def node8_test(o, inv, origin_words, lo, hi, tmax):
     """o, inv: [n, 3]; origin_words: [n, 3] uint32 (origin float whose low mantissa byte is the scale exponent); lo, hi: [n, 3, 8] uint8; tmax: [n].
     Returns [n, 8] bool."""
     with np.errstate(all="ignore"):
-        tl = np.fmin(tmax, f32(1e30)).astype(f32)
+        tl = np.maximum(tmax.astype(f32).view(np.uint32), f32(1e-12).view(np.uint32)).view(f32)  # unsigned maximum of the bit patterns: a floor for tmax >= +0 only
+        tl = np.fmin(tl, f32(1e30)).astype(f32)
         rt = ((f32(1) / tl).astype(f32) * DOWN).astype(f32)
         i = (inv * rt[:, None]).astype(f32)
         p = origin_words.view(f32)
@@ -112,3 +113,26 @@ def test_negative_limit_flags_nothing_and_empty_slots_are_never_flagged():
     lo[:, :, 3], hi[:, :, 3] = 255, 0  # slot 3 empty everywhere (the builder's inverted box)
     got = node8_test(o, inv, words, lo, hi, np.full(n, 1e9, f32))
     assert not got[:, 3].any()
+
+
+def test_a_best_hit_at_the_origin_still_enters_the_boxes_that_hold_the_origin():
+    """tmax = +0 is a ray whose best hit so far is at its origin (an origin on a triangle).  A second triangle there with a lower face id must still be found, so the boxes
+    that hold the origin must be flagged (the unit has a floor of 1e-12), while boxes that start later are not, a negative limit still flags nothing and a NaN limit still
+    counts as none."""
+    rng = np.random.default_rng(11)
+    n = 50_000
+    o, inv, words, lo, hi = random_cases(rng, n)
+    zero = np.zeros(n, f32)
+    got = node8_test(o, inv, words, lo, hi, zero)
+    p = words.view(f32).astype(np.float64)
+    k = np.ldexp(1.0, (words & np.uint32(0xFF)).astype(np.int64) - 127)
+    blo, bhi = p[:, :, None] + k[:, :, None] * lo.astype(np.float64), p[:, :, None] + k[:, :, None] * hi.astype(np.float64)
+    oo = o.astype(np.float64)[:, :, None]
+    holds = ((blo < oo - 1e-6) & (oo + 1e-6 < bhi)).all(axis=1)   # the origin strictly inside the box
+    assert holds.sum() > 200 and not (holds & ~got).any()
+    a, b = (blo - oo) * inv.astype(np.float64)[:, :, None], (bhi - oo) * inv.astype(np.float64)[:, :, None]
+    later = np.minimum(a, b).max(axis=1) > 1e-6                     # the ray enters the box after t = 1e-6: not a candidate for a hit at t = 0
+    assert not (got & later).any()
+    assert not (node8_test(o, inv, words, lo, hi, np.full(n, -0.5, f32)) & (lo <= hi).any(axis=1)).any()
+    nan = node8_test(o, inv, words, lo, hi, np.full(n, np.nan, f32))
+    assert not (exact_slab(o, inv, words, lo, hi, np.full(n, 1e30, f32), 1e-5) & ~nan).any()

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets it)}
 # Round-3 profile of one configuration on the GPU box (one gpurun call): the bench line, rocprofv3 kernel traces with the passes in flight and serial,
 # and the counter passes (never next to tracing): SQ x2, FETCH_SIZE, WRITE_SIZE + TCC.
 # usage: bash tools/profile_round3.sh <tag> <config> [pmc spp]      -> gpurun_out/<tag>_*      then: python tools/collect_profile3.py <tag> <config> <pmc spp>
