@@ -420,6 +420,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_off("FH_SORT_SMALL", t.sort_small);
     env_off("FH_OVERLAP", t.overlap_secondary);
     env_off("FH_MERGE", t.merge_trace);
+    env_uint("FH_SKY_BLOCKS", 0, 64, t.sky_blocks_per_cu);
     if (const char* e = getenv("FH_POISON")) t.poison_pools = e[0] == '1';
     env_off("FH_SKY_SPLIT", t.sky_split);
     env_uint("FH_SKY_SPLIT_MIN_LOG2", 0, 40, t.sky_split_min_log2);

@@ -77,6 +77,7 @@ struct fh_ctx {
   uint32_t n_refits = 0;
   uint32_t bvh8_depth = 0;            // node LEVELS of the wide tree; a traversal stack needs levels - 1 entries (fh_trace.h: stack_entries_for), of which the streaming kernels keep the first in LDS
   uint32_t occupancy_key = 0xffffffffu, occupancy_blocks = 0, occupancy_blocks_secondary = 0;  // resident workgroups per CU of the streaming kernels, as the runtime reports them (render.hip)
+  uint32_t info_blocks[2] = {0, 0}, info_entries[2] = {0, 0};  // the same two facts for the uninstrumented closest-hit / secondary kernels as last launched (fh_kernel_info)
   uint32_t lds_configured_bytes = 0;  // dynamic-LDS size the traversal kernels were last configured for (render.hip)
   uint32_t stream_lds_entries = 0, stream_lds_entries_secondary = 0;    // stack levels the closest-hit / secondary streaming kernel keeps in LDS (the rest spills to d_stack_spill)
   uint2* d_stack_spill = nullptr;     // [6 launches in flight][entry beyond the LDS part][thread of the launch]
@@ -156,6 +157,7 @@ struct fh_ctx {
     bool overlap_secondary = true;  // FH_OVERLAP=0: single-pass calls keep every launch on one stream
     bool sky_split = true;          // FH_SKY_SPLIT=0: every pixel goes through the passes (no k_sky_pixels)
     uint32_t sky_split_min_log2 = 27; // FH_SKY_SPLIT_MIN_LOG2: a call splits its pixels from 2^n camera paths on (27: 64 spp of a 1080p frame; tests lower it)
+    uint32_t sky_blocks_per_cu = 0; // FH_SKY_BLOCKS: workgroups per CU k_sky_pixels is launched with (grid-stride over the sky pixels); 0 = one thread per pixel
     bool poison_pools = false;      // FH_POISON=1: new path pools are filled with 0xa5 before their first use (tests: nothing may read what nobody wrote)
     bool merge_trace = true;        // FH_MERGE=0: single-pass calls trace secondary rays and the next bounce's closest-hit rays in two launches (two streams) instead of one
     uint32_t shade_stream = 0;      // FH_SHADE_STREAM=1|2 (experiment, profiles/README.md r4): the shade-side launches of a pass on their own stream, 2: of high priority

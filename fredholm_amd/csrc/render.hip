@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(kBlock) k_bump_issued(uint32_t* issued, const 
 struct SplitDev {
   f3 centre;      // bounding sphere of the padded scene bounds, camera space
   float radius;
+  float far;      // distance of the farthest corner of the padded scene bounds from the lens centre
   uint32_t* wave_px; uint32_t* wave_xy; uint32_t* sky_px; uint32_t* sky_xy;
   uint32_t* counters;  // [0] wave pixels, [1] sky pixels, [2] bounds-test violations seen by k_sky_pixels
 };
@@ -266,6 +267,28 @@ __global__ void __launch_bounds__(kBlock) k_split_pixels(FrameDev fr, SplitDev s
       const float q = 1.0f - (m / L) * (m / L);
       const float nearest = d0 * sqrt_cr(fmaxf(q, 0.0f)) - fabsf(fr.cam_lens_radius) - m * fabsf(tau) / L;
       sky = L > 0.0f && q > 0.0f && nearest > sp.radius * 1.001f + 1e-3f * (length(w) + 1.0f);  // (NaN anywhere: not sky)
+      // The sphere is a loose fit of a box (a cube's has 2.4 times its silhouette): a second test, against the bounds themselves.  A ray of the pixel that reaches a point P
+      // of the bounds does so at a parameter |s| <= (|P - A0| + R) / (L - m), and there it is within R + m |s| of the centre line's point at s (above).  So with the bounds
+      // grown by d = R + m (far + R) / (L - m) on every side -- `far` the distance of their farthest corner from the lens centre -- the centre LINE, a rigid transform away
+      // in world space, passes through the grown box whenever any ray of the pixel reaches the bounds; a centre line that misses the grown box makes the pixel sky.
+      if (!sky && L > m * 1.01f) {
+        const float d = (fabsf(fr.cam_lens_radius) + m * (sp.far + fabsf(fr.cam_lens_radius)) / (L - m)) * 1.001f + 1e-3f * (sp.far + 1.0f);
+        const f3 o = xform_point(fr.cam_xf, a0), dir = xform_dir(fr.cam_xf, (1.0f / L) * ab);  // (unit length: the line parameters below are world distances)
+        float tn = -3.0e38f, tf = 3.0e38f;
+        bool miss = false;
+        const float oo[3] = {o.x, o.y, o.z}, dd[3] = {dir.x, dir.y, dir.z}, lo[3] = {fr.scene_lo.x - d, fr.scene_lo.y - d, fr.scene_lo.z - d}, hi[3] = {fr.scene_hi.x + d, fr.scene_hi.y + d, fr.scene_hi.z + d};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (fabsf(dd[a]) < 1e-12f) miss = miss || oo[a] < lo[a] || oo[a] > hi[a];  // parallel to this pair of planes (a NaN compares false: not a miss)
+          else {
+            const float t0 = (lo[a] - oo[a]) / dd[a], t1 = (hi[a] - oo[a]) / dd[a];
+            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+          }
+        }
+        // (the interval is widened by a thousandth of the distances involved: the parameters are quotients of quantities of the scene's size, rounded a few times)
+        miss = miss || tn - 1e-3f * (fabsf(tn) + sp.far) > tf + 1e-3f * (fabsf(tf) + sp.far);
+        sky = miss && dd[0] == dd[0] && dd[1] == dd[1] && dd[2] == dd[2] && d == d;
+      }
       wave = !sky;
     }
     uint32_t* const counters2[2] = {sp.counters, sp.counters + 1};
@@ -1609,8 +1632,8 @@ int kernel_info(fh_ctx* ctx, int which, uint32_t out[6])
   out[0] = (uint32_t)at.numRegs;
   out[1] = (uint32_t)at.sharedSizeBytes;
   out[2] = (uint32_t)at.localSizeBytes;
-  out[3] = which == 0 ? ctx->occupancy_blocks : ctx->occupancy_blocks_secondary;
-  out[4] = which == 0 ? ctx->stream_lds_entries : ctx->stream_lds_entries_secondary;
+  out[3] = ctx->info_blocks[which];
+  out[4] = ctx->info_entries[which];
   out[5] = stack_entries_for(ctx->bvh8_depth);
   return FH_OK;
 }
@@ -1777,6 +1800,16 @@ static int split_pixels(fh_ctx* ctx, const fh_camera* cam, const FrameDev& fr)
   sp.centre = mk3(t[0] * w[0] + t[4] * w[1] + t[8] * w[2], t[1] * w[0] + t[5] * w[1] + t[9] * w[2], t[2] * w[0] + t[6] * w[1] + t[10] * w[2]);  // R^T (C - T)
   const float e[3] = {ctx->scene_hi[0] - ctx->scene_lo[0], ctx->scene_hi[1] - ctx->scene_lo[1], ctx->scene_hi[2] - ctx->scene_lo[2]};
   sp.radius = 0.5f * sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  {
+    const float f = fr.cam_inv_tan, a0w[3] = {t[2] * f + t[3], t[6] * f + t[7], t[10] * f + t[11]};  // the lens centre (0, 0, f) in world space
+    float far2 = 0.0f;
+    for (int k = 0; k < 8; ++k) {
+      float d2 = 0.0f;
+      for (int a = 0; a < 3; ++a) { const float c = ((k >> a) & 1) ? ctx->scene_hi[a] : ctx->scene_lo[a]; d2 += (c - a0w[a]) * (c - a0w[a]); }
+      far2 = fmaxf(far2, d2);
+    }
+    sp.far = sqrtf(far2) * 1.001f;
+  }
   sp.wave_px = ctx->d_split[0]; sp.wave_xy = ctx->d_split[1]; sp.sky_px = ctx->d_split[2]; sp.sky_xy = ctx->d_split[3];
   sp.counters = ctx->d_split_counters;
   FH_HIP(hipMemsetAsync(ctx->d_split_counters, 0, 8, ctx->stream));  // (the violation counter, word 2, keeps counting)
@@ -1921,7 +1954,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (n_sky) {  // the sky pixels of this call, all samples at once, on a stream of their own next to the passes (they share no pixel with them)
     FH_HIP(hipStreamWaitEvent(ctx->sky_stream, ctx->ev_enter, 0));
     Span sp(ctx, ctx->sky_stream, 4);
-    hipLaunchKernelGGL(k_sky_pixels, dim3(grid_for(n_sky)), dim3(kBlock), 0, ctx->sky_stream, fr, L, ctx->d_sample_issued, ctx->d_split[2], ctx->d_split[3], n_sky, n_samples, ctx->d_split_counters + 2);
+    uint32_t sky_grid = grid_for(n_sky);
+    if (ctx->tun.sky_blocks_per_cu && sky_grid > ctx->tun.n_cus * ctx->tun.sky_blocks_per_cu) sky_grid = ctx->tun.n_cus * ctx->tun.sky_blocks_per_cu;
+    hipLaunchKernelGGL(k_sky_pixels, dim3(sky_grid), dim3(kBlock), 0, ctx->sky_stream, fr, L, ctx->d_sample_issued, ctx->d_split[2], ctx->d_split[3], n_sky, n_samples, ctx->d_split_counters + 2);
     ctx->stats.paths += (uint64_t)n_sky * n_samples;
     ctx->stats.sky_pixel_samples += (uint64_t)n_sky * n_samples;
   }
@@ -1977,6 +2012,10 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       pick(false, FH_STREAM_BLOCKS_CLOSEST, ctx->stream_lds_entries, ctx->occupancy_blocks);
       pick(true, sc.n_lights > 0 ? FH_SECONDARY_BLOCKS_HEAVY : (sc.has_alpha ? FH_STREAM_BLOCKS_ALPHA : FH_STREAM_BLOCKS), ctx->stream_lds_entries_secondary, ctx->occupancy_blocks_secondary);
       ctx->occupancy_key = key;
+      if (!count) {  // (what fh_kernel_info reports: the plan of the kernels that render, not of the instrumented variants a counting call has just been launched with)
+        ctx->info_blocks[0] = ctx->occupancy_blocks; ctx->info_blocks[1] = ctx->occupancy_blocks_secondary;
+        ctx->info_entries[0] = ctx->stream_lds_entries; ctx->info_entries[1] = ctx->stream_lds_entries_secondary;
+      }
       if (getenv("FH_DEBUG_BVH"))
         fprintf(stderr, "[trace] stack of %u entries; in LDS: closest %u (%u B + %u B per workgroup, %u resident workgroups per CU), secondary %u (%u B + %u B, %u workgroups)\n", stack_entries,
                 ctx->stream_lds_entries, lds_stack_bytes(ctx->stream_lds_entries), kCoopLdsBytesPerBlock, ctx->occupancy_blocks, ctx->stream_lds_entries_secondary,
