@@ -444,7 +444,13 @@ int fh_ctx_create(int device, fh_ctx** out)
     if (const char* e = getenv("FH_NO_ALPHA")) t.ignore_alpha = e[0] == '1';
     if (const char* e = getenv("FH_FORCE_ALPHA")) t.force_alpha = e[0] == '1';
   }
-  if (hipStreamCreateWithFlags(&ctx->sky_stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+  {  // the sky-pixel kernel's stream has the lowest priority: its workgroups -- pure arithmetic, 110 registers -- take what the passes leave instead of the wave slots the
+     // traversal launches want (FH_SKY_PRIO=0: default priority; profiles/README.md r4-13)
+    int least = 0, greatest = 0;
+    const char* e = getenv("FH_SKY_PRIO");
+    const bool low = !(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+    if ((low ? hipStreamCreateWithPriority(&ctx->sky_stream, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&ctx->sky_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate failed");
+  }
   (void)hipEventCreateWithFlags(&ctx->ev_sky, hipEventDisableTiming);
   if (hipMalloc((void**)&ctx->d_split_counters, 16) != hipSuccess) return bail("hipMalloc failed");
   (void)hipMemsetAsync(ctx->d_split_counters, 0, 16, ctx->stream);

@@ -109,13 +109,18 @@ FH_D f3 env_radiance(const FrameDev& fr, f3 d)
 
 // sample n_spp of pixel (px, py): CMJ slots 0 / 1 -> thin-lens camera ray (pt.cu:433-454, camera.cu:24-53) and the Russian roulette of bounce 0, which has probability 1 but
 // still consumes (and can fail on) a draw (pt.cu:457-461).  Returns whether the path is alive.
+FH_D bool camera_ray(const FrameDev& fr, const uint32_t* sobol_dim1, uint32_t image_idx, uint32_t px, uint32_t py, uint32_t n_spp, f2 u, f2 u_lens, f3& org, f3& dir);
 FH_D bool camera_sample(const FrameDev& fr, const uint32_t* sobol_dim1, uint32_t image_idx, uint32_t px, uint32_t py, uint32_t n_spp, f3& org, f3& dir)
 {
-  f2 u = cmj_draw(n_spp, image_idx, 0u, fr.seed_hash);
+  return camera_ray(fr, sobol_dim1, image_idx, px, py, n_spp, cmj_draw(n_spp, image_idx, 0u, fr.seed_hash), cmj_draw(n_spp, image_idx, 1u, fr.seed_hash), org, dir);
+}
+// (u, u_lens: CMJ slots 0 and 1 of the sample)
+FH_D bool camera_ray(const FrameDev& fr, const uint32_t* sobol_dim1, uint32_t image_idx, uint32_t px, uint32_t py, uint32_t n_spp, f2 u, f2 u_lens, f3& org, f3& dir)
+{
   float uvx = (2.0f * (px + u.x) - fr.width) / fr.height;
   const float uvy = (2.0f * (py + u.y) - fr.height) / fr.height;
   uvx = -uvx;
-  u = cmj_draw(n_spp, image_idx, 1u, fr.seed_hash);
+  u = u_lens;
   // thin lens (camera.cu:24-53); a + b and the lens radius are the same for every ray: computed once on the host, in fp32 with the reference's operations
   const float f = fr.cam_inv_tan;
   const f3 p_sensor = mk3(uvx, uvy, 0.0f);
@@ -319,9 +324,17 @@ __global__ void __launch_bounds__(kBlock) k_sky_pixels(FrameDev fr, LayersDev la
     const float4 tc4 = layers.texcoord[image_idx];
     float tcx = tc4.x, tcy = tc4.y;
     bool violated = false;
+    uint32_t blk = 0xffffffffu;  // sixteen consecutive samples share most of their two CMJ draws (fh_sampler.h: cmj_block)
+    CmjBlock b0{}, b1{};
     for (uint32_t k = 0; k < n_samples; ++k) {
       f3 org, dir;
-      const bool alive = camera_sample(fr, rows.m[0], image_idx, xy & 0xffffu, xy >> 16, first + k, org, dir);
+      const uint32_t n = first + k;
+      if ((n >> 4) != blk) {
+        blk = n >> 4;
+        b0 = cmj_block(blk, image_idx, 0u, fr.seed_hash);
+        b1 = cmj_block(blk, image_idx, 1u, fr.seed_hash);
+      }
+      const bool alive = camera_ray(fr, rows.m[0], image_idx, xy & 0xffffu, xy >> 16, n, cmj_draw_in_block(b0, n), cmj_draw_in_block(b1, n), org, dir);
       RayPre rp;
       rp.o = org;
       rp.inv = safe_reciprocal(dir);
