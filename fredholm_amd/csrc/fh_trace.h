@@ -367,9 +367,6 @@ FH_D void node8_eval(const Ray8& r, uint32_t ni, const uint4 n0, const uint4 n1,
   group = make_uint2(n0.w >> 8, (octant_permute(hm & imask, r.oct) << 24) | imask);
   tg = make_uint2(8u * ni, hm & ~imask);
 }
-#ifndef FH_NODE_PREFETCH
-#define FH_NODE_PREFETCH 0  // (experiment, profiles/README.md r4-17)
-#endif
 #ifndef FH_ANYHIT_UNORDERED
 #define FH_ANYHIT_UNORDERED 0  // (experiment: a streaming launch whose rays ALL stop at their first hit visits the children in slot order and saves the octant permutation)
 #endif
@@ -744,9 +741,6 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   uint32_t q_head = 0, q_count = 0;  // wave-uniform
   bool dry = false;                  // wave-uniform: a refill found no work at all
   uint32_t ray_n0 = 0;               // instrumented build: node counter when the lane's ray started
-#if FH_NODE_PREFETCH
-  uint32_t pf_val = 0u, pf_acc = 0u;
-#endif
   cl.key[lane] = 0ull;
   for (;;) {
     const unsigned long long idle = __ballot(!busy);
@@ -837,17 +831,6 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       const uint32_t ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
       node8_visit<ordered>(bvh, r, ni, best_t, group, tg);
-#if FH_NODE_PREFETCH
-      // (experiment: the node this lane visits NEXT is known here when the ray entered an inner child -- the same selection as above, on the new group; touching its line now
-      // puts the hand-over and the triangle tests below between the request and the four loads of the next visit)
-      if (group.y & 0xff000000u) {
-        const uint32_t nbit = 31u - (uint32_t)__clz((int)group.y);
-        const uint32_t nslot = ordered ? (nbit - 24u) ^ r.oct : nbit - 24u;
-        const uint32_t nni = group.x + (uint32_t)__popc(group.y & ~(0xffffffffu << nslot));
-        pf_acc ^= pf_val;
-        pf_val = *(const volatile uint32_t*)((const char*)bvh.nodes + ((size_t)nni << 6));
-      }
-#endif
     }
 #endif
     if (FH_HANDOVER_SCAN && (!ALPHA || FH_HANDOVER_SCAN_ALPHA)) {
@@ -897,9 +880,6 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       q_count = 0u;
     }
   }
-#if FH_NODE_PREFETCH
-  if ((pf_acc ^ pf_val) == 0x9e3779b9u && bvh.n_nodes == 0xffffffffu) cl.key[lane] = 1ull;  // (never true: keeps the touched words alive)
-#endif
 }
 
 template <bool ANY_HIT, bool COUNT>

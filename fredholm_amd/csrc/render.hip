@@ -1964,12 +1964,14 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   FH_HIP(hipEventRecord(ctx->ev_enter, ctx->stream));
   for (int k = 0; k + 1 < ctx->n_slots; ++k) FH_HIP(hipStreamWaitEvent(ctx->aux_stream[k], ctx->ev_enter, 0));
   int last_slot = 0;
+  // (FH_FLAG_SERIAL_PASSES: in line on the main stream, so that every kernel of the call is alone on the GPU and the spans add up)
+  hipStream_t sky_st = (ctx->flags & FH_FLAG_SERIAL_PASSES) != 0 ? ctx->stream : ctx->sky_stream;
   if (n_sky) {  // the sky pixels of this call, all samples at once, on a stream of their own next to the passes (they share no pixel with them)
-    FH_HIP(hipStreamWaitEvent(ctx->sky_stream, ctx->ev_enter, 0));
-    Span sp(ctx, ctx->sky_stream, 4);
+    if (sky_st != ctx->stream) FH_HIP(hipStreamWaitEvent(sky_st, ctx->ev_enter, 0));
+    Span sp(ctx, sky_st, 4);
     uint32_t sky_grid = grid_for(n_sky);
     if (ctx->tun.sky_blocks_per_cu && sky_grid > ctx->tun.n_cus * ctx->tun.sky_blocks_per_cu) sky_grid = ctx->tun.n_cus * ctx->tun.sky_blocks_per_cu;
-    hipLaunchKernelGGL(k_sky_pixels, dim3(sky_grid), dim3(kBlock), 0, ctx->sky_stream, fr, L, ctx->d_sample_issued, ctx->d_split[2], ctx->d_split[3], n_sky, n_samples, ctx->d_split_counters + 2);
+    hipLaunchKernelGGL(k_sky_pixels, dim3(sky_grid), dim3(kBlock), 0, sky_st, fr, L, ctx->d_sample_issued, ctx->d_split[2], ctx->d_split[3], n_sky, n_samples, ctx->d_split_counters + 2);
     ctx->stats.paths += (uint64_t)n_sky * n_samples;
     ctx->stats.sky_pixel_samples += (uint64_t)n_sky * n_samples;
   }
@@ -2281,7 +2283,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   // join: later work on the main stream (pack, post-process, copies, the caller's clears) sees every pass of this call
   // (the accumulates form a chain across the streams, so the last one implies all the others)
   if (last_slot != 0 && n_px) FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_acc[last_slot], 0));
-  if (n_sky) { FH_HIP(hipEventRecord(ctx->ev_sky, ctx->sky_stream)); FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_sky, 0)); }
+  if (n_sky && sky_st != ctx->stream) { FH_HIP(hipEventRecord(ctx->ev_sky, sky_st)); FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_sky, 0)); }
   FH_HIP(hipGetLastError());
   return FH_OK;
 }
