@@ -1964,8 +1964,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   FH_HIP(hipEventRecord(ctx->ev_enter, ctx->stream));
   for (int k = 0; k + 1 < ctx->n_slots; ++k) FH_HIP(hipStreamWaitEvent(ctx->aux_stream[k], ctx->ev_enter, 0));
   int last_slot = 0;
-  // (FH_FLAG_SERIAL_PASSES: in line on the main stream, so that every kernel of the call is alone on the GPU and the spans add up)
-  hipStream_t sky_st = (ctx->flags & FH_FLAG_SERIAL_PASSES) != 0 ? ctx->stream : ctx->sky_stream;
+  // (FH_FLAG_SERIAL_PASSES and FH_PIPELINE=0, the measuring modes: in line on the main stream, so that every kernel of the call is alone on the GPU, the spans add up and
+  // a serial kernel trace shows the kernel's work instead of the time a starved background kernel was resident)
+  hipStream_t sky_st = ((ctx->flags & FH_FLAG_SERIAL_PASSES) != 0 || ctx->n_slots == 1) ? ctx->stream : ctx->sky_stream;
   if (n_sky) {  // the sky pixels of this call, all samples at once, on a stream of their own next to the passes (they share no pixel with them)
     if (sky_st != ctx->stream) FH_HIP(hipStreamWaitEvent(sky_st, ctx->ev_enter, 0));
     Span sp(ctx, sky_st, 4);
