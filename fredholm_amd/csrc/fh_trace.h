@@ -116,18 +116,25 @@ __device__ __attribute__((noinline)) bool alpha_pass(const SceneDev& sc, uint32_
 {
   // one 64-byte record per face (capi.hip: rebuild_device_scene): texture coordinates of the three vertices + the textures that can actually cut
   // (a texture whose every texel is opaque is not listed: a filtered fetch of it cannot come out below 0.5)
+#if defined(FH_ALPHA_STUB) && FH_ALPHA_STUB == 1
+  return true;  // (measurement only: the kernels with the any-hit test compiled in, every candidate accepted without a look at its texture)
+#endif
   const uint4* r = sc.alpha_rec + 4 * (size_t)prim;
-  const uint4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+  const uint4 q0 = r[0], q1 = r[1], q2 = r[2];  // (the alpha texture's entry, r[3], is read where a face has one: most cut-outs sit in the base colour's alpha)
   const float bw = 1.0f - bu - bv;
   const float tu = bw * __uint_as_float(q0.x) + bu * __uint_as_float(q0.z) + bv * __uint_as_float(q1.x);
   const float tv = bw * __uint_as_float(q0.y) + bu * __uint_as_float(q0.w) + bv * __uint_as_float(q1.y);
   const uint32_t flags = q1.z;
   if (flags & 1u) {  // alpha of the base-colour texture
-    const uint8_t* tex = (const uint8_t*)(uintptr_t)(((unsigned long long)q2.y << 32) | q2.x);
+    const uint8_t* tex = (const uint8_t*)(const __attribute__((address_space(1))) uint8_t*)(uintptr_t)(((unsigned long long)q2.y << 32) | q2.x);  // (a pointer into global memory: four global loads instead of flat ones)
+#if defined(FH_ALPHA_STUB) && FH_ALPHA_STUB == 2
+    { const float a = fht_tex2d_channel8(tex, q2.z, q2.w, nullptr, 3u, tu, tv); asm volatile("" ::"v"(a)); return true; }  // (measurement only: the whole fetch, every candidate accepted)
+#endif
     if (fht_tex2d_channel8(tex, q2.z, q2.w, nullptr, 3u, tu, tv) < 0.5f) return false;
   }
   if (flags & 2u) {  // red of the alpha texture
-    const uint8_t* tex = (const uint8_t*)(uintptr_t)(((unsigned long long)q3.y << 32) | q3.x);
+    const uint4 q3 = r[3];
+    const uint8_t* tex = (const uint8_t*)(const __attribute__((address_space(1))) uint8_t*)(uintptr_t)(((unsigned long long)q3.y << 32) | q3.x);
     if (fht_tex2d_channel8(tex, q3.z, q3.w, (flags & 4u) ? sc.srgb_lut : nullptr, 0u, tu, tv) < 0.5f) return false;
   }
   return true;
@@ -531,7 +538,32 @@ struct CoopLds {            // per-wave slices of the block's LDS
   unsigned long long* key;  // [64]
   float2* uv;               // [64]
   uint32_t* queue;          // [kCoopQueue]
+  uint4* aring = nullptr;   // [kAlphaRing] candidates waiting for their any-hit test + one counter word behind them (streaming kernels of scenes with cut-outs, alpha_ring)
 };
+// Pending any-hit tests (scenes with cut-outs, streaming kernels).  A candidate on a face that can cut needs alpha_pass -- a 64-byte record, four texels, ~200 instructions --
+// before it may be committed, and inside coop_test a wave runs all of that for the two or three of its 64 lanes whose candidate is such a face, round after round (the Sponza-class
+// scene: 520 VALU instructions per wave-level node visit against 250 without cut-outs).  So those lanes only park (owner lane, face, t, u, v) in a per-wave ring and go on; the
+// ring is worked off by as many lanes as it holds entries -- when it fills up, once it holds kAlphaFlush of them, and always before a finished ray is committed.  What a ray
+// ends up with is the minimum over the same accepted candidates as before (a parked candidate only keeps the ray's limit and its first-hit stop from taking effect a few visits
+// earlier): the bits do not change.
+#ifndef FH_ALPHA_FLUSH
+#define FH_ALPHA_FLUSH 16
+#endif
+#ifndef FH_ALPHA_DEFER_MIXED
+#define FH_ALPHA_DEFER_MIXED 0  // (1, measured: park candidates in the kernels whose rays stop at their first hit as well)
+#endif
+constexpr uint32_t kAlphaRing = 32, kAlphaFlush = FH_ALPHA_FLUSH;
+// which streaming kernels park: the closest-hit launch.  A ray that stops at its first hit (every secondary ray of a scene without emitters) is finished by the first candidate
+// that passes, and parked it goes on walking the tree until the ring is worked off: secondary 760 -> 835 ms per 512 spp of configs[3] with parking, closest 357 -> 329
+template <bool MIXED, bool ALPHA>
+struct AlphaDefer { static constexpr bool value = ALPHA && (!MIXED || FH_ALPHA_DEFER_MIXED != 0); };
+constexpr uint32_t kAlphaLdsBytesPerWave = kAlphaRing * 16 + 16;
+constexpr uint32_t kAlphaLdsBytesPerBlock = 4u * kAlphaLdsBytesPerWave;
+FH_D void alpha_ring(CoopLds& cl, unsigned char* block_lds, uint32_t wave_in_block)
+{
+  cl.aring = (uint4*)(block_lds + (size_t)wave_in_block * kAlphaLdsBytesPerWave);
+  if (__lane_id() == 0u) *(uint32_t*)(cl.aring + kAlphaRing) = 0u;
+}
 constexpr uint32_t kCoopLdsBytesPerWave = 64 * 32 + 64 * 8 + 64 * 8 + kCoopQueue * 4;
 // static LDS of one 256-thread workgroup of a cooperative / streaming traversal kernel (the stack comes on top, dynamically)
 constexpr uint32_t kCoopLdsBytesPerBlock = 4u * kCoopLdsBytesPerWave;
@@ -547,7 +579,7 @@ FH_D CoopLds coop_lds(unsigned char* block_lds, uint32_t wave_in_block)
 }
 
 // one queued candidate: test triangle (e >> 6) against the ray of lane (e & 63), commit into that lane's LDS record
-template <bool ANY_HIT, bool COUNT, bool ALPHA>
+template <bool ANY_HIT, bool COUNT, bool ALPHA, bool DEFER = false>
 FH_D void coop_test(const Bvh8Dev& bvh, const CoopLds& cl, uint32_t e, uint32_t& n_tris, WaveSteps* ws, const SceneDev* sc)
 {
   const uint32_t owner = e & 63u;
@@ -566,9 +598,36 @@ FH_D void coop_test(const Bvh8Dev& bvh, const CoopLds& cl, uint32_t e, uint32_t&
   const uint32_t prim = __float_as_uint(a.w);
   const unsigned long long mine = ((unsigned long long)__float_as_uint(t) << 32) | prim;
   if (mine >= cl.key[owner]) return;  // also rejects t > tmax: the record starts at (tmax, 0xffffffff)
-  if (ALPHA && bb.w != 0.0f && !alpha_pass(*sc, prim, bu, bv)) return;
+  if (ALPHA && bb.w != 0.0f) {
+    if (DEFER) {  // park it (above); a full ring: test in place (face ids stay below 2^26: the builder refuses trees of 2^23 nodes)
+      const uint32_t pos = atomicAdd((uint32_t*)(cl.aring + kAlphaRing), 1u);
+      if (pos < kAlphaRing) { cl.aring[pos] = make_uint4((owner << 26) | prim, __float_as_uint(t), __float_as_uint(bu), __float_as_uint(bv)); return; }
+    }
+    if (!alpha_pass(*sc, prim, bu, bv)) return;
+  }
   atomicMin(&cl.key[owner], mine);
   if (cl.key[owner] == mine) cl.uv[owner] = make_float2(bu, bv);
+}
+// work the ring off (all 64 lanes of the wave call together); `at_least`: only if it holds that many entries
+template <bool ANY_HIT>
+FH_D void alpha_flush(const CoopLds& cl, const SceneDev* sc, uint32_t at_least)
+{
+  uint32_t* const counter = (uint32_t*)(cl.aring + kAlphaRing);
+  uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)*counter);
+  if (n < at_least || n == 0u) return;
+  n = n < kAlphaRing ? n : kAlphaRing;  // (lanes that found the ring full tested in place and left the counter above its size)
+  if (__lane_id() < n) {
+    const uint4 q = cl.aring[__lane_id()];
+    const uint32_t owner = q.x >> 26, prim = q.x & 0x03ffffffu;
+    const unsigned long long mine = ((unsigned long long)q.y << 32) | prim;
+    const unsigned long long k = cl.key[owner];
+    const bool stopped = ANY_HIT && cl.ray[64 + owner].w != 0.0f && (uint32_t)k != 0xffffffffu;
+    if (!stopped && mine < k && alpha_pass(*sc, prim, __uint_as_float(q.z), __uint_as_float(q.w))) {
+      atomicMin(&cl.key[owner], mine);
+      if (cl.key[owner] == mine) cl.uv[owner] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
+    }
+  }
+  if (__lane_id() == 0u) *counter = 0u;
 }
 
 // MODE 0: every ray wants its closest hit; 1: every ray stops at its first hit; 2: per lane (`any_lane`), as in the streaming kernels
@@ -749,10 +808,11 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       // every candidate of a finished ray must be tested before the ray is committed: drain the queue
       while (q_count) {
         const uint32_t n = q_count < 64u ? q_count : 64u;
-        if (lane < n) coop_test<MIXED, COUNT, ALPHA>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
+        if (lane < n) coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
         q_head = (q_head + n) & (kCoopQueue - 1u);
         q_count -= n;
       }
+      if (AlphaDefer<MIXED, ALPHA>::value) alpha_flush<MIXED>(cl, sc, 1u);  // ... and every parked candidate decided
       if (have && !busy) {
         const unsigned long long k = cl.key[lane];
         const float2 uv = cl.uv[lane];
@@ -850,7 +910,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       }
       q_count += total;
       while (q_count >= 64u) {
-        coop_test<MIXED, COUNT, ALPHA>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
+        coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
         q_head = (q_head + 64u) & (kCoopQueue - 1u);
         q_count -= 64u;
       }
@@ -868,17 +928,18 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       }
       q_count += (uint32_t)__popcll(m);
       if (q_count >= 64u) {
-        coop_test<MIXED, COUNT, ALPHA>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
+        coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
         q_head = (q_head + 64u) & (kCoopQueue - 1u);
         q_count -= 64u;
       }
     }
     if (q_count >= flush) {
       const uint32_t n = q_count;  // < 64 here
-      if (lane < n) coop_test<MIXED, COUNT, ALPHA>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
+      if (lane < n) coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
       q_head = (q_head + n) & (kCoopQueue - 1u);
       q_count = 0u;
     }
+    if (AlphaDefer<MIXED, ALPHA>::value) alpha_flush<MIXED>(cl, sc, kAlphaFlush);
   }
 }
 

@@ -466,6 +466,17 @@ FH_D uint32_t stream_chunk_for(uint32_t count, uint32_t chunk)
 // be, and in-wave refill keeps their lanes busy.  Big launches are untouched (every workgroup takes part from 6144 x min_rays entries on).
 FH_D bool stream_block_idle(uint32_t count, uint32_t min_rays) { return blockIdx.x != 0u && (unsigned long long)blockIdx.x * (kBlock / 64u) * min_rays >= count; }
 
+template <bool ALPHA>
+struct AlphaLds { static FH_D void attach(CoopLds&) {} };
+template <>
+struct AlphaLds<true> {
+  static FH_D void attach(CoopLds& cl)
+  {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_alpha[kAlphaLdsBytesPerBlock];
+    alpha_ring(cl, lds_alpha, threadIdx.x >> 6);
+  }
+};
+
 template <bool COUNT>
 struct ClosestStream {
   static constexpr bool all_any = false;
@@ -504,7 +515,8 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : FH_STREAM_BLOCKS_CLOSEST) 
   const uint32_t count = pool.counters[depth * kCounterStride + CNT_RAD];
   if (stream_block_idle(count, min_rays)) return;
   const ClockStamp stamp;
-  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  AlphaLds<AlphaDefer<false, ALPHA>::value>::attach(cl);  // candidates waiting for their any-hit test (fh_trace.h: alpha_ring): LDS of the kernels with the test compiled in only
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, stream_chunk_for(count, chunk)), tc.hist);
@@ -1227,7 +1239,8 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
   __shared__ HosekSky s_sky;  // (light rays that escape see the sky: resolve_light_ray)
   if (LIGHTS) { stage_sky(fr, s_sky); __syncthreads(); }
   const ClockStamp stamp;
-  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  AlphaLds<AlphaDefer<true, ALPHA>::value>::attach(cl);  // candidates waiting for their any-hit test (fh_trace.h: alpha_ring): LDS of the kernels with the test compiled in only
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)), tc.hist);
@@ -1292,7 +1305,8 @@ __global__ void __launch_bounds__(kBlock, LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : (
   __shared__ HosekSky s_sky;
   if (LIGHTS) { stage_sky(fr, s_sky); __syncthreads(); }
   const ClockStamp stamp;
-  const CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  CoopLds cl = coop_lds(lds, threadIdx.x >> 6);
+  AlphaLds<AlphaDefer<true, ALPHA>::value>::attach(cl);  // candidates waiting for their any-hit test (fh_trace.h: alpha_ring): LDS of the kernels with the test compiled in only
   uint32_t nn = 0, nt = 0;
   MergedStream<LIGHTS> pol(sc, fr, ps, pn, pn.q_rad[(depth + 1u) & 1u], n_sec, ChunkFeed(ps.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)));
   traverse_stream<true, false, true, ALPHA>(sc.bvh8, pol, nn, nt, nullptr, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill);
@@ -1993,6 +2007,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (sc.use_bvh8 && stack_bytes + ctx->lds_static_max > tun.lds_per_block) return fail(ctx, FH_E_UNSUPPORTED, "fh_render: BVH too deep for the LDS traversal stack");
   // all workgroups of a streaming launch are resident: as many per CU as its LDS (160 KB on gfx950) holds (at most 6: the kernels' register budget)
   const uint32_t stack_entries = stack_entries_for(ctx->bvh8_depth);
+  // static LDS of a streaming kernel's workgroup: the cooperative-test records and, where candidates are parked for their any-hit test (AlphaDefer), the ring
+  const uint32_t static_lds_closest = kCoopLdsBytesPerBlock + (sc.has_alpha && AlphaDefer<false, true>::value ? kAlphaLdsBytesPerBlock : 0u);
+  const uint32_t static_lds_secondary = kCoopLdsBytesPerBlock + (sc.has_alpha && AlphaDefer<true, true>::value ? kAlphaLdsBytesPerBlock : 0u);
   if (stream) {  // what the runtime says really fits (LDS granularity, registers of the variant in use): a grid above it would leave blocks queued behind the resident ones
     const uint32_t key = stack_bytes | (count ? 1u : 0u) | (sc.has_alpha ? 2u : 0u) | (sc.n_lights > 0 ? 4u : 0u) | (tun.stack_lds_entries << 20);
     if (ctx->occupancy_key != key) {
@@ -2012,7 +2029,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       // the deeper levels, which are rarely reached, to global memory (GroupStack<true>).  FH_STACK_LDS=n fixes the number for both, FH_STACK_LDS=99 keeps everything in LDS.
       auto pick = [&](bool secondary, uint32_t blocks_wanted, uint32_t& entries_out, uint32_t& blocks_out) {
         const uint32_t lds_share = tun.lds_per_cu / blocks_wanted;
-        const uint32_t fit = lds_share > kCoopLdsBytesPerBlock + 1280u ? (lds_share - kCoopLdsBytesPerBlock) / 1280u : 1u;
+        const uint32_t static_lds = secondary ? static_lds_secondary : static_lds_closest;
+        const uint32_t fit = lds_share > static_lds + 1280u ? (lds_share - static_lds) / 1280u : 1u;
         const uint32_t floor_entries = fit < 8u ? fit : 8u;
         uint32_t entries = stack_entries;
         int got = occupancy(secondary, entries);
@@ -2034,21 +2052,21 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       }
       if (getenv("FH_DEBUG_BVH"))
         fprintf(stderr, "[trace] stack of %u entries; in LDS: closest %u (%u B + %u B per workgroup, %u resident workgroups per CU), secondary %u (%u B + %u B, %u workgroups)\n", stack_entries,
-                ctx->stream_lds_entries, lds_stack_bytes(ctx->stream_lds_entries), kCoopLdsBytesPerBlock, ctx->occupancy_blocks, ctx->stream_lds_entries_secondary,
-                lds_stack_bytes(ctx->stream_lds_entries_secondary), kCoopLdsBytesPerBlock, ctx->occupancy_blocks_secondary);
+                ctx->stream_lds_entries, lds_stack_bytes(ctx->stream_lds_entries), static_lds_closest, ctx->occupancy_blocks, ctx->stream_lds_entries_secondary,
+                lds_stack_bytes(ctx->stream_lds_entries_secondary), static_lds_secondary, ctx->occupancy_blocks_secondary);
     }
   }
   const uint32_t stream_entries = stream ? ctx->stream_lds_entries : stack_entries, stream_entries_secondary = stream ? ctx->stream_lds_entries_secondary : stack_entries;
   const uint32_t stream_stack_bytes = lds_stack_bytes(stream_entries), stream_stack_bytes_secondary = lds_stack_bytes(stream_entries_secondary);
-  auto wgs_for = [&](uint32_t bytes, uint32_t compiled_for, uint32_t reported) {
-    uint32_t w = tun.lds_per_cu / (bytes + kCoopLdsBytesPerBlock);
+  auto wgs_for = [&](uint32_t bytes, uint32_t static_lds, uint32_t compiled_for, uint32_t reported) {
+    uint32_t w = tun.lds_per_cu / (bytes + static_lds);
     w = w > compiled_for ? compiled_for : (w < 1u ? 1u : w);
     if (stream && reported && reported < w) w = reported;
     if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < w) w = tun.stream_wgs_per_cu;
     return w;
   };
-  const uint32_t wgs_closest = wgs_for(stream_stack_bytes, FH_STREAM_BLOCKS_CLOSEST, ctx->occupancy_blocks);
-  const uint32_t wgs_secondary = wgs_for(stream_stack_bytes_secondary, FH_STREAM_BLOCKS > FH_SECONDARY_BLOCKS_HEAVY ? FH_STREAM_BLOCKS : FH_SECONDARY_BLOCKS_HEAVY, ctx->occupancy_blocks_secondary);
+  const uint32_t wgs_closest = wgs_for(stream_stack_bytes, static_lds_closest, FH_STREAM_BLOCKS_CLOSEST, ctx->occupancy_blocks);
+  const uint32_t wgs_secondary = wgs_for(stream_stack_bytes_secondary, static_lds_secondary, FH_STREAM_BLOCKS > FH_SECONDARY_BLOCKS_HEAVY ? FH_STREAM_BLOCKS : FH_SECONDARY_BLOCKS_HEAVY, ctx->occupancy_blocks_secondary);
   const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_closest;
   const uint32_t stream_grid_secondary = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_secondary;
   // spill area of the streaming launches: [launch in flight: pass slot x (closest, secondary)][entry beyond the LDS part][thread of the launch]
