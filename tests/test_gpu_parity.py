@@ -921,6 +921,37 @@ def test_textured_scene_matches_checker(oracle):
     r.close()
 
 
+def test_many_cut_out_layers_fill_the_ring_of_parked_any_hit_tests(oracle, monkeypatch):
+    """The closest-hit launch of the streaming kernels parks candidates on cut-out faces in a 32-entry ring per wave and works the ring off in one go (fh_trace.h:
+    alpha_ring / alpha_flush): at 16 entries, when it is full -- a lane that finds it full tests in place -- and before a finished ray is committed.  Ninety-six
+    layers of cut-out cards between the camera and the back wall (two textures: the cut-out in the base colour's alpha, and in an alpha texture) make nearly every
+    candidate of a wave such a face, so all three triggers and the in-place path run; images and AOVs against the checker, whose any-hit test runs per candidate."""
+    monkeypatch.setenv("FH_STREAM", "1")  # (the ring belongs to the streaming kernels; the fixed-batch kernels of so small a tree test in place)
+    base = scenes.textured_cornell_box()
+    nm = base["materials"].shape[0]
+    layers = []
+    rng = np.random.default_rng(5)
+    for k in range(96):
+        z = -0.9 + 1.7 * k / 95.0
+        x0, y0 = rng.uniform(-0.9, -0.2), rng.uniform(0.1, 0.6)
+        x1, y1 = x0 + rng.uniform(0.6, 1.0), y0 + rng.uniform(0.6, 1.0)
+        layers += [[x0, y0, z], [x1, y0, z], [x1, y1, z], [x0, y0, z], [x1, y1, z], [x0, y1, z]]
+    quads = np.asarray(layers, np.float32)
+    sc = dict(base)
+    nv = base["vertices"].shape[0]
+    sc["vertices"] = np.concatenate([base["vertices"], quads])
+    sc["normals"] = np.concatenate([base["normals"], np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (quads.shape[0], 1))])
+    uv = rng.uniform(-1.5, 2.5, (quads.shape[0], 2)).astype(np.float32)
+    sc["texcoords"] = np.concatenate([base["texcoords"], uv])
+    sc["indices"] = np.concatenate([base["indices"], (nv + np.arange(quads.shape[0], dtype=np.uint32)).reshape(-1, 3)])
+    # the two cut-out materials of the base scene are its last two (base-colour alpha, alpha texture)
+    sc["material_ids"] = np.concatenate([base["material_ids"], np.array([nm - 2, nm - 2, nm - 1, nm - 1] * 48, np.uint32)])
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    gpu, ref = _render_pair(oracle, sc, cam, 72, 54, launches=2, spp_per_launch=2, depth=4)
+    for name in F.RenderLayer.NAMES:
+        _assert_image_parity(gpu[name], ref[name])
+
+
 def test_wild_texture_coordinates_on_opaque_textures_still_take_the_any_hit_test(oracle):
     """Faces whose textures cannot cut (every texel opaque) skip the any-hit test -- unless a texture coordinate is NaN, infinite or about to overflow: the
     texture unit fetches 0 there and the reference's any-hit program discards the hit (pt.cu:545-678).  Same hits and same images as the checker."""
