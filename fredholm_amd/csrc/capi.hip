@@ -339,7 +339,7 @@ uint64_t pool_bytes_per_path(const fh_ctx* ctx)
 {
   const uint32_t sec = 2u + (ctx->has_dir ? 1u : 0u) + (ctx->n_lights > 0 ? 1u : 0u);
   const uint32_t classes = ctx->n_classes < 1u ? 1u : ctx->n_classes;
-  return 64u + 16u + 8u + 4u + 64u + 48u * sec + (ctx->n_lights > 0 ? 32u : 0u) + 20u + 4u + 4u * classes;
+  return 64u + 16u + 8u + 4u + 64u + 48u * sec + (ctx->n_lights > 0 ? 32u : 0u) + 20u + 4u + 4u + 4u * classes;  // (... + queue keys and sorted queues 20, q_sec 4, q_prim 4, class queues)
 }
 }  // namespace fh
 

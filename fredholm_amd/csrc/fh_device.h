@@ -132,6 +132,8 @@ struct PoolDev {
   uint32_t* q_rad[2];            // radiance-ray queue, ping-pong per bounce
   uint32_t* q_cls;               // (shading classes of the scene) x capacity: hits routed by shading class
   uint32_t* q_sec;               // shaded paths with secondary rays
+  uint32_t* q_prim;              // face id of the closest hit of radiance-queue ENTRY i of the bounce being traced (0xffffffff: miss), written next to pool.hit by whoever traces
+                                 // entry i: k_route then reads queue and face ids as two streams instead of one 64-byte path record per ray for four of its bytes
   uint32_t* counters;            // kCounterStride words per bounce, zeroed once per pass
   // spatial ordering of the bounce queues (render.hip: sort_queue_by_cell): the shade kernel stores the cell of the hit point next
   // to every queue entry it appends; a counting sort brings entries of one cell together before the rays are traced

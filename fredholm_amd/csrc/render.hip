@@ -142,7 +142,7 @@ FH_D bool camera_ray(const FrameDev& fr, const uint32_t* sobol_dim1, uint32_t im
 // grid: x over the owned pixels (grid-stride), y = sample of the pass -- slot p = sample * n_owned + pixel without a division per path, and the pixel's
 // coordinates come packed from the ownership list instead of from image_idx / width and % width (four integer divisions by run-time values were ~60 of the
 // kernel's ~1070 non-FMA instructions per path)
-constexpr int kGenChunks = 4;
+constexpr int kGenChunks = 4;  // (eight measure the same: profiles/README.md r4-20)
 __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, const uint32_t* issued, const uint32_t* owned, const uint32_t* owned_xy, uint32_t n_owned)
 {
   __shared__ SobolRows<1> rows;
@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_static(SceneDev sc, Po
     else traverse_bvh2<false, COUNT, ALPHA>(sc.bvh2, mk3(o), mk3(d), o.w, h, nn, nt, &sc);
     if (COUNT) { const uint32_t k = nn - nn0; int b = 0; while (b < 7 && k > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
     pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+    pool.q_prim[i] = h.prim;
   }
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
@@ -418,7 +419,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_coop(SceneDev sc, Pool
     const uint32_t nn0 = nn;
     traverse_bvh8_coop<false, COUNT, true, ALPHA>(sc.bvh8, valid, mk3(o), mk3(d), o.w, h, nn, nt, &ws, cl, flush, lds_stack, (int)sc.bvh8.depth, &sc);
     if (COUNT && valid) { const uint32_t k = nn - nn0; int b = 0; while (b < 7 && k > (8u << b)) ++b; atomicAdd(tc.hist + b, 1ull); }
-    if (valid) pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+    if (valid) { pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)); pool.q_prim[i] = h.prim; }
   }
   if (COUNT) {
     atomicAdd(tc.nodes, (unsigned long long)nn);
@@ -483,7 +484,7 @@ struct ClosestStream {
   const PoolDev& pool;
   const uint32_t* q;
   ChunkFeed feed;
-  uint32_t p = 0;
+  uint32_t p = 0, qi = 0;  // path slot and queue entry of the lane's ray
   uint32_t n_rays = 0;
   unsigned long long* hist;
   HistPack hp;
@@ -493,6 +494,7 @@ struct ClosestStream {
   {
     if (i >= feed.end) return false;
     p = q[i];
+    qi = i;
     const float4 o4 = pool.ray_o[p], d4 = pool.ray_d[p];
     o = mk3(o4); d = mk3(d4); tmax = o4.w; any = false;
     if (COUNT) n_rays++;
@@ -501,6 +503,7 @@ struct ClosestStream {
   FH_D void commit(bool, const HitRec& h, uint32_t nodes)
   {
     pool.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+    pool.q_prim[qi] = h.prim;
     if (COUNT) hp.add(nodes);
   }
   FH_D bool drained() const { return feed.drained(); }
@@ -536,37 +539,48 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : FH_STREAM_BLOCKS_CLOSEST) 
 // ------------------------------------------------------------------------------------------------
 // Sort the hits of this bounce into per-class queues.  Appends are aggregated per block: wave
 // ballot + popcount, a prefix over the block's waves in LDS, one atomic per block and class.
+constexpr int kRouteChunks = 8;
 __global__ void __launch_bounds__(kBlock) k_route(SceneDev sc, PoolDev pool, uint32_t depth, uint32_t n_classes, unsigned long long* hit_counter)
 {
-  __shared__ uint32_t wave_cnt[kMaxClasses][kBlock / 64];
+  // A workgroup takes kRouteChunks x 256 consecutive entries per round and reserves its part of every class queue with ONE returning atomic per class: a class counter is one
+  // address, the chip serves ~85 M returning atomics per address and second, and with 256 entries per atomic the 357 M closest hits of a configs[2] frame were 1.4 M atomics per
+  // counter -- 16.4 ms of the kernel's 16.6 (profiles/README.md r4-20)
+  __shared__ uint32_t wave_cnt[kMaxClasses][kRouteChunks * (kBlock / 64)];
   __shared__ uint32_t block_base[kMaxClasses];
   uint32_t* cnt = pool.counters + depth * kCounterStride;
   const uint32_t count = cnt[CNT_RAD];
   const uint32_t* q = pool.q_rad[depth & 1u];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
-    const uint32_t i = base + threadIdx.x;
-    uint32_t p = 0, cls = 0xffu;
-    if (i < count) {
-      p = q[i];
-      const uint32_t prim = __float_as_uint(pool.hit[p].w);
-      if (prim != 0xffffffffu) cls = sc.face_cls[prim] & 0x3fu;
+  for (uint32_t base = blockIdx.x * blockDim.x * kRouteChunks; base < count; base += gridDim.x * blockDim.x * kRouteChunks) {
+    uint32_t p[kRouteChunks], cls[kRouteChunks], rank[kRouteChunks];
+#pragma unroll
+    for (int c = 0; c < kRouteChunks; ++c) {
+      const uint32_t i = base + (uint32_t)c * blockDim.x + threadIdx.x;
+      p[c] = 0u; cls[c] = 0xffu; rank[c] = 0u;
+      if (i < count) {
+        p[c] = q[i];
+        const uint32_t prim = pool.q_prim[i];  // (= the face id bits of pool.hit[p].w, from a stream)
+        if (prim != 0xffffffffu) cls[c] = sc.face_cls[prim] & 0x3fu;
+      }
     }
-    uint32_t my_rank = 0;
-    for (uint32_t c = 0; c < n_classes; ++c) {
-      const unsigned long long m = __ballot(cls == c);
-      if (lane == 0) wave_cnt[c][wave] = (uint32_t)__popcll(m);
-      if (cls == c) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    }
+#pragma unroll
+    for (int c = 0; c < kRouteChunks; ++c)
+      for (uint32_t k = 0; k < n_classes; ++k) {
+        const unsigned long long m = __ballot(cls[c] == k);
+        if (lane == 0) wave_cnt[k][c * (kBlock / 64) + wave] = (uint32_t)__popcll(m);
+        if (cls[c] == k) rank[c] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      }
     __syncthreads();
     if (threadIdx.x < n_classes) {
       uint32_t total = 0;
-      for (uint32_t w = 0; w < kBlock / 64; ++w) { const uint32_t v = wave_cnt[threadIdx.x][w]; wave_cnt[threadIdx.x][w] = total; total += v; }
+      for (uint32_t w = 0; w < kRouteChunks * (kBlock / 64); ++w) { const uint32_t v = wave_cnt[threadIdx.x][w]; wave_cnt[threadIdx.x][w] = total; total += v; }
       block_base[threadIdx.x] = total ? atomicAdd(&cnt[CNT_CLS + threadIdx.x], total) : 0u;
       if (hit_counter && total) atomicAdd(hit_counter, (unsigned long long)total);  // instrumented runs: surface hits that get shaded
     }
     __syncthreads();
-    if (cls < n_classes) pool.q_cls[(size_t)cls * pool.capacity + block_base[cls] + wave_cnt[cls][wave] + my_rank] = p;
+#pragma unroll
+    for (int c = 0; c < kRouteChunks; ++c)
+      if (cls[c] < n_classes) pool.q_cls[(size_t)cls[c] * pool.capacity + block_base[cls[c]] + wave_cnt[cls[c]][c * (kBlock / 64) + wave] + rank[c]] = p[c];
     __syncthreads();
   }
 }
@@ -581,8 +595,8 @@ __global__ void __launch_bounds__(kBlock) k_miss_primary(FrameDev fr, PoolDev po
   const uint32_t count = pool.counters[CNT_RAD];
   const uint32_t* q = pool.q_rad[0];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    if (pool.q_prim[i] != 0xffffffffu) continue;  // (the closest hit's face id of queue entry i, as k_route reads it: no path record is touched for a ray that hit)
     const uint32_t p = q[i];
-    if (__float_as_uint(pool.hit[p].w) != 0xffffffffu) continue;
     if (pool.flags[p] & 4u) continue;  // bug-compat mode: an earlier sample of this launch already hit something (k_firsthit_scan)
     const f3 T = mk3(pool.thr[p]);
     const f3 d = mk3(pool.ray_d[p]);
@@ -1270,7 +1284,7 @@ struct MergedStream {
   const uint32_t* q_closest;
   uint32_t n_sec;
   ChunkFeed feed;
-  uint32_t pc = 0;
+  uint32_t pc = 0, qc = 0;    // path slot and entry (in the next bounce's radiance queue) of the lane's closest-hit ray
   bool closest = false;       // the lane's current item is a closest-hit ray
   FH_D MergedStream(const SceneDev& s, const FrameDev& f, const PoolDev& ps, const PoolDev& pn, const uint32_t* qc, uint32_t ns, const ChunkFeed& cf)
       : sec(s, f, ps, cf, nullptr), next(pn), q_closest(qc), n_sec(ns), feed(cf) {}
@@ -1280,14 +1294,15 @@ struct MergedStream {
     if (i >= feed.end) return false;
     if (i < n_sec) { closest = false; return sec.take_item(i, o, d, tmax, any); }
     closest = true;
-    pc = q_closest[i - n_sec];
+    qc = i - n_sec;
+    pc = q_closest[qc];
     const float4 o4 = next.ray_o[pc], d4 = next.ray_d[pc];
     o = mk3(o4); d = mk3(d4); tmax = o4.w; any = false;
     return true;
   }
   FH_D void commit(bool hit, const HitRec& h, uint32_t nodes)
   {
-    if (closest) next.hit[pc] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+    if (closest) { next.hit[pc] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)); next.q_prim[qc] = h.prim; }
     else sec.commit(hit, h, nodes);
   }
   FH_D bool drained() const { return feed.drained(); }
@@ -1727,7 +1742,7 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
     P.pixel.base = ident; P.nspp.base = ident + 1;
     P.aov_position.base = aov; P.aov_normal.base = aov + 1; P.aov_albedo.base = aov + 2; P.aov_texdepth.base = aov + 3;
     P.lp_a.base = lp; P.lp_b.base = lp ? lp + 1 : nullptr;
-    FH_POOL(P.q_rad[0], n); FH_POOL(P.q_rad[1], n); FH_POOL(P.q_cls, n * need.classes); FH_POOL(P.q_sec, n);
+    FH_POOL(P.q_rad[0], n); FH_POOL(P.q_rad[1], n); FH_POOL(P.q_cls, n * need.classes); FH_POOL(P.q_sec, n); FH_POOL(P.q_prim, n);
     FH_POOL(P.counters, (size_t)kCounterStride * 66);  // up to 65 bounces per pass
     FH_POOL(P.key_sec, n); FH_POOL(P.key_rad, n); FH_POOL(P.q_tmp, n); FH_POOL(P.q_sec_sorted, n);
     FH_POOL(P.bins, (size_t)2 * kCells);
