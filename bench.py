@@ -265,19 +265,38 @@ def latency_block(r, w, cam, layers, frames=(200, 100)):
     return out
 
 
-def pmc_file(cfg, pool_spp, width, height):
-    """newest committed counter summary for this configuration AND launch size (separate rocprofv3 --pmc passes, tools/profile_round3.sh): counters cannot be read
-    from inside this process, and per-launch counts only describe launches of the samples per pass they were collected with"""
+def pass_size_differs(pmc_k, spp, n_passes, steps):
+    """the counters of a launch belong to one pass size: samples per pass as the library SUBMITTED them (a call that splits off its sky pixels cuts itself into other passes
+    than the nominal pool size says) in the counter run against this run; None when the file does not say"""
+    then = pmc_k.get("submitted_spp_per_pass")
+    now = spp / max(n_passes / max(steps, 1), 1e-9)
+    if not then:
+        return None
+    return {"then": then, "now": round(now, 2)} if abs(then - now) > 0.02 * now else False
+
+
+def pmc_file(cfg, pool_spp, width, height, submitted=None):
+    """committed counter summary for this configuration AND launch size (separate rocprofv3 --pmc passes, tools/profile_round3.sh): counters cannot be read from inside
+    this process, and per-launch counts only describe launches of the pass size they were collected with.  `submitted` = samples per pass as the library cut this run (spp per
+    step / passes per step): the file whose counter run submitted the nearest pass size is taken (pass_size_differs then says whether it is near enough); without it, or for
+    files that do not say what they submitted, the nominal samples per pass of the pools have to be equal."""
     import glob
+    best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
         try:
             tj = json.load(open(f))
         except Exception:
             continue
-        if tj.get("config", 2) == cfg and tj.get("spp_per_pass", 128 if cfg == 2 else None) == pool_spp:
-            tj["file"] = os.path.relpath(f, ROOT)
+        if tj.get("config", 2) != cfg:
+            continue
+        tj["file"] = os.path.relpath(f, ROOT)
+        if submitted and tj.get("submitted_spp_per_pass"):
+            d = abs(tj["submitted_spp_per_pass"] - submitted)
+            if best is None or d < best[0]:
+                best = (d, tj)
+        elif not submitted and tj.get("spp_per_pass", 128 if cfg == 2 else None) == pool_spp:
             return tj
-    return None
+    return best[1] if best else None
 
 
 def pass_size(r, torch, local_rank, n_owned, spp, pool_spp_arg=0):
@@ -352,7 +371,7 @@ def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1):
     key = max(fam, key=lambda k: fam[k]["alone"])
     f = fam[key]
     launches = max(f["launches"], 1)
-    pmc = pmc_file(3, pool_spp, W, H)
+    pmc = pmc_file(3, pool_spp, W, H, submitted=spp / max(timed["n_passes"] / max(steps, 1), 1e-9))
     pmc_k = pmc if (pmc and pmc.get("kernel", "").startswith(f["kernel"])) else None
     roof = traversal_roofline(cnt, timed, key, steps, launches, f["ms"] / launches, f["alone"] / max(launches / steps, 1), f["bytes"] * steps / launches, f["kernel"], "whole frame", bw,
                               pmc_k.get("traffic_bytes_per_launch") if pmc_k else None)
@@ -360,6 +379,10 @@ def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1):
     if pmc_k:
         roof["counters_from"] = pmc_k.get("file")
         roof["counters_stale"] = not (pmc_k.get("source_fingerprint") == source_fingerprint())
+        differs = pass_size_differs(pmc_k, spp, timed["n_passes"], steps)
+        if differs:
+            roof["counters_stale"] = True
+            roof["counters_pass_size"] = differs
         if pmc_k.get("traffic_bytes_per_launch") and f["alone"] > 0:
             roof["frac_hbm_measured"] = round(pmc_k["traffic_bytes_per_launch"] / (f["alone"] / max(launches / steps, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     paths = max(cnt["paths"], 1)
@@ -598,7 +621,7 @@ def main():
         avg_ms = f["ms"] / launches
         avg_alone_ms = f["alone"] / max(launches / steps, 1)
         alg_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        pmc = pmc_file(args.config, pool_spp, WIDTH, HEIGHT) if world == 1 else None  # (a shard's launches are not the launches the counters saw)
+        pmc = pmc_file(args.config, pool_spp, WIDTH, HEIGHT, submitted=spp / max(timed["n_passes"] / max(steps, 1), 1e-9)) if world == 1 else None  # (a shard's launches are not the launches the counters saw)
         pmc_k = pmc if (pmc and pmc.get("kernel", "").startswith(dom)) else None  # the dominant kernel's own counters
         traffic = pmc_k.get("traffic_bytes_per_launch") if pmc_k else None
         kernel_name = dom.replace("_stream", "_coop") if dom.startswith("k_trace") and small_tree else dom
@@ -651,6 +674,10 @@ def main():
             then = {"source_fingerprint": pmc_k.get("source_fingerprint"), "kernel_info": pmc_k.get("kernel_info")}
             same_kernel = then["kernel_info"] is None or now["kernel_info"] is None or all(then["kernel_info"].get(k) == now["kernel_info"].get(k) for k in ("vgprs", "static_lds_bytes", "scratch_bytes"))
             roof["counters_stale"] = not (then["source_fingerprint"] == now["source_fingerprint"] and same_kernel)
+            differs = pass_size_differs(pmc_k, spp, timed["n_passes"], steps)
+            if differs:  # (the launches the counters describe are not the launches of this run)
+                roof["counters_stale"] = True
+                roof["counters_pass_size"] = differs
             roof["counters_built_from"] = {"git_head": pmc_k.get("git_head"), "source_fingerprint": then["source_fingerprint"], "this_run": now["source_fingerprint"]}
         sec = lambda k: fam[k]["alone"] * 1e-3  # seconds per step with the kernel alone on the GPU
         rates = {"closest_hit_grays_per_s": round(cnt["rays_closest"] / sec("k_trace_closest_stream") / 1e9, 3) if sec("k_trace_closest_stream") > 0 else None,

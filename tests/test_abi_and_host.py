@@ -814,6 +814,32 @@ def test_counter_files_and_issue_model_are_tied_to_the_sources(tmp_path, monkeyp
     assert im["node"] == bench.NODE_TEST_SIMD_CYCLES and im["stale"] is True
 
 
+def test_counters_of_another_pass_size_are_flagged():
+    """The counters of a launch belong to one pass size.  A call that splits off its sky pixels cuts itself into other passes than the nominal pool size says (configs[2]:
+    three passes of 342 samples of the pixels that see the scene, whatever `spp_per_pass` is), so the counter files also record the pass the library SUBMITTED in the counter
+    run (`submitted_spp_per_pass`) and bench.py marks the line `counters_stale` when this run's passes differ by more than 2 %."""
+    sys.path.insert(0, ROOT)
+    import glob
+    import json
+    import bench
+
+    assert bench.pass_size_differs({}, 1024, 3, 1) is None                                      # an old file: no statement
+    assert bench.pass_size_differs({"submitted_spp_per_pass": 342.0}, 1024, 3, 1) is False      # 341.3 against 342
+    assert bench.pass_size_differs({"submitted_spp_per_pass": 342.0}, 1024, 60, 20) is False    # ... over 20 steps
+    d = bench.pass_size_differs({"submitted_spp_per_pass": 384.0}, 1024, 3, 1)
+    assert d == {"then": 384.0, "now": 341.33}
+    # this round's files say what was submitted, and the default runs of configs[2] and of the general_scene leg find a file of their pass size
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_*_traffic_config*.json")))
+    assert files and all(json.load(open(f)).get("submitted_spp_per_pass") for f in files)
+    subs = {(json.load(open(f))["config"], round(json.load(open(f))["submitted_spp_per_pass"])) for f in files}
+    assert (2, 342) in subs and (3, 103) in subs
+    # the file is chosen by the pass the run submitted, not by the nominal pool size: configs[2]'s default run (1024 spp in three passes) takes the 342-sample set
+    got = bench.pmc_file(2, 999, 1920, 1080, submitted=1024 / 3)
+    assert got and round(got["submitted_spp_per_pass"]) == 342 and bench.pass_size_differs(got, 1024, 3, 1) is False
+    got = bench.pmc_file(3, 999, 1920, 1080, submitted=512 / 5)
+    assert got and round(got["submitted_spp_per_pass"]) == 103
+
+
 def test_committed_issue_model_file_is_well_formed():
     sys.path.insert(0, ROOT)
     import glob

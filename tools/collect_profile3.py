@@ -36,9 +36,12 @@ except Exception as e:
     print("no vector-memory passes:", e)
 renders = 4  # --warmup 1 --steps 1 + the serial step + the counting replay
 pmc_line = [ln for ln in open(f"gpurun_out/{tag}_sqa.log") if ln.startswith("{")][-1]
-pmc_pass_spp = json.loads(pmc_line)["config"]["spp_per_pass"]  # the launch size the counters belong to: bench.py quotes them only for runs with the same samples per pass
+pmc_cfg = json.loads(pmc_line)["config"]
+pmc_pass_spp = pmc_cfg["spp_per_pass"]  # the nominal launch size the counters belong to: bench.py quotes them only for runs with the same samples per pass
+# ... and the pass the library really submitted in the counter run (a call that splits off its sky pixels cuts itself differently): bench.py flags a run whose passes differ
+pmc_submitted = round(pmc_cfg["spp_per_step"] / max(pmc_cfg.get("passes_per_step", 0) or 1, 1e-9), 2) if pmc_cfg.get("passes_per_step") else None
 frame = sum((2 * x.get("FETCH_SIZE", (0, 0))[1] + x.get("WRITE_SIZE", (0, 0))[1]) * 1024 for x in ks)
-d = {"kernel": k["name"], "config": cfg, "spp_per_pass": pmc_pass_spp,
+d = {"kernel": k["name"], "config": cfg, "spp_per_pass": pmc_pass_spp, "submitted_spp_per_pass": pmc_submitted,
      "source": f"profiles/{tag}_pmc_summary.txt (tools/profile_round3.sh {tag} {cfg} {pspp}: separate rocprofv3 --pmc passes -- SQ group a, SQ group b, FETCH_SIZE, WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- of "
                f"bench.py --config {cfg} --steps 1 --warmup 1 --spp {pspp} --no-cpu-baseline --no-extras; mean over the {k['dispatches']} dispatches of the kernel)",
      "FETCH_SIZE_KB_per_launch": g("FETCH_SIZE"), "WRITE_SIZE_KB_per_launch": g("WRITE_SIZE"),

@@ -6,7 +6,7 @@
 tag=${1:-r03_x}; cfg=${2:-2}; pspp=${3:-384}; only=${4:-all}   # (4th argument "l1": only the vector-memory passes)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-B="python3 $R/bench.py --config $cfg"
+B="python3 $R/bench.py --config $cfg ${FH_BENCH_EXTRA:-}"   # (FH_BENCH_EXTRA="--pool-spp 86": pools of the default run's size for counter passes of ONE of its passes)
 if [ "$only" = all ]; then
 $B > $R/gpurun_out/${tag}_bench.json 2> $R/gpurun_out/${tag}_bench.err; echo "bench rc=$?"
 S="--steps 2 --warmup 1 --no-cpu-baseline --no-extras"
