@@ -7,13 +7,21 @@ import fredholm_amd as F
 from fredholm_amd import scenes
 N = int(os.environ.get("SOAK_FRAMES", "150"))
 CITY = os.environ.get("SCENE", "soup") == "city"
-r = F.Renderer(0); r.load_scene(scenes.city(80000) if CITY else scenes.triangle_soup(1_000_000)); r.build_ias()
+SPONZA = os.environ.get("SCENE", "soup") == "sponza"  # the Sponza-class interior of configs[3]: cut-outs (parked any-hit tests), textures, a 15-level tree (spilled stack)
+if SPONZA:
+    import tempfile
+    import bench
+    with tempfile.TemporaryDirectory() as td:
+        wl = bench.workload(3, td)
+        r = F.Renderer(0); r.load_scene(wl["scene"]); r.build_ias()
+else:
+    r = F.Renderer(0); r.load_scene(scenes.city(80000) if CITY else scenes.triangle_soup(1_000_000)); r.build_ias()
 r.set_directional_light((0, 0, 0), scenes.SOUP_SUN, 0.0); r.clear_directional_light(); r.load_arhosek_sky(3.0, 0.3)
 W, H = 1920, 1080
 r.set_resolution(W, H)
 r.set_path_pool(W * H * 8)   # 4 passes of 8 spp per frame: both streams and both pools busy
 L = F.RenderLayer(r, W, H)
-cam = F.Camera(**(scenes.CITY_CAMERA if CITY else scenes.SOUP_CAMERA))
+cam = F.Camera(**(wl["camera"] if SPONZA else (scenes.CITY_CAMERA if CITY else scenes.SOUP_CAMERA)))
 ref = None
 t0 = time.perf_counter()
 for k in range(N):
