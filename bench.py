@@ -1,4 +1,3 @@
-    # path-pool slots = owned pixels x samples per pass, one pool per pass in flight (pass_size above)
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the path-tracing hot path on MI355X (BASELINE.json metric).
 
@@ -108,7 +107,7 @@ def traversal_roofline(cnt, timed, key, steps, launches, avg_ms, avg_alone_ms, b
                             "wave_tri_tests_per_launch": int(wt * steps / launches), "source": im["source"], "stale": im["stale"]},
             "lane_utilisation": {"node_tests": round(nodes / max(64 * wn, 1), 4), "triangle_tests": round(tris / max(64 * wt, 1), 4)},
             "per_ray": {"nodes": round(nodes / max(rays, 1), 2), "triangles": round(tris / max(rays, 1), 2), "bytes": round(bytes_per_launch * launches / steps / max(rays, 1), 1)},
-            "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_gbs": round(alg_gbs, 1), "frac_algorithmic_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 5),
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_gbs": round(alg_gbs, 1), "algorithmic_gbs_over_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 5),
             "measured_hbm_gbs": {"read": round(bw_read, 1), "copy": round(bw_copy, 1)},
             "note": where + "; achieved = (wave-level node tests x %g + wave-level triangle tests x %g SIMD cycles)" % (im["node"], im["tri"]) + " per launch / launch time measured inside the timed region, where passes on the other "
                     "streams share the GPU with the launch; *_alone: the same launch with the GPU to itself (one untimed step with serial passes); algorithmic_* = SURVEY.md 8(d) bytes per ray x rays, "
@@ -275,13 +274,10 @@ def pass_size_differs(pmc_k, spp, n_passes, steps):
     return {"then": then, "now": round(now, 2)} if abs(then - now) > 0.02 * now else False
 
 
-def pmc_file(cfg, pool_spp, width, height, submitted=None):
-    """committed counter summary for this configuration AND launch size (separate rocprofv3 --pmc passes, tools/profile_round3.sh): counters cannot be read from inside
-    this process, and per-launch counts only describe launches of the pass size they were collected with.  `submitted` = samples per pass as the library cut this run (spp per
-    step / passes per step): the file whose counter run submitted the nearest pass size is taken (pass_size_differs then says whether it is near enough); without it, or for
-    files that do not say what they submitted, the nominal samples per pass of the pools have to be equal."""
+def counter_files(cfg):
+    """committed counter summaries of this configuration, newest first (separate rocprofv3 --pmc passes, tools/profile_round3.sh: counters cannot be read from inside this process)"""
     import glob
-    best = None
+    out = []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
         try:
             tj = json.load(open(f))
@@ -290,13 +286,45 @@ def pmc_file(cfg, pool_spp, width, height, submitted=None):
         if tj.get("config", 2) != cfg:
             continue
         tj["file"] = os.path.relpath(f, ROOT)
-        if submitted and tj.get("submitted_spp_per_pass"):
-            d = abs(tj["submitted_spp_per_pass"] - submitted)
-            if best is None or d < best[0]:
-                best = (d, tj)
-        elif not submitted and tj.get("spp_per_pass", 128 if cfg == 2 else None) == pool_spp:
-            return tj
-    return best[1] if best else None
+        out.append(tj)
+    return out
+
+
+def usable_counters(cfg, kernel, spp, n_passes, steps):
+    """Per-launch counters describe launches of ONE pass size.  A counter file is USED only when it is about `kernel` and the pass its counter run submitted
+    (`submitted_spp_per_pass`) is within 2 % of the pass this run submitted (pass_size_differs(...) is False).  Anything else -- another pass size, a file that does not say
+    what it submitted -- is refused: the line then carries NO counter-derived field (traffic, frac_hbm_measured, valu, vl1d, the shade / generate issue fraction) and names what
+    it refused under `counters_unusable`.  Returns (counters or None, counters_unusable or None)."""
+    refused = None
+    for tj in counter_files(cfg):
+        if not tj.get("kernel", "").startswith(kernel):
+            continue
+        differs = pass_size_differs(tj, spp, n_passes, steps)
+        if differs is False:
+            return tj, None
+        if refused is None:
+            now = round(spp / max(n_passes / max(steps, 1), 1e-9), 2)
+            refused = {"file": tj["file"], "then": differs["then"] if differs else None, "now": now,
+                       "why": "samples per pass of the counter run differ from this run's by more than 2 %" if differs else "the file does not say which pass size its counter run submitted"}
+    return None, refused
+
+
+def refuse_bad_fracs(obj, path=""):
+    """A fraction of a roof is in [0, 1].  Any `frac*` field outside (a model priced against the wrong launch, a counter file of another launch size) is NOT printed: it is taken
+    out of the line and listed under `fractions_refused` at the top level, and the run says so on stderr.  Returns the list of (path, value) removed."""
+    bad = []
+    if isinstance(obj, dict):
+        for k in list(obj.keys()):
+            v = obj[k]
+            if isinstance(v, (dict, list)):
+                bad += refuse_bad_fracs(v, f"{path}.{k}" if path else k)
+            elif k.startswith("frac") and isinstance(v, (int, float)) and not isinstance(v, bool) and not (0.0 <= v <= 1.0):
+                bad.append((f"{path}.{k}" if path else k, v))
+                del obj[k]
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            bad += refuse_bad_fracs(v, f"{path}[{i}]")
+    return bad
 
 
 def pass_size(r, torch, local_rank, n_owned, spp, pool_spp_arg=0):
@@ -371,18 +399,15 @@ def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1):
     key = max(fam, key=lambda k: fam[k]["alone"])
     f = fam[key]
     launches = max(f["launches"], 1)
-    pmc = pmc_file(3, pool_spp, W, H, submitted=spp / max(timed["n_passes"] / max(steps, 1), 1e-9))
-    pmc_k = pmc if (pmc and pmc.get("kernel", "").startswith(f["kernel"])) else None
+    pmc_k, unusable = usable_counters(3, f["kernel"], spp, timed["n_passes"], steps)
     roof = traversal_roofline(cnt, timed, key, steps, launches, f["ms"] / launches, f["alone"] / max(launches / steps, 1), f["bytes"] * steps / launches, f["kernel"], "whole frame", bw,
                               pmc_k.get("traffic_bytes_per_launch") if pmc_k else None)
     roof["kernel_info"] = r.kernel_info(0 if key == "closest" else 1)
+    if unusable:
+        roof["counters_unusable"] = unusable
     if pmc_k:
         roof["counters_from"] = pmc_k.get("file")
         roof["counters_stale"] = not (pmc_k.get("source_fingerprint") == source_fingerprint())
-        differs = pass_size_differs(pmc_k, spp, timed["n_passes"], steps)
-        if differs:
-            roof["counters_stale"] = True
-            roof["counters_pass_size"] = differs
         if pmc_k.get("traffic_bytes_per_launch") and f["alone"] > 0:
             roof["frac_hbm_measured"] = round(pmc_k["traffic_bytes_per_launch"] / (f["alone"] / max(launches / steps, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     paths = max(cnt["paths"], 1)
@@ -621,8 +646,9 @@ def main():
         avg_ms = f["ms"] / launches
         avg_alone_ms = f["alone"] / max(launches / steps, 1)
         alg_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        pmc = pmc_file(args.config, pool_spp, WIDTH, HEIGHT, submitted=spp / max(timed["n_passes"] / max(steps, 1), 1e-9)) if world == 1 else None  # (a shard's launches are not the launches the counters saw)
-        pmc_k = pmc if (pmc and pmc.get("kernel", "").startswith(dom)) else None  # the dominant kernel's own counters
+        # the dominant kernel's own counters, from a counter run of THIS pass size or not at all (a shard's launches are not the launches the counters saw either)
+        pmc_k, unusable = usable_counters(args.config, dom, spp, timed["n_passes"], steps) if world == 1 else (None, None)
+        pmc = pmc_k
         traffic = pmc_k.get("traffic_bytes_per_launch") if pmc_k else None
         kernel_name = dom.replace("_stream", "_coop") if dom.startswith("k_trace") and small_tree else dom
         where = ("rank 0 shard" if world > 1 else "whole frame")
@@ -641,7 +667,7 @@ def main():
                     "frac_alone": round(issue_cycles_per_launch / (avg_alone_ms * 1e-3) / 1e9 / peak, 5) if avg_alone_ms > 0 else None,
                     "issue_model": {"valu_insts_per_launch": pmc_k["valu_insts_per_launch"], "fma_class_share": share, "cycles_per_instruction_of_this_mix": round(cyc, 3),
                                     "source": "SQ_INSTS_VALU of the kernel (" + str(pmc_k.get("file")) + "), class rates from profiles/r03_issue_peak.txt, class share from the code object (tools/isa_stats.py)"},
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_gbs": round(alg_gbs, 1), "frac_algorithmic_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 5),
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_gbs": round(alg_gbs, 1), "algorithmic_gbs_over_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 5),
                     "measured_hbm_gbs": {"read": round(bw_read, 1), "copy": round(bw_copy, 1)},
                     "note": where + "; achieved = executed VALU instructions per launch x issue cycles per instruction of the kernel's mix / launch time inside the timed region (passes on the other streams share the "
                             "GPU with the launch: *_alone is the same launch with the GPU to itself); algorithmic_* = DESIGN.md 4 bytes per hit, for reference"}
@@ -674,11 +700,9 @@ def main():
             then = {"source_fingerprint": pmc_k.get("source_fingerprint"), "kernel_info": pmc_k.get("kernel_info")}
             same_kernel = then["kernel_info"] is None or now["kernel_info"] is None or all(then["kernel_info"].get(k) == now["kernel_info"].get(k) for k in ("vgprs", "static_lds_bytes", "scratch_bytes"))
             roof["counters_stale"] = not (then["source_fingerprint"] == now["source_fingerprint"] and same_kernel)
-            differs = pass_size_differs(pmc_k, spp, timed["n_passes"], steps)
-            if differs:  # (the launches the counters describe are not the launches of this run)
-                roof["counters_stale"] = True
-                roof["counters_pass_size"] = differs
             roof["counters_built_from"] = {"git_head": pmc_k.get("git_head"), "source_fingerprint": then["source_fingerprint"], "this_run": now["source_fingerprint"]}
+        if unusable:
+            roof["counters_unusable"] = unusable
         sec = lambda k: fam[k]["alone"] * 1e-3  # seconds per step with the kernel alone on the GPU
         rates = {"closest_hit_grays_per_s": round(cnt["rays_closest"] / sec("k_trace_closest_stream") / 1e9, 3) if sec("k_trace_closest_stream") > 0 else None,
                  "secondary_grays_per_s": round(cnt["rays_shadow"] / sec("k_trace_secondary_stream") / 1e9, 3) if sec("k_trace_secondary_stream") > 0 else None,
@@ -733,6 +757,13 @@ def main():
             r.close()  # (the headline's path pools go back to the device first)
             r = None
             out["general_scene"] = general_scene_block(local_rank, tmp.name, (bw_read, bw_copy))
+        refused = refuse_bad_fracs(out)
+        if refused:
+            out["fractions_refused"] = [{"field": k, "value": v} for k, v in refused]
+            print("bench.py: refused to print fractions outside [0, 1]: " + ", ".join(f"{k} = {v}" for k, v in refused), file=sys.stderr, flush=True)
+            if "frac" not in out["roofline"]:  # the contract's field: the SURVEY 8(d) view of the same kernel stands in, named as such
+                out["roofline"]["frac"] = min(out["roofline"].get("algorithmic_gbs_over_hbm_peak") or 0.0, 1.0)
+                out["roofline"]["frac_is"] = "algorithmic_gbs_over_hbm_peak (the modelled fraction was refused)"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

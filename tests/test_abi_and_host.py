@@ -757,12 +757,9 @@ def test_every_bench_configuration_has_a_counter_file_the_bench_line_can_quote()
     import bench
 
     for cfg in (1, 2, 3, 4):
-        found = None
-        for spp in range(1, 257):  # whatever pass size the file was collected with
-            found = bench.pmc_file(cfg, spp, 1920, 1080)
-            if found:
-                break
-        assert found, f"no profiles/r*_traffic*.json for configs[{cfg}]"
+        files = [tj for tj in bench.counter_files(cfg) if tj.get("submitted_spp_per_pass")]  # (files that do not say which pass they saw are never used)
+        assert files, f"no profiles/r*_traffic*.json for configs[{cfg}] that says which pass size it was collected with"
+        found = files[0]
         assert os.path.exists(os.path.join(ROOT, found["file"]))
         assert found["kernel"].startswith("k_") and found["traffic_bytes_per_launch"] > 0 and found["valu_insts_per_launch"] > 0
         assert 0.0 < found["valu_lane_utilisation"] <= 1.0 and 0.0 < found["tcc_hit_rate"] <= 1.0
@@ -814,10 +811,11 @@ def test_counter_files_and_issue_model_are_tied_to_the_sources(tmp_path, monkeyp
     assert im["node"] == bench.NODE_TEST_SIMD_CYCLES and im["stale"] is True
 
 
-def test_counters_of_another_pass_size_are_flagged():
+def test_counters_of_another_pass_size_are_refused():
     """The counters of a launch belong to one pass size.  A call that splits off its sky pixels cuts itself into other passes than the nominal pool size says (configs[2]:
-    three passes of 342 samples of the pixels that see the scene, whatever `spp_per_pass` is), so the counter files also record the pass the library SUBMITTED in the counter
-    run (`submitted_spp_per_pass`) and bench.py marks the line `counters_stale` when this run's passes differ by more than 2 %."""
+    three passes of 342 samples of the pixels that see the scene, whatever `spp_per_pass` is), so the counter files record the pass the library SUBMITTED in the counter
+    run (`submitted_spp_per_pass`).  bench.py USES a file only when this run's passes are within 2 % of that; otherwise the line carries no counter-derived field at all and
+    names the refused file under `counters_unusable` (round 4 took the nearest file, priced 85-sample counters against a 2.7-sample launch and printed frac 2.86)."""
     sys.path.insert(0, ROOT)
     import glob
     import json
@@ -828,16 +826,32 @@ def test_counters_of_another_pass_size_are_flagged():
     assert bench.pass_size_differs({"submitted_spp_per_pass": 342.0}, 1024, 60, 20) is False    # ... over 20 steps
     d = bench.pass_size_differs({"submitted_spp_per_pass": 384.0}, 1024, 3, 1)
     assert d == {"then": 384.0, "now": 341.33}
-    # this round's files say what was submitted, and the default runs of configs[2] and of the general_scene leg find a file of their pass size
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_*_traffic_config*.json")))
-    assert files and all(json.load(open(f)).get("submitted_spp_per_pass") for f in files)
-    subs = {(json.load(open(f))["config"], round(json.load(open(f))["submitted_spp_per_pass"])) for f in files}
-    assert (2, 342) in subs and (3, 103) in subs
-    # the file is chosen by the pass the run submitted, not by the nominal pool size: configs[2]'s default run (1024 spp in three passes) takes the 342-sample set
-    got = bench.pmc_file(2, 999, 1920, 1080, submitted=1024 / 3)
-    assert got and round(got["submitted_spp_per_pass"]) == 342 and bench.pass_size_differs(got, 1024, 3, 1) is False
-    got = bench.pmc_file(3, 999, 1920, 1080, submitted=512 / 5)
-    assert got and round(got["submitted_spp_per_pass"]) == 103
+    # the default runs of configs[2] and of the general_scene leg find a file of their pass size ...
+    got, unusable = bench.usable_counters(2, "k_trace_secondary_stream", 1024, 3, 1)
+    assert got and unusable is None and bench.pass_size_differs(got, 1024, 3, 1) is False
+    got, unusable = bench.usable_counters(3, "k_trace_secondary_stream", 512, 5, 1)
+    assert got and unusable is None and abs(got["submitted_spp_per_pass"] - 512 / 5) < 0.02 * 512 / 5
+    # ... the short runs of the bench-contract test (GPUTEST_r04: configs[1] at 8 spp = 3 passes of 2.7, configs[2] at 12 spp = 3 passes of 4) get NOTHING
+    for cfg, kernel, spp in ((1, "k_shade", 8), (2, "k_trace_secondary_stream", 12), (3, "k_trace_secondary_stream", 12)):
+        got, unusable = bench.usable_counters(cfg, kernel, spp, 3, 1)
+        assert got is None and unusable["file"].startswith("profiles/") and unusable["now"] == round(spp / 3, 2) and unusable["then"] > 10 * unusable["now"]
+    # a kernel no file is about: nothing used, nothing refused
+    assert bench.usable_counters(2, "k_no_such_kernel", 1024, 3, 1) == (None, None)
+    # a file that does not say what it submitted is never used
+    old = [tj for tj in bench.counter_files(2) if not tj.get("submitted_spp_per_pass")]
+    assert old, "the round-2 / round-3 files of configs[2] carry no submitted_spp_per_pass"
+    assert all(bench.pass_size_differs(tj, 1024, 3, 1) is None for tj in old)
+
+
+def test_fractions_outside_0_1_are_never_printed():
+    sys.path.insert(0, ROOT)
+    import bench
+    out = {"roofline": {"frac": 2.86412, "frac_alone": 0.4, "valu": {"frac_x": -0.1}, "algorithmic_gbs_over_hbm_peak": 1.03, "frac_none": None}, "general_scene": {"roofline": {"frac_hbm_measured": 1.2, "frac": 0.34}},
+           "list": [{"frac_a": 7.0}], "fraction_of_nothing": 0.5}
+    bad = bench.refuse_bad_fracs(out)
+    assert sorted(k for k, _ in bad) == ["general_scene.roofline.frac_hbm_measured", "list[0].frac_a", "roofline.frac", "roofline.valu.frac_x"]
+    assert out == {"roofline": {"frac_alone": 0.4, "valu": {}, "algorithmic_gbs_over_hbm_peak": 1.03, "frac_none": None}, "general_scene": {"roofline": {"frac": 0.34}}, "list": [{}], "fraction_of_nothing": 0.5}
+    assert bench.refuse_bad_fracs(out) == []
 
 
 def test_committed_issue_model_file_is_well_formed():
