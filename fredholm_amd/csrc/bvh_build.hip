@@ -465,7 +465,7 @@ __global__ void k_cut_tables(int n_leaves, const int2* children, const int* node
 
 __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* children, const int2* ranges, const float4* node_lo, const float4* node_hi, const float4* leaf_lo,
                             const float4* leaf_hi, float pad, uint32_t leaf_max, uint32_t absorb, uint4* nodes, uint32_t* node_counter, uint32_t* tri_counter, uint32_t* tri_slot, Work8* next_items, uint32_t* next_count,
-                            const uint2* decision)
+                            const uint2* decision, uint32_t* wparent)
 {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_items) return;
@@ -594,6 +594,7 @@ __global__ void k_collapse8(const Work8* items, uint32_t n_items, const int2* ch
     if (ref[c] >= 0 && cnt > leaf_max) {
       imask |= 1u << sl;
       next_items[next_base + inner_seen] = Work8{ref[c], child_base + inner_seen};
+      wparent[child_base + inner_seen] = (it.wnode << 3) | (uint32_t)sl;  // the way up (fh_trace.h: bottom-up start of rays that leave a surface)
       inner_seen++;
     } else {
       tri_slot[ref_first(ref[c], ranges)] = 8u * it.wnode + (uint32_t)sl;  // (leaf_max is 1: one triangle per leaf child)
@@ -632,12 +633,14 @@ __global__ void k_collapse8_tiny(int n, const float4* face_lo, const float4* fac
 }
 
 // triangle slots of the wide tree: 8 per node, slot 8 * node + child slot; slots without a triangle hold a degenerate one (all zero, face id 0xffffffff)
-__global__ void k_emit_tris8(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, const uint32_t* tri_slot, uint32_t n, float4* tris, const uint32_t* ref_face)
+__global__ void k_emit_tris8(const float4* face_rec, const uint8_t* face_cls, const uint32_t* sorted_face, const uint32_t* tri_slot, uint32_t n, float4* tris, const uint32_t* ref_face,
+                             uint32_t* face_node, const uint32_t* split_count)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t f = sorted_face[i];
   if (ref_face) f = ref_face[f];
+  if (face_node) face_node[f] = (split_count && split_count[f] > 1u) ? 0u : tri_slot[i] >> 3;  // the wide node that holds the face; a face that entered the build as several references: the root
   const size_t t = 3 * (size_t)tri_slot[i];
   const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
   tris[t] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
@@ -737,6 +740,199 @@ __global__ void k_sah_sum(int n_inner, const float4* node_lo, const float4* node
   if (i < n_inner) a = (double)box_area(node_lo[i], node_hi[i]);
   for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
   if ((threadIdx.x & 63) == 0 && a != 0.0) atomicAdd(sum, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SAH refinement of the binary tree by parallel reinsertion (Meister & Bittner, "Parallel Reinsertion for Bounding Volume
+// Hierarchy Optimization", Eurographics 2018).  The radix tree splits by Morton prefix, PLOC merges greedily; neither looks at
+// the surface-area heuristic the traversal cost follows.  optixAccelBuild, which the reference calls (renderer.h:484-494), is a
+// SAH-class builder; this pass is what brings the tree under the collapse to that class.  Per round:
+//   1. search   every node x (thread per node) looks for the position y where removing x (its parent p disappears, its sibling
+//               takes p's place, the ancestors shrink) and re-attaching it next to y (p becomes the parent of x and y, the
+//               ancestors of y grow) lowers the summed area of the inner nodes the most: a branch-and-bound walk that climbs
+//               from p to the root and, at every ancestor (the pivot), descends into the sibling subtree while
+//               gain so far - growth along the descent - area(x) can still beat the best gain found (parent pointers, no stack);
+//   2. lock     every x with a positive gain writes (gain, x) with atomicMax into every node its move touches: the nodes on the
+//               tree path from x to y below their common ancestor, and p, the grandparent, the sibling and y's parent;
+//   3. apply    an x that still holds all of its locks re-links p between y and y's parent.  Moves with disjoint lock sets touch
+//               disjoint pointers and cannot put a node under itself (a node that became an ancestor of y would lie on the
+//               locked path), so any subset of them leaves a tree; nothing depends on the order they run in;
+//   4. refit    boxes (and leaf counts) bottom up with arrival counters; the sum of the inner-node areas is the objective.
+// Rounds stop when a round gains less than 1 % (FH_SAH_MIN_GAIN) or after FH_SAH_ITERS rounds (default 0 = off until measured).
+// Everything is deterministic (atomicMax of unique keys; unions are order independent).  Hits do not depend on the shape of the
+// tree (fh_trace.h: ties break by face id), so images are bit-identical with and without this pass.
+// Unified node index u: inner nodes 0 .. n_inner-1, leaf i at n_inner + i.  box lo.w / hi.w of an inner node = left / right child.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float area_of(const float4& lo, const float4& hi) { return box_area(lo, hi); }
+__device__ __forceinline__ float union_area(const float4& alo, const float4& ahi, const float4& blo, const float4& bhi)
+{
+  const float ex = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), ey = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y), ez = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
+  return ex * ey + ey * ez + ez * ex;
+}
+
+__global__ void k_ri_init(int n_inner, int n_leaves, int root, const int2* children, const float4* node_lo, const float4* node_hi, const float4* leaf_lo, const float4* leaf_hi,
+                          float4* ulo, float4* uhi, int* upar)
+{
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_inner + n_leaves) return;
+  if (u < n_inner) {
+    const int2 ch = children[u];
+    const int l = ch.x >= 0 ? ch.x : n_inner + ~ch.x, r = ch.y >= 0 ? ch.y : n_inner + ~ch.y;
+    float4 lo = node_lo[u], hi = node_hi[u];
+    lo.w = __int_as_float(l); hi.w = __int_as_float(r);
+    ulo[u] = lo; uhi[u] = hi;
+    upar[l] = u; upar[r] = u;
+    if (u == root) upar[u] = -1;
+  } else {
+    float4 lo = leaf_lo[u - n_inner], hi = leaf_hi[u - n_inner];
+    lo.w = __int_as_float(-1); hi.w = __int_as_float(-1);
+    ulo[u] = lo; uhi[u] = hi;
+  }
+}
+
+// best re-insertion position of every node: out_gain[u] > 0, out_y[u] = the node x is to become the sibling of, out_c[u] = the pivot (common ancestor) it was found under
+__global__ void k_ri_search(int n_total, int n_inner, int root, const float4* __restrict__ ulo, const float4* __restrict__ uhi, const int* __restrict__ upar, float* out_gain, int* out_y,
+                            int* out_c, int max_visits, float min_gain)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n_total) return;
+  float best = min_gain;
+  int best_y = -1, best_c = -1;
+  const int p = x == root ? -1 : upar[x];
+  if (p >= 0 && p != root) {
+    const float4 xlo = ulo[x], xhi = uhi[x];
+    const float ax = area_of(xlo, xhi);
+    float d_up = area_of(ulo[p], uhi[p]);  // what the removal has gained below the current pivot: area(p) + the shrinkage of the ancestors passed
+    float4 rlo = make_float4(3e38f, 3e38f, 3e38f, 0.0f), rhi = make_float4(-3e38f, -3e38f, -3e38f, 0.0f);  // box of the current ancestor without x
+    int cur = x, pivot = p, visits = 0;
+    while (pivot >= 0) {
+      const int left = __float_as_int(ulo[pivot].w), right = __float_as_int(uhi[pivot].w);
+      const int sib = left == cur ? right : left;
+      // ---- candidates in the subtree of sib; c = growth of the nodes between sib and the candidate's parent (inclusive) if x goes below them
+      int z = sib;
+      float c = 0.0f;
+      bool down = true;
+      for (;;) {
+        if (down) {
+          const float4 zlo = ulo[z], zhi = uhi[z];
+          ++visits;
+          const float m = union_area(zlo, zhi, xlo, xhi);
+          if (!(pivot == p && z == sib)) {  // (next to its own sibling is where x is)
+            const float g = d_up - c - m;
+            if (g > best) { best = g; best_y = z; best_c = pivot; }
+          }
+          const float inc = m - area_of(zlo, zhi);
+          if (z < n_inner && d_up - (c + inc) - ax > best && visits < max_visits) { c += inc; z = __float_as_int(zlo.w); continue; }
+          down = false;
+        }
+        if (z == sib) break;
+        const int pz = upar[z];
+        const float4 plo = ulo[pz], phi = uhi[pz];
+        if (__float_as_int(plo.w) == z) { z = __float_as_int(phi.w); down = true; }
+        else { z = pz; c -= union_area(plo, phi, xlo, xhi) - area_of(plo, phi); }
+      }
+      // ---- one level up: the pivot shrinks to the union of the siblings passed so far
+      const float4 slo = ulo[sib], shi = uhi[sib];
+      rlo = make_float4(fminf(rlo.x, slo.x), fminf(rlo.y, slo.y), fminf(rlo.z, slo.z), 0.0f);
+      rhi = make_float4(fmaxf(rhi.x, shi.x), fmaxf(rhi.y, shi.y), fmaxf(rhi.z, shi.z), 0.0f);
+      if (pivot != p) {
+        d_up += area_of(ulo[pivot], uhi[pivot]) - area_of(rlo, rhi);
+        if (pivot != root) {  // next to the shrunken ancestor itself (the root stays the root)
+          const float g = d_up - union_area(rlo, rhi, xlo, xhi);
+          if (g > best) { best = g; best_y = pivot; best_c = upar[pivot]; }
+        }
+      }
+      if (visits >= max_visits) break;
+      cur = pivot;
+      pivot = upar[pivot];
+    }
+  }
+  out_gain[x] = best_y >= 0 ? best : 0.0f;
+  out_y[x] = best_y;
+  out_c[x] = best_c;
+}
+
+// the nodes a move of x next to y touches; F(node) returns false to stop
+template <class F>
+__device__ __forceinline__ bool ri_for_lock_set(int x, int y, int c, const float4* ulo, const float4* uhi, const int* upar, F f)
+{
+  const int p = upar[x], g = upar[p];
+  const int s = __float_as_int(ulo[p].w) == x ? __float_as_int(uhi[p].w) : __float_as_int(ulo[p].w);
+  if (!f(p) || !f(g) || !f(s) || !f(upar[y])) return false;
+  for (int z = x, guard = 0; z != c && z >= 0 && guard < 4096; z = upar[z], ++guard) if (!f(z)) return false;
+  for (int z = y, guard = 0; z != c && z >= 0 && guard < 4096; z = upar[z], ++guard) if (!f(z)) return false;
+  return true;
+}
+
+__global__ void k_ri_lock(int n_total, const float4* ulo, const float4* uhi, const int* upar, const float* gain, const int* ys, const int* cs, unsigned long long* lock)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n_total) return;
+  const int y = ys[x];
+  if (y < 0) return;
+  const unsigned long long key = ((unsigned long long)__float_as_uint(gain[x]) << 32) | (uint32_t)x;  // (gains are positive floats: their bits order like their values)
+  ri_for_lock_set(x, y, cs[x], ulo, uhi, upar, [&](int n) { atomicMax(&lock[n], key); return true; });
+}
+
+__device__ __forceinline__ void ri_replace_child(float4* ulo, float4* uhi, int node, int from, int to)
+{
+  if (__float_as_int(ulo[node].w) == from) ulo[node].w = __int_as_float(to);
+  else uhi[node].w = __int_as_float(to);
+}
+
+__global__ void k_ri_apply(int n_total, float4* ulo, float4* uhi, int* upar, const float* gain, const int* ys, const int* cs, const unsigned long long* lock, uint32_t* n_applied)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n_total) return;
+  const int y = ys[x];
+  if (y < 0) return;
+  const unsigned long long key = ((unsigned long long)__float_as_uint(gain[x]) << 32) | (uint32_t)x;
+  // (a node that is not ours is never followed: ri_for_lock_set stops at the first one, and the nodes we did follow are modified by nobody else)
+  if (!ri_for_lock_set(x, y, cs[x], ulo, uhi, upar, [&](int n) { return lock[n] == key; })) return;
+  const int p = upar[x], g = upar[p];
+  const int s = __float_as_int(ulo[p].w) == x ? __float_as_int(uhi[p].w) : __float_as_int(ulo[p].w);
+  ri_replace_child(ulo, uhi, g, p, s);  // p leaves: the sibling takes its place
+  upar[s] = g;
+  const int q = upar[y];                // p goes between y and y's parent
+  ri_replace_child(ulo, uhi, q, y, p);
+  upar[p] = q;
+  ulo[p].w = __int_as_float(x);
+  uhi[p].w = __int_as_float(y);
+  upar[y] = p;
+  atomicAdd(n_applied, 1u);
+}
+
+// boxes and leaf counts of the inner nodes, bottom up (child links in .w are kept)
+__global__ void k_ri_refit(int n_inner, int n_leaves, float4* ulo, float4* uhi, const int* upar, unsigned int* arrive, int* count)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_leaves) return;
+  int cur = upar[n_inner + i];
+  while (cur >= 0) {
+    __threadfence();
+    const unsigned int prev = atomicAdd(&arrive[cur], 1u);
+    if (prev == 0u) return;
+    __threadfence();
+    const float4 mylo = ulo[cur], myhi = uhi[cur];
+    const int l = __float_as_int(mylo.w), r = __float_as_int(myhi.w);
+    const float4 al = ulo[l], ah = uhi[l], bl = ulo[r], bh = uhi[r];
+    ulo[cur] = make_float4(fminf(al.x, bl.x), fminf(al.y, bl.y), fminf(al.z, bl.z), mylo.w);
+    uhi[cur] = make_float4(fmaxf(ah.x, bh.x), fmaxf(ah.y, bh.y), fmaxf(ah.z, bh.z), myhi.w);
+    count[cur] = (l < n_inner ? count[l] : 1) + (r < n_inner ? count[r] : 1);
+    cur = upar[cur];
+  }
+}
+
+__global__ void k_ri_export(int n_inner, const float4* ulo, const float4* uhi, const int* count, int2* children, int2* ranges, float4* node_lo, float4* node_hi)
+{
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_inner) return;
+  const float4 lo = ulo[u], hi = uhi[u];
+  const int l = __float_as_int(lo.w), r = __float_as_int(hi.w);
+  children[u] = make_int2(l < n_inner ? l : ~(l - n_inner), r < n_inner ? r : ~(r - n_inner));
+  ranges[u] = make_int2(0, count[u] - 1);
+  node_lo[u] = make_float4(lo.x, lo.y, lo.z, 0.0f);
+  node_hi[u] = make_float4(hi.x, hi.y, hi.z, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -883,6 +1079,8 @@ int bvh_build_device(fh_ctx* ctx)
   if (ctx->d_bvh2_tris) { (void)hipFree(ctx->d_bvh2_tris); ctx->d_bvh2_tris = nullptr; }
   if (ctx->d_bvh8_nodes) { (void)hipFree(ctx->d_bvh8_nodes); ctx->d_bvh8_nodes = nullptr; }
   if (ctx->d_bvh8_tris) { (void)hipFree(ctx->d_bvh8_tris); ctx->d_bvh8_tris = nullptr; }
+  if (ctx->d_bvh8_parent) { (void)hipFree(ctx->d_bvh8_parent); ctx->d_bvh8_parent = nullptr; }
+  if (ctx->d_face_node) { (void)hipFree(ctx->d_face_node); ctx->d_face_node = nullptr; }
   ctx->bvh2_n_nodes = ctx->bvh2_n_tris = ctx->bvh8_n_nodes = ctx->bvh8_n_tris = 0;
   ctx->use_bvh8 = false;
   ctx->bvh_valid = false;
@@ -927,7 +1125,7 @@ int bvh_build_device(fh_ctx* ctx)
       FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * 8ull));
       hipLaunchKernelGGL(k_clear_tris8, dim3(1), dim3(64), 0, st, ctx->d_bvh8_tris, 8u);
       hipLaunchKernelGGL(k_collapse8_tiny, dim3(1), dim3(1), 0, st, (int)n, face_lo.p, face_hi.p, pad, ctx->d_bvh8_nodes, tri_slot.p);
-      hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, tri_slot.p, n, ctx->d_bvh8_tris, (const uint32_t*)nullptr);
+      hipLaunchKernelGGL(k_emit_tris8, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_a.p, tri_slot.p, n, ctx->d_bvh8_tris, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr);
       FH_HIP(hipStreamSynchronize(st));
       ctx->bvh8_n_nodes = 1;
       ctx->bvh8_n_tris = n;
@@ -1085,11 +1283,102 @@ int bvh_build_device(fh_ctx* ctx)
     const float4* c_node_lo = ploc ? p_node_lo.p : node_lo.p;
     const float4* c_node_hi = ploc ? p_node_hi.p : node_hi.p;
 
+    // ---- SAH refinement of the chosen binary tree by parallel reinsertion (kernels above), in place
+    {
+      int sah_iters = 0;          // FH_SAH_ITERS: rounds at most (0: off, the default: profiles/README.md r5-1)
+      double sah_min_gain = 0.01; // FH_SAH_MIN_GAIN: stop when a round lowers the summed inner-node area by less than this share
+      int sah_visits = 1024;      // FH_SAH_VISITS: nodes one search may look at
+      if (const char* e = getenv("FH_SAH_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) sah_iters = v; }
+      if (const char* e = getenv("FH_SAH_MIN_GAIN")) { const double v = atof(e); if (v >= 0.0 && v < 1.0) sah_min_gain = v; }
+      if (const char* e = getenv("FH_SAH_VISITS")) { const int v = atoi(e); if (v >= 8 && v <= (1 << 20)) sah_visits = v; }
+      ctx->stats_sah_before = ctx->stats_sah_after = 0.0;
+      ctx->stats_sah_rounds = 0;
+      if (sah_iters > 0 && n_inner >= 3) {
+        const auto t_sah = std::chrono::steady_clock::now();
+        const uint32_t n_total = n_inner + nr;
+        const uint32_t tblocks = (n_total + 255) / 256;
+        DevBuf<float4> ulo, uhi;
+        DevBuf<int> upar, ri_y, ri_c, ri_count;
+        DevBuf<float> ri_gain;
+        DevBuf<unsigned long long> ri_lock;
+        DevBuf<double> ri_sum;
+        DevBuf<uint32_t> ri_applied;
+        FH_HIP(ulo.alloc(n_total)); FH_HIP(uhi.alloc(n_total)); FH_HIP(upar.alloc(n_total)); FH_HIP(ri_y.alloc(n_total)); FH_HIP(ri_c.alloc(n_total)); FH_HIP(ri_count.alloc(n_inner));
+        FH_HIP(ri_gain.alloc(n_total)); FH_HIP(ri_lock.alloc(n_total)); FH_HIP(ri_sum.alloc(1)); FH_HIP(ri_applied.alloc(1));
+        int2* m_children = ploc ? p_children.p : children.p;
+        int2* m_ranges = ploc ? p_ranges.p : ranges.p;
+        float4* m_node_lo = ploc ? p_node_lo.p : node_lo.p;
+        float4* m_node_hi = ploc ? p_node_hi.p : node_hi.p;
+        hipLaunchKernelGGL(k_ri_init, dim3(tblocks), dim3(256), 0, st, (int)n_inner, (int)nr, root_node, m_children, m_node_lo, m_node_hi, leaf_lo.p, leaf_hi.p, ulo.p, uhi.p, upar.p);
+        auto sah_of = [&](double* out) -> int {
+          FH_HIP(hipMemsetAsync(ri_sum.p, 0, 8, st));
+          hipLaunchKernelGGL(k_sah_sum, dim3(iblocks), dim3(256), 0, st, (int)n_inner, ulo.p, uhi.p, ri_sum.p);
+          FH_HIP(hipMemcpyAsync(out, ri_sum.p, 8, hipMemcpyDeviceToHost, st));
+          FH_HIP(hipStreamSynchronize(st));
+          return FH_OK;
+        };
+        double sah_prev = 0.0;
+        { const int rc = sah_of(&sah_prev); if (rc) return rc; }
+        ctx->stats_sah_before = sah_prev;
+        double root_area_eps = 0.0;
+        {
+          float4 rl, rh;
+          FH_HIP(hipMemcpyAsync(&rl, ulo.p + root_node, 16, hipMemcpyDeviceToHost, st));
+          FH_HIP(hipMemcpyAsync(&rh, uhi.p + root_node, 16, hipMemcpyDeviceToHost, st));
+          FH_HIP(hipStreamSynchronize(st));
+          const double ex = rh.x - rl.x, ey = rh.y - rl.y, ez = rh.z - rl.z;
+          root_area_eps = (ex * ey + ey * ez + ez * ex) * 1e-9;  // gains below a billionth of the root's area are rounding noise, not moves worth a lock
+        }
+        int rounds = 0;
+        for (int it = 0; it < sah_iters; ++it) {
+          hipLaunchKernelGGL(k_ri_search, dim3(tblocks), dim3(256), 0, st, (int)n_total, (int)n_inner, root_node, ulo.p, uhi.p, upar.p, ri_gain.p, ri_y.p, ri_c.p, sah_visits,
+                             (float)root_area_eps);
+          FH_HIP(hipMemsetAsync(ri_lock.p, 0, 8ull * n_total, st));
+          FH_HIP(hipMemsetAsync(ri_applied.p, 0, 4, st));
+          hipLaunchKernelGGL(k_ri_lock, dim3(tblocks), dim3(256), 0, st, (int)n_total, ulo.p, uhi.p, upar.p, ri_gain.p, ri_y.p, ri_c.p, ri_lock.p);
+          hipLaunchKernelGGL(k_ri_apply, dim3(tblocks), dim3(256), 0, st, (int)n_total, ulo.p, uhi.p, upar.p, ri_gain.p, ri_y.p, ri_c.p, ri_lock.p, ri_applied.p);
+          FH_HIP(hipMemsetAsync(arrive.p, 0, 4ull * n_inner, st));
+          hipLaunchKernelGGL(k_ri_refit, dim3(rblocks), dim3(256), 0, st, (int)n_inner, (int)nr, ulo.p, uhi.p, upar.p, arrive.p, ri_count.p);
+          double sah_now = 0.0;
+          { const int rc = sah_of(&sah_now); if (rc) return rc; }
+          ++rounds;
+          if (getenv("FH_DEBUG_BVH")) {
+            uint32_t applied = 0;
+            FH_HIP(hipMemcpy(&applied, ri_applied.p, 4, hipMemcpyDeviceToHost));
+            std::vector<int> hy(n_total);
+            FH_HIP(hipMemcpy(hy.data(), ri_y.p, 4ull * n_total, hipMemcpyDeviceToHost));
+            size_t wanted = 0;
+            for (int v : hy) wanted += v >= 0;
+            fprintf(stderr, "[bvh] reinsertion round %d: %zu nodes with a better place, ", it + 1, wanted);
+            fprintf(stderr, "%u moves, inner-node area %.4f -> %.4f (%.2f %%)\n", applied, sah_prev, sah_now, 100.0 * (sah_prev - sah_now) / sah_prev);
+          }
+          const bool done = !(sah_prev - sah_now > sah_min_gain * sah_prev);
+          sah_prev = sah_now;
+          if (done) break;
+        }
+        if (rounds == 0) {  // (counts for the export)
+          FH_HIP(hipMemsetAsync(arrive.p, 0, 4ull * n_inner, st));
+          hipLaunchKernelGGL(k_ri_refit, dim3(rblocks), dim3(256), 0, st, (int)n_inner, (int)nr, ulo.p, uhi.p, upar.p, arrive.p, ri_count.p);
+        }
+        hipLaunchKernelGGL(k_ri_export, dim3(iblocks), dim3(256), 0, st, (int)n_inner, ulo.p, uhi.p, ri_count.p, m_children, m_ranges, m_node_lo, m_node_hi);
+        FH_HIP(hipGetLastError());
+        FH_HIP(hipStreamSynchronize(st));
+        ctx->stats_sah_after = sah_prev;
+        ctx->stats_sah_rounds = rounds;
+        ctx->stats_sah_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sah).count();
+        if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[bvh] reinsertion: %d rounds, %.2f ms, inner-node area %.4f -> %.4f\n", rounds, ctx->stats_sah_ms, ctx->stats_sah_before, ctx->stats_sah_after);
+      }
+    }
+
     // ---- collapse to BVH8, breadth first
     DevBuf<Work8> work_a, work_b;
     DevBuf<uint32_t> counters, tri_slot;  // [0] node counter, [1] triangle counter, [2] next-level item count; triangle slot of every sorted leaf
     FH_HIP(work_a.alloc(n_inner)); FH_HIP(work_b.alloc(n_inner)); FH_HIP(counters.alloc(3)); FH_HIP(tri_slot.alloc(nr));
     FH_HIP(hipMalloc((void**)&ctx->d_bvh8_nodes, sizeof(uint4) * (size_t)kBvh8NodeVec * n_inner));
+    FH_HIP(hipMalloc((void**)&ctx->d_bvh8_parent, 4ull * n_inner));
+    FH_HIP(hipMalloc((void**)&ctx->d_face_node, 4ull * n));
+    FH_HIP(hipMemsetAsync(ctx->d_bvh8_parent, 0xff, 4ull * n_inner, st));  // (the root keeps 0xffffffff: no way up)
+    FH_HIP(hipMemsetAsync(ctx->d_face_node, 0xff, 4ull * n, st));
     const uint32_t leaf_max8 = 1;  // one triangle per leaf child (the node layout has one triangle slot per child slot): box tests are ~4x cheaper than triangle tests (profiles/README.md)
     uint32_t absorb8 = 1u;  // FH_ABSORB=0: plain largest-child-first collapse
     if (const char* e = getenv("FH_ABSORB")) absorb8 = e[0] != '0' ? 1u : 0u;
@@ -1108,6 +1397,11 @@ int bvh_build_device(fh_ctx* ctx)
                          cut_decision.p);
       FH_HIP(hipGetLastError());
       FH_HIP(hipStreamSynchronize(st));  // (the parent arrays go out of scope here)
+      if (getenv("FH_DEBUG_BVH")) {
+        float c_root = 0.0f;
+        FH_HIP(hipMemcpy(&c_root, cut_cost_tab.p + 7ull * (size_t)root_node, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[bvh] least summed area of the wide nodes (cut tables, root): %.4f\n", c_root);
+      }
     }
     const Work8 root{root_node, 0u};
     const uint32_t init_counters[3] = {1u, 0u, 0u};
@@ -1123,7 +1417,7 @@ int bvh_build_device(fh_ctx* ctx)
       level_start.push_back(level_start.back() + level_count);
       FH_HIP(hipMemsetAsync(counters.p + 2, 0, 4, st));
       hipLaunchKernelGGL(k_collapse8, dim3((level_count + 63) / 64), dim3(64), 0, st, cur, level_count, c_children, c_ranges, c_node_lo, c_node_hi, leaf_lo.p, leaf_hi.p, pad,
-                         leaf_max8, absorb8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_slot.p, nxt, counters.p + 2, optimal_cut ? cut_decision.p : (const uint2*)nullptr);
+                         leaf_max8, absorb8, ctx->d_bvh8_nodes, counters.p, counters.p + 1, tri_slot.p, nxt, counters.p + 2, optimal_cut ? cut_decision.p : (const uint2*)nullptr, ctx->d_bvh8_parent);
       FH_HIP(hipMemcpyAsync(&level_count, counters.p + 2, 4, hipMemcpyDeviceToHost, st));
       FH_HIP(hipStreamSynchronize(st));
       Work8* t = cur; cur = nxt; nxt = t;
@@ -1139,7 +1433,7 @@ int bvh_build_device(fh_ctx* ctx)
     const uint32_t n_slots = 8u * final_counters[0];  // one triangle slot per child slot
     FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n_slots));
     hipLaunchKernelGGL(k_clear_tris8, dim3((n_slots + 255) / 256), dim3(256), 0, st, ctx->d_bvh8_tris, n_slots);
-    hipLaunchKernelGGL(k_emit_tris8, dim3(rblocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_slot.p, nr, ctx->d_bvh8_tris, ref_face);
+    hipLaunchKernelGGL(k_emit_tris8, dim3(rblocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_slot.p, nr, ctx->d_bvh8_tris, ref_face, ctx->d_face_node, ref_face ? split_count.p : (const uint32_t*)nullptr);
     FH_HIP(hipGetLastError());
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh8_n_nodes = final_counters[0];

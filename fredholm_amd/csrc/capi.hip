@@ -440,6 +440,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_TAIL_DEPTH", 0, 64, t.tail_depth);
     env_uint("FH_TAIL_PATHS", 64, 1 << 30, t.tail_paths);
     env_off("FH_SORT", t.sort_queues);
+    env_off("FH_BOTTOM_UP", t.bottom_up);
     t.debug_tail = getenv("FH_DEBUG_TAIL") != nullptr;
     if (const char* e = getenv("FH_NO_ALPHA")) t.ignore_alpha = e[0] == '1';
     if (const char* e = getenv("FH_FORCE_ALPHA")) t.force_alpha = e[0] == '1';
@@ -470,7 +471,7 @@ int fh_ctx_destroy(fh_ctx* ctx)
   void* ptrs[] = {ctx->d_sample_issued, ctx->d_sobol, ctx->d_sobol_bytes, ctx->d_alpha_rec, ctx->d_lut_refl, ctx->d_lut_sheen, ctx->d_face_rec, ctx->d_face_cls, ctx->d_materials, ctx->d_lights, ctx->d_bvh2_nodes, ctx->d_bvh2_tris,
                   ctx->d_bvh8_nodes, ctx->d_bvh8_tris, ctx->d_sample_count, ctx->d_owned, ctx->d_trace_counters, ctx->d_texels, ctx->d_textures, ctx->d_srgb_lut, ctx->d_ibl,
                   ctx->d_bloom_weights, ctx->d_quirk_seen, ctx->d_quirk_aov, ctx->d_obj_vertices, ctx->d_obj_normals, ctx->d_obj_texcoords, ctx->d_obj_indices, ctx->d_face_meta, ctx->d_o2w, ctx->d_w2o,
-                  ctx->d_bvh8_box, ctx->d_denoise_tmp[0], ctx->d_denoise_tmp[1], ctx->d_hosek, ctx->d_owned_xy, ctx->d_stack_spill};
+                  ctx->d_bvh8_box, ctx->d_denoise_tmp[0], ctx->d_denoise_tmp[1], ctx->d_hosek, ctx->d_owned_xy, ctx->d_stack_spill, ctx->d_bvh8_parent, ctx->d_face_node};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (fh_ctx::ShardList& c : ctx->shard_lists)

@@ -69,6 +69,8 @@ struct fh_ctx {
   uint4* d_bvh8_nodes = nullptr;
   float4* d_bvh8_tris = nullptr;
   uint32_t bvh8_n_nodes = 0, bvh8_n_tris = 0;
+  uint32_t* d_bvh8_parent = nullptr;  // per wide node: parent << 3 | child slot in the parent (root: 0xffffffff)
+  uint32_t* d_face_node = nullptr;    // per face: the wide node that holds it (bottom-up start of the rays that leave it, fh_trace.h)
   // kept after a full build so that a change of instance transforms refits the wide tree instead of rebuilding it (bvh_build.hip)
   float4* d_bvh8_box = nullptr;             // full-precision (lo, hi) of every wide node
   std::vector<uint32_t> bvh8_level_start;   // node index range of every level (levels are contiguous: the collapse is breadth first)
@@ -86,6 +88,8 @@ struct fh_ctx {
   bool use_bvh8 = false;
   int builder_choice = 0;  // 0 = not decided for this scene, 1 = radix tree (LBVH), 2 = PLOC; decided at the first build after an upload
   double bvh_build_ms = 0.0;
+  double stats_sah_before = 0.0, stats_sah_after = 0.0, stats_sah_ms = 0.0;  // summed inner-node area of the binary tree before / after the reinsertion rounds of the last full build
+  int stats_sah_rounds = 0;
   float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};  // padded world bounds of the geometry
 
   // frame state
@@ -171,6 +175,7 @@ struct fh_ctx {
                                          // whose items are whole paths with two to four rays each, loses with more than 64: 113.9 -> 115.7 ms at 128)
     uint32_t tail_depth = 0;        // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail
     uint32_t tail_paths = 0;        // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail; 0 = 65536, 262144 for passes of at most 4 Mi paths
+    bool bottom_up = false;         // FH_BOTTOM_UP=1 (measured, profiles/README.md r5-2; off): rays that leave a surface start their traversal at the wide node that holds the face and climb
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
     bool debug_tail = false;        // FH_DEBUG_TAIL
     bool force_alpha = false;       // FH_FORCE_ALPHA=1 (timing experiments): the kernels with the any-hit path compiled in, whatever the scene

@@ -47,6 +47,7 @@ struct Bvh8Dev {
   uint32_t n_nodes;
   uint32_t n_tris;
   uint32_t depth;       // entries of the LDS traversal stack: levels of the tree - 1 (fh_trace.h: stack_entries_for)
+  const uint32_t* parent;  // per node: parent << 3 | child slot in the parent, root 0xffffffff; null: rays start at the root (fh_trace.h: bottom-up start)
 };
 
 struct SceneDev {
@@ -63,6 +64,7 @@ struct SceneDev {
   Bvh2Dev bvh2;
   Bvh8Dev bvh8;
   uint32_t use_bvh8;
+  const uint32_t* face_node;    // per face: the wide node that holds it; null when rays start at the root
 };
 
 struct FrameDev {

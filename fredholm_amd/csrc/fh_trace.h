@@ -428,6 +428,9 @@ struct GroupStack<false> {
   FH_D GroupStack(uint2*, int, uint2*, uint32_t, uint32_t) {}
   FH_D void push(uint2 g) { if (sp < kBvh8Stack) spill[sp++] = g; }
   FH_D uint2 pop() { return spill[--sp]; }
+  FH_D void set_anchor(uint32_t node, uint32_t skip) { spill[0] = make_uint2(node, skip); }
+  FH_D uint32_t anchor() const { return spill[0].x; }
+  FH_D uint32_t anchor_skip() const { return spill[0].y; }
 };
 template <>
 struct GroupStack<true> {
@@ -458,6 +461,11 @@ struct GroupStack<true> {
     const uint32_t w = word[sp * 256];
     return make_uint2(w >> 8, (w << 24) | mask[sp * 256]);
   }
+  // entry 0 of a ray that started below the root (traverse_stream: bottom-up start) is not a group: it holds the node the ray climbs from next and, while that node's
+  // parent is being visited, the child slot of the parent the ray came up through (always in LDS: every configuration keeps at least one level there)
+  FH_D void set_anchor(uint32_t node, uint32_t skip) { word[0] = node; mask[0] = (uint8_t)skip; }
+  FH_D uint32_t anchor() const { return word[0]; }
+  FH_D uint32_t anchor_skip() const { return mask[0]; }
 };
 // where the streaming kernels put stack entries beyond the LDS part (null: everything in LDS)
 struct StackSpill { uint2* area; uint32_t lds_entries; };  // lds_entries: levels kept in LDS when area is set
@@ -790,7 +798,19 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
                           uint2* lds_column, int lds_stride, const SceneDev* sc, StackSpill spill = StackSpill{nullptr, 0u})
 {
   const uint32_t lane = __lane_id();
-  GroupStack<LDS> stack(lds_column, spill.area ? (int)spill.lds_entries : lds_stride, spill.area, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x);
+  GroupStack<LDS> stack(lds_column, spill.lds_entries ? (int)spill.lds_entries : lds_stride, spill.area, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x);
+  // ---- Bottom-up start.  A ray that leaves a surface (every secondary ray, every closest-hit ray after the first bounce) starts INSIDE the tree: at the wide node that holds
+  // the face it leaves (bvh.parent != null; the policy says which node).  It walks that node's subtree first, then climbs: the parent is visited with the child it came up
+  // through masked out, the siblings' subtrees are walked with the ordinary stack, and so on to the root -- the same nodes a walk from the root visits for a ray that reaches
+  // nothing, in the order nearest first.  A ray that stops at its first hit and finds one near its origin (1M-triangle soup: mean free path 0.05 in a scene of size 2) never
+  // sees the upper levels, which a walk from the root pays for every ray (9 of its 15 node visits); a closest-hit ray climbs with its limit already at the near hit, so the
+  // siblings are culled by their parent's node test instead of being popped one by one.  MEASURED (profiles/README.md r5-2) and OFF by default (FH_BOTTOM_UP=1): on the soup a
+  // secondary ray visits 11.8 nodes instead of 15.3 and the kernel takes the same 29.6 ms per 256 spp (one more dependent load per level climbed, shorter rays = more refills;
+  // the kernel sits on the vector L1's look-up rate as much as on issue); on the Sponza-class interior, where rays are long, it tests 15 % more triangles (the coplanar
+  // neighbours of the face the ray leaves come first) and is 10 % slower.  Hits do not depend on the order nodes are visited in (closest: minimum over the
+  // accepted candidates, none of which a conservative node test can cull; first-hit: a yes / no), so the bits do not change.
+  // State: `up` (the lane's ray still has levels to climb) and entry 0 of the lane's stack (GroupStack::set_anchor); the groups of the subtree being walked sit above it.
+  bool up = false;
   Ray8 r;
   r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct = 0u; r.nx = r.ny = r.nz = false;
   uint2 group = make_uint2(0u, 0u);
@@ -842,7 +862,10 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
           cl.uv[lane] = make_float2(0.0f, 0.0f);
           stack.sp = 0;
           have = true;
-          group = make_uint2(0u, 0x80000000u);
+          const uint32_t start = bvh.parent ? pol.start_node() : 0u;
+          up = start != 0u;
+          if (up) { stack.set_anchor(start, 8u); stack.sp = 1; }
+          group = make_uint2(start, 0x80000000u);  // (hit bit 7 of a group without inner-child bits: node group.x itself)
           busy = bvh.n_nodes != 0u;
           if (COUNT) ray_n0 = n_nodes;
         }
@@ -854,15 +877,26 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       }
     }
     uint2 tg = make_uint2(0u, 0u);
-    if (busy && (group.y & 0xff000000u) == 0u) {
-      if (stack.sp == 0) busy = false;
-      else group = stack.pop();
-    }
     float best_t = 0.0f;
     if (busy) {
       const unsigned long long k = cl.key[lane];
       best_t = __uint_as_float((uint32_t)(k >> 32));
       if (MIXED && any && (uint32_t)k != 0xffffffffu) busy = false;
+    }
+    bool climbing = false;  // this visit is the parent of the subtree just finished
+    if (busy && (group.y & 0xff000000u) == 0u) {
+      if (stack.sp == (up ? 1 : 0)) {
+        if (!up) busy = false;
+        else {
+          const uint32_t link = bvh.parent[stack.anchor()];
+          if (link == 0xffffffffu) busy = false;  // the root's subtree is done
+          else {
+            stack.set_anchor(link >> 3, link & 7u);
+            group = make_uint2(link >> 3, 0x80000000u);
+            climbing = true;
+          }
+        }
+      } else group = stack.pop();
     }
 #if FH_NODE_FETCH_PAIR
     uint32_t ni = 0u;
@@ -879,6 +913,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       uint4 n0, n1, n2, n3;
       node8_fetch_pair(bvh, busy, ni, n0, n1, n2, n3);  // (all 64 lanes)
       if (busy) node8_eval(r, ni, n0, n1, n2, n3, best_t, group, tg);
+      if (busy && climbing) group.y &= ~(1u << (24u + (stack.anchor_skip() ^ r.oct)));
     }
 #else
     if (busy) {
@@ -891,6 +926,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       const uint32_t ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
       node8_visit<ordered>(bvh, r, ni, best_t, group, tg);
+      if (climbing) group.y &= ~(1u << (24u + (ordered ? (stack.anchor_skip() ^ r.oct) : stack.anchor_skip())));  // the child the ray came up through has been walked
     }
 #endif
     if (FH_HANDOVER_SCAN && (!ALPHA || FH_HANDOVER_SCAN_ALPHA)) {

@@ -478,6 +478,10 @@ struct AlphaLds<true> {
   }
 };
 
+// direction.w of a ray record (store_secondary below, PoolSink::next): 0 = no ray; otherwise 1 + the wide node the ray starts its traversal at (1: the root)
+FH_D bool sec_present(const float4& d4) { return __float_as_uint(d4.w) != 0u; }
+FH_D uint32_t start_node_of(const float4& d4) { const uint32_t b = __float_as_uint(d4.w); return b ? b - 1u : 0u; }
+
 template <bool COUNT>
 struct ClosestStream {
   static constexpr bool all_any = false;
@@ -485,6 +489,7 @@ struct ClosestStream {
   const uint32_t* q;
   ChunkFeed feed;
   uint32_t p = 0, qi = 0;  // path slot and queue entry of the lane's ray
+  uint32_t start = 0;      // wide node the ray starts its traversal at (0: the root; camera rays)
   uint32_t n_rays = 0;
   unsigned long long* hist;
   HistPack hp;
@@ -497,6 +502,7 @@ struct ClosestStream {
     qi = i;
     const float4 o4 = pool.ray_o[p], d4 = pool.ray_d[p];
     o = mk3(o4); d = mk3(d4); tmax = o4.w; any = false;
+    start = start_node_of(d4);
     if (COUNT) n_rays++;
     return true;
   }
@@ -508,6 +514,7 @@ struct ClosestStream {
   }
   FH_D bool drained() const { return feed.drained(); }
   FH_D bool followup() const { return false; }
+  FH_D uint32_t start_node() const { return start; }
 };
 
 template <bool COUNT, bool ALPHA>
@@ -644,13 +651,16 @@ FH_D f3 emission_of(const SceneDev& sc, const MaterialDev& m, float tu, float tv
   return tex_id(m, 41) >= 0 ? tex_rgb(sc, tex_id(m, 41), tu, tv) : mk3(m.w[38], m.w[39], m.w[40]);
 }
 
-FH_D void store_secondary(const PoolDev& pool, uint32_t slot, uint32_t p, f3 o, float tmax, f3 d, bool active, f3 c)
+// (direction.w of a ray record: 0 = no ray in this place; otherwise 1 + the wide node the ray starts its traversal at -- the node that holds the face it leaves, fh_trace.h:
+// bottom-up start -- or 1 = the root.  Read as BITS everywhere: small integers are denormal floats.)
+FH_D void store_secondary(const PoolDev& pool, uint32_t slot, uint32_t p, f3 o, float tmax, f3 d, bool active, f3 c, uint32_t start_bits = 1u)
 {
   const size_t k = pool.sec_at(slot, p);
   pool.sec[k] = mk4(o, tmax);
-  pool.sec[k + 1] = mk4(d, active ? 1.0f : 0.0f);
+  pool.sec[k + 1] = mk4(d, __uint_as_float(active ? start_bits : 0u));
   pool.sec[k + 2] = mk4(c, 0.0f);
 }
+
 
 // Sobol' dimensions and CMJ slots of one bounce
 struct BounceSlots {
@@ -713,7 +723,8 @@ struct PoolSink {      // memory sink (k_shade): path slot p of the pool
   float hit_t;
   bool shaded = false, cont = false;
   f3 origin;           // where the path's rays leave the surface (cell key of the bounce queues)
-  FH_D PoolSink(const PoolDev& pl, uint32_t slot, float t) : pool(pl), p(slot), hit_t(t), origin(mk3(0.0f)) {}
+  uint32_t start_bits; // 1 + the wide node that holds the face the rays leave (1: they start at the root)
+  FH_D PoolSink(const PoolDev& pl, uint32_t slot, float t, uint32_t sb = 1u) : pool(pl), p(slot), hit_t(t), origin(mk3(0.0f)), start_bits(sb) {}
   FH_D void aov(f3 position, f3 normal, f3 albedo, float u, float v)
   {
     pool.aov_position[p] = mk4(position, 0.0f);
@@ -725,7 +736,7 @@ struct PoolSink {      // memory sink (k_shade): path slot p of the pool
   FH_D void emissive(f3 l) { pool.rad[p] = mk4(l, 0.0f); }
   FH_D void secondary(uint32_t slot, f3 o, float tmax, f3 d, bool active, f3 c)
   {
-    store_secondary(pool, slot, p, o, tmax, d, active, c);
+    store_secondary(pool, slot, p, o, tmax, d, active, c, start_bits);
     if (!shaded) origin = o;  // all rays of a path leave (almost) the same point
     shaded = true;
   }
@@ -733,7 +744,7 @@ struct PoolSink {      // memory sink (k_shade): path slot p of the pool
   FH_D void next(f3 o, f3 d, f3 t)
   {
     pool.ray_o[p] = mk4(o, 1e9f);
-    pool.ray_d[p] = mk4(d, 0.0f);
+    pool.ray_d[p] = mk4(d, __uint_as_float(start_bits));
     pool.thr[p] = mk4(t, 0.0f);
     if (!shaded) origin = o;
     cont = true;
@@ -1010,7 +1021,8 @@ __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : BLOCKS)) k_shade
     if (valid) {
       p = q[i];
       const float4 hit = pool.hit[p];
-      PoolSink o(pool, p, hit.x);
+      // the rays of this bounce leave the face that was hit: they start their traversal at the wide node that holds it (fh_trace.h: bottom-up start)
+      PoolSink o(pool, p, hit.x, sc.face_node ? sc.face_node[__float_as_uint(hit.w)] + 1u : 1u);
       const bool first = depth != 0 || (pool.flags[p] & 4u) == 0u;
       const f3 L = depth == 0u ? mk3(pool.rad[p]) : mk3(0.0f);  // the radiance so far only enters at a directly visible emitter (first hit): later bounces skip the load
       shade_hit<LOBES>(sc, fr, rows, bs, depth, hit, mk3(pool.ray_d[p]), mk3(pool.thr[p]), L, pool.pixel[p], pool.nspp[p], o, first);
@@ -1089,7 +1101,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_secondary_static(SceneDev sc, 
       if (slot == SEC_AREA && !has_lights) continue;
       const size_t k = pool.sec_at(slot, p);
       const float4 d = pool.sec[k + 1];
-      if (d.w == 0.0f) continue;
+      if (!sec_present(d)) continue;
       const float4 o = pool.sec[k];
       HitRec h;
       if (COUNT) nr++;
@@ -1142,7 +1154,7 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? 5 : 6)) k_trace_
       if (slot == SEC_AREA && !has_lights) continue;
       const size_t k = pool.sec_at(slot, p);
       const float4 d = in_range ? pool.sec[k + 1] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-      const bool valid = in_range && d.w != 0.0f;
+      const bool valid = in_range && sec_present(d);
       if (__ballot(valid) == 0ull) continue;
       const float4 o = valid ? pool.sec[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       HitRec h;
@@ -1181,6 +1193,7 @@ struct SecondaryStream {
   const PoolDev& pool;
   ChunkFeed feed;
   uint32_t p = 0, slot = 0;
+  uint32_t start = 0;  // wide node the lane's current ray starts its traversal at (0: the root)
   bool active = false;
   f3 L;
   uint32_t n_rays = 0;
@@ -1195,9 +1208,10 @@ struct SecondaryStream {
       if (s == SEC_AREA && !LIGHTS) continue;
       const size_t k = pool.sec_at(s, p);
       const float4 d4 = pool.sec[k + 1];
-      if (d4.w == 0.0f) continue;
+      if (!sec_present(d4)) continue;
       const float4 o4 = pool.sec[k];
       o = mk3(o4); d = mk3(d4); tmax = o4.w;
+      start = start_node_of(d4);
       any = !(s == SEC_LIGHT && LIGHTS);
       slot = s;
       if (COUNT) n_rays++;
@@ -1241,6 +1255,7 @@ struct SecondaryStream {
   }
   FH_D bool drained() const { return feed.drained(); }
   FH_D bool followup() const { return active && slot < SEC_LIGHT; }
+  FH_D uint32_t start_node() const { return start; }
 };
 
 template <bool COUNT, bool LIGHTS, bool ALPHA>
@@ -1285,6 +1300,7 @@ struct MergedStream {
   uint32_t n_sec;
   ChunkFeed feed;
   uint32_t pc = 0, qc = 0;    // path slot and entry (in the next bounce's radiance queue) of the lane's closest-hit ray
+  uint32_t start_closest = 0;
   bool closest = false;       // the lane's current item is a closest-hit ray
   FH_D MergedStream(const SceneDev& s, const FrameDev& f, const PoolDev& ps, const PoolDev& pn, const uint32_t* qc, uint32_t ns, const ChunkFeed& cf)
       : sec(s, f, ps, cf, nullptr), next(pn), q_closest(qc), n_sec(ns), feed(cf) {}
@@ -1298,8 +1314,10 @@ struct MergedStream {
     pc = q_closest[qc];
     const float4 o4 = next.ray_o[pc], d4 = next.ray_d[pc];
     o = mk3(o4); d = mk3(d4); tmax = o4.w; any = false;
+    start_closest = start_node_of(d4);
     return true;
   }
+  FH_D uint32_t start_node() const { return closest ? start_closest : sec.start; }
   FH_D void commit(bool hit, const HitRec& h, uint32_t nodes)
   {
     if (closest) { next.hit[pc] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)); next.q_prim[qc] = h.prim; }
@@ -1656,6 +1674,11 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.bvh8.n_tris = ctx->bvh8_n_tris;
   s.bvh8.depth = stack_entries_for(ctx->bvh8_depth);
   s.use_bvh8 = ctx->use_bvh8 ? 1u : 0u;
+  // bottom-up start (fh_trace.h): rays that leave a surface begin at the wide node that holds the face.  Only the streaming kernels climb; they trace trees of 4096 nodes and more
+  const bool bottom_up = ctx->tun.bottom_up && ctx->use_bvh8 && ctx->d_bvh8_parent && ctx->d_face_node && ctx->tun.coop && ctx->tun.stream && (ctx->tun.stream_forced || ctx->bvh8_n_nodes >= 4096u) &&
+                         ctx->bvh8_n_tris < kCoopMaxTris;
+  s.bvh8.parent = bottom_up ? ctx->d_bvh8_parent : nullptr;
+  s.face_node = bottom_up ? ctx->d_face_node : nullptr;
   return s;
 }
 
@@ -2015,18 +2038,21 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const bool stream = coop && tun.stream && (tun.stream_forced || ctx->bvh8_n_nodes >= 4096u);
   // the traversal stack of every lane lives in LDS, one entry per level of the BVH (bvh_build.hip records the depth); the streaming kernels may spill deep levels (below)
   const uint32_t stack_bytes = lds_stack_bytes(stack_entries_for(ctx->bvh8_depth));
-  if (sc.use_bvh8 && ctx->lds_configured_bytes != stack_bytes) {  // kernels that may need more than the default 64 KB of LDS are told so once per BVH depth
-    const int rc = configure_traversal_lds(ctx, stack_bytes);
+  const uint32_t cfg_bytes = lds_stack_bytes(stack_entries_for(ctx->bvh8_depth) + 1u);  // (+ 1: the anchor entry of rays that start below the root, fh_trace.h)
+  if (sc.use_bvh8 && ctx->lds_configured_bytes != cfg_bytes) {  // kernels that may need more than the default 64 KB of LDS are told so once per BVH depth
+    const int rc = configure_traversal_lds(ctx, cfg_bytes);
     if (rc) return rc;
   }
   if (sc.use_bvh8 && stack_bytes + ctx->lds_static_max > tun.lds_per_block) return fail(ctx, FH_E_UNSUPPORTED, "fh_render: BVH too deep for the LDS traversal stack");
   // all workgroups of a streaming launch are resident: as many per CU as its LDS (160 KB on gfx950) holds (at most 6: the kernels' register budget)
   const uint32_t stack_entries = stack_entries_for(ctx->bvh8_depth);
+  // the streaming kernels' rays may start below the root: entry 0 of such a ray's stack is its anchor, the groups come on top (fh_trace.h: bottom-up start)
+  const uint32_t stream_need = stack_entries + (sc.bvh8.parent ? 1u : 0u);
   // static LDS of a streaming kernel's workgroup: the cooperative-test records and, where candidates are parked for their any-hit test (AlphaDefer), the ring
   const uint32_t static_lds_closest = kCoopLdsBytesPerBlock + (sc.has_alpha && AlphaDefer<false, true>::value ? kAlphaLdsBytesPerBlock : 0u);
   const uint32_t static_lds_secondary = kCoopLdsBytesPerBlock + (sc.has_alpha && AlphaDefer<true, true>::value ? kAlphaLdsBytesPerBlock : 0u);
   if (stream) {  // what the runtime says really fits (LDS granularity, registers of the variant in use): a grid above it would leave blocks queued behind the resident ones
-    const uint32_t key = stack_bytes | (count ? 1u : 0u) | (sc.has_alpha ? 2u : 0u) | (sc.n_lights > 0 ? 4u : 0u) | (tun.stack_lds_entries << 20);
+    const uint32_t key = stack_bytes | (count ? 1u : 0u) | (sc.has_alpha ? 2u : 0u) | (sc.n_lights > 0 ? 4u : 0u) | (sc.bvh8.parent ? 8u : 0u) | (tun.stack_lds_entries << 20);
     if (ctx->occupancy_key != key) {
       auto occupancy = [&](bool secondary, uint32_t entries) {
         const uint32_t bytes = lds_stack_bytes(entries);
@@ -2047,14 +2073,14 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         const uint32_t static_lds = secondary ? static_lds_secondary : static_lds_closest;
         const uint32_t fit = lds_share > static_lds + 1280u ? (lds_share - static_lds) / 1280u : 1u;
         const uint32_t floor_entries = fit < 8u ? fit : 8u;
-        uint32_t entries = stack_entries;
+        uint32_t entries = stream_need;
         int got = occupancy(secondary, entries);
-        if (tun.stack_lds_entries) entries = tun.stack_lds_entries < stack_entries ? tun.stack_lds_entries : stack_entries;
-        else if (stack_entries > floor_entries) {
+        if (tun.stack_lds_entries) entries = tun.stack_lds_entries < stream_need ? tun.stack_lds_entries : stream_need;
+        else if (stream_need > floor_entries) {
           const int best = occupancy(secondary, floor_entries);
           while (entries > floor_entries && got < best) { --entries; got = occupancy(secondary, entries); }
         }
-        if (entries != stack_entries) got = occupancy(secondary, entries);
+        if (entries != stream_need) got = occupancy(secondary, entries);
         entries_out = entries;
         blocks_out = got > 0 ? (uint32_t)got : 0u;
       };
@@ -2066,12 +2092,12 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         ctx->info_entries[0] = ctx->stream_lds_entries; ctx->info_entries[1] = ctx->stream_lds_entries_secondary;
       }
       if (getenv("FH_DEBUG_BVH"))
-        fprintf(stderr, "[trace] stack of %u entries; in LDS: closest %u (%u B + %u B per workgroup, %u resident workgroups per CU), secondary %u (%u B + %u B, %u workgroups)\n", stack_entries,
+        fprintf(stderr, "[trace] stack of %u entries (%s); in LDS: closest %u (%u B + %u B per workgroup, %u resident workgroups per CU), secondary %u (%u B + %u B, %u workgroups)\n", stream_need, sc.bvh8.parent ? "rays start at the node of the face they leave" : "rays start at the root",
                 ctx->stream_lds_entries, lds_stack_bytes(ctx->stream_lds_entries), static_lds_closest, ctx->occupancy_blocks, ctx->stream_lds_entries_secondary,
                 lds_stack_bytes(ctx->stream_lds_entries_secondary), static_lds_secondary, ctx->occupancy_blocks_secondary);
     }
   }
-  const uint32_t stream_entries = stream ? ctx->stream_lds_entries : stack_entries, stream_entries_secondary = stream ? ctx->stream_lds_entries_secondary : stack_entries;
+  const uint32_t stream_entries = stream ? ctx->stream_lds_entries : stream_need, stream_entries_secondary = stream ? ctx->stream_lds_entries_secondary : stream_need;
   const uint32_t stream_stack_bytes = lds_stack_bytes(stream_entries), stream_stack_bytes_secondary = lds_stack_bytes(stream_entries_secondary);
   auto wgs_for = [&](uint32_t bytes, uint32_t static_lds, uint32_t compiled_for, uint32_t reported) {
     uint32_t w = tun.lds_per_cu / (bytes + static_lds);
@@ -2085,8 +2111,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_closest;
   const uint32_t stream_grid_secondary = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_secondary;
   // spill area of the streaming launches: [launch in flight: pass slot x (closest, secondary)][entry beyond the LDS part][thread of the launch]
-  const uint32_t spill_entries = stream_entries < stack_entries ? stack_entries - stream_entries : 0u;
-  const uint32_t spill_entries_secondary = stream_entries_secondary < stack_entries ? stack_entries - stream_entries_secondary : 0u;
+  const uint32_t spill_entries = stream_entries < stream_need ? stream_need - stream_entries : 0u;
+  const uint32_t spill_entries_secondary = stream_entries_secondary < stream_need ? stream_need - stream_entries_secondary : 0u;
   const size_t spill_threads = (size_t)(stream_grid > stream_grid_secondary ? stream_grid : stream_grid_secondary) * kBlock;
   const size_t spill_region = (size_t)(spill_entries > spill_entries_secondary ? spill_entries : spill_entries_secondary) * spill_threads;  // uint2 each
   if (spill_region * 6u > ctx->stack_spill_capacity) {
