@@ -443,21 +443,22 @@ struct GroupStack<true> {
   uint8_t* mask;
   int sp = 0;
   int cap = kBvh8Stack;
-  uint2* over = nullptr;   // this thread's column of the spill area
+  uint2* over = nullptr;   // the spill area of the launch (wave-uniform: it stays in scalar registers; the thread's column is formed where an entry is spilled)
   uint32_t ostride = 0;    // threads of the launch
   FH_D GroupStack(uint2* block_lds, int depth) : word((uint32_t*)block_lds + threadIdx.x), mask((uint8_t*)((uint32_t*)block_lds + depth * 256) + threadIdx.x) {}
-  FH_D GroupStack(uint2* block_lds, int depth, uint2* spill, uint32_t threads, uint32_t thread)
-      : word((uint32_t*)block_lds + threadIdx.x), mask((uint8_t*)((uint32_t*)block_lds + depth * 256) + threadIdx.x), cap(spill ? depth : kBvh8Stack), over(spill ? spill + thread : nullptr), ostride(threads) {}
+  FH_D GroupStack(uint2* block_lds, int depth, uint2* spill, uint32_t threads, uint32_t)
+      : word((uint32_t*)block_lds + threadIdx.x), mask((uint8_t*)((uint32_t*)block_lds + depth * 256) + threadIdx.x), cap(spill ? depth : kBvh8Stack), over(spill), ostride(threads) {}
+  FH_D uint2* over_at(int level) const { return over + ((size_t)(uint32_t)(level - cap) * ostride + (blockIdx.x * blockDim.x + threadIdx.x)); }
   FH_D void push(uint2 g)
   {
     if (sp < cap) { word[sp * 256] = (g.x << 8) | (g.y >> 24); mask[sp * 256] = (uint8_t)g.y; }
-    else over[(size_t)(uint32_t)(sp - cap) * ostride] = g;
+    else *over_at(sp) = g;
     ++sp;
   }
   FH_D uint2 pop()
   {
     --sp;
-    if (sp >= cap) return over[(size_t)(uint32_t)(sp - cap) * ostride];
+    if (sp >= cap) return *over_at(sp);
     const uint32_t w = word[sp * 256];
     return make_uint2(w >> 8, (w << 24) | mask[sp * 256]);
   }
@@ -558,19 +559,27 @@ struct CoopLds {            // per-wave slices of the block's LDS
 #define FH_ALPHA_FLUSH 16
 #endif
 #ifndef FH_ALPHA_DEFER_MIXED
-#define FH_ALPHA_DEFER_MIXED 0  // (1, measured: park candidates in the kernels whose rays stop at their first hit as well)
+#define FH_ALPHA_DEFER_MIXED 0  // 1 (measured twice, r4-19 and r5-3): park candidates in the kernels whose rays stop at their first hit as well
+#endif
+#ifndef FH_ALPHA_SUSPEND
+#define FH_ALPHA_SUSPEND 1      // a ray that stops at its first hit WAITS while a candidate of its is parked (0: it goes on walking the tree, round 4's r4-19 loss)
 #endif
 constexpr uint32_t kAlphaRing = 32, kAlphaFlush = FH_ALPHA_FLUSH;
 // which streaming kernels park: the closest-hit launch.  A ray that stops at its first hit (every secondary ray of a scene without emitters) is finished by the first candidate
-// that passes, and parked it goes on walking the tree until the ring is worked off: secondary 760 -> 835 ms per 512 spp of configs[3] with parking, closest 357 -> 329
+// that passes, and parked it goes on walking the tree until the ring is worked off: secondary 760 -> 835 ms per 512 spp of configs[3] with parking, closest 357 -> 329 (r4-19).
+// Round 5 built what that suggests -- the owner of a parked candidate SUSPENDED (FH_ALPHA_SUSPEND: a bit per lane next to the ring's counter, set by whoever parks, cleared
+// by alpha_flush, takes the lane out of the node visits and counts it as idle for the refill trigger) -- and measured it on the same box: secondary 752 ms testing in place,
+// 831 parked and walking on, 876 parked and suspended (profiles/README.md r5-3).  The loss is not the walking: it is the ring's LDS (seven stack levels in LDS become five),
+// 32 bytes of scratch instead of 16, and lanes that wait for a round of sixteen.  In place it stays.
 template <bool MIXED, bool ALPHA>
 struct AlphaDefer { static constexpr bool value = ALPHA && (!MIXED || FH_ALPHA_DEFER_MIXED != 0); };
 constexpr uint32_t kAlphaLdsBytesPerWave = kAlphaRing * 16 + 16;
 constexpr uint32_t kAlphaLdsBytesPerBlock = 4u * kAlphaLdsBytesPerWave;
+FH_D unsigned long long* alpha_suspended(const CoopLds& cl) { return (unsigned long long*)(cl.aring + kAlphaRing) + 1; }  // lanes whose first-hit ray waits for a parked candidate
 FH_D void alpha_ring(CoopLds& cl, unsigned char* block_lds, uint32_t wave_in_block)
 {
   cl.aring = (uint4*)(block_lds + (size_t)wave_in_block * kAlphaLdsBytesPerWave);
-  if (__lane_id() == 0u) *(uint32_t*)(cl.aring + kAlphaRing) = 0u;
+  if (__lane_id() == 0u) { *(uint32_t*)(cl.aring + kAlphaRing) = 0u; *alpha_suspended(cl) = 0ull; }
 }
 constexpr uint32_t kCoopLdsBytesPerWave = 64 * 32 + 64 * 8 + 64 * 8 + kCoopQueue * 4;
 // static LDS of one 256-thread workgroup of a cooperative / streaming traversal kernel (the stack comes on top, dynamically)
@@ -609,7 +618,11 @@ FH_D void coop_test(const Bvh8Dev& bvh, const CoopLds& cl, uint32_t e, uint32_t&
   if (ALPHA && bb.w != 0.0f) {
     if (DEFER) {  // park it (above); a full ring: test in place (face ids stay below 2^26: the builder refuses trees of 2^23 nodes)
       const uint32_t pos = atomicAdd((uint32_t*)(cl.aring + kAlphaRing), 1u);
-      if (pos < kAlphaRing) { cl.aring[pos] = make_uint4((owner << 26) | prim, __float_as_uint(t), __float_as_uint(bu), __float_as_uint(bv)); return; }
+      if (pos < kAlphaRing) {
+        cl.aring[pos] = make_uint4((owner << 26) | prim, __float_as_uint(t), __float_as_uint(bu), __float_as_uint(bv));
+        if (ANY_HIT && FH_ALPHA_SUSPEND && r1.w != 0.0f) atomicOr(alpha_suspended(cl), 1ull << owner);  // the owner's ray stops at its first hit: it waits for this one (traverse_stream)
+        return;
+      }
     }
     if (!alpha_pass(*sc, prim, bu, bv)) return;
   }
@@ -635,7 +648,7 @@ FH_D void alpha_flush(const CoopLds& cl, const SceneDev* sc, uint32_t at_least)
       if (cl.key[owner] == mine) cl.uv[owner] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
     }
   }
-  if (__lane_id() == 0u) *counter = 0u;
+  if (__lane_id() == 0u) { *counter = 0u; if (ANY_HIT && FH_ALPHA_SUSPEND) *alpha_suspended(cl) = 0ull; }
 }
 
 // MODE 0: every ray wants its closest hit; 1: every ray stops at its first hit; 2: per lane (`any_lane`), as in the streaming kernels
@@ -729,6 +742,9 @@ FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float t
 #ifndef FH_HANDOVER_SCAN
 #define FH_HANDOVER_SCAN 1
 #endif
+#ifndef FH_BOTTOM_UP_BUILD
+#define FH_BOTTOM_UP_BUILD 0  // (1: the streaming kernels can start rays below the root, traverse_stream; FH_BOTTOM_UP=1 then switches it on)
+#endif
 #ifndef FH_HANDOVER_SCAN_ALPHA
 #define FH_HANDOVER_SCAN_ALPHA 1  // (0: the kernels with the any-hit test keep the ballot rounds -- the scan's registers can push them into scratch)
 #endif
@@ -810,6 +826,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   // neighbours of the face the ray leaves come first) and is 10 % slower.  Hits do not depend on the order nodes are visited in (closest: minimum over the
   // accepted candidates, none of which a conservative node test can cull; first-hit: a yes / no), so the bits do not change.
   // State: `up` (the lane's ray still has levels to climb) and entry 0 of the lane's stack (GroupStack::set_anchor); the groups of the subtree being walked sit above it.
+  // Compiled in with -DFH_BOTTOM_UP_BUILD=1 only (tools/build_variant.sh): even switched off the climb costs the kernels with the any-hit test registers they do not have.
   bool up = false;
   Ray8 r;
   r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct = 0u; r.nx = r.ny = r.nz = false;
@@ -821,8 +838,11 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   bool dry = false;                  // wave-uniform: a refill found no work at all
   uint32_t ray_n0 = 0;               // instrumented build: node counter when the lane's ray started
   cl.key[lane] = 0ull;
+  constexpr bool kSuspend = AlphaDefer<MIXED, ALPHA>::value && MIXED && FH_ALPHA_SUSPEND != 0;
   for (;;) {
-    const unsigned long long idle = __ballot(!busy);
+    // (lanes whose first-hit ray has a candidate parked for its any-hit test wait: they take no node visit and count as idle, coop_test / alpha_flush)
+    const bool waiting = kSuspend && ((*alpha_suspended(cl) >> lane) & 1ull) != 0ull;
+    const unsigned long long idle = __ballot(!busy || waiting);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
     if (n_idle == 64u || (!dry && n_idle >= refill)) {
       // every candidate of a finished ray must be tested before the ray is committed: drain the queue
@@ -862,7 +882,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
           cl.uv[lane] = make_float2(0.0f, 0.0f);
           stack.sp = 0;
           have = true;
-          const uint32_t start = bvh.parent ? pol.start_node() : 0u;
+          const uint32_t start = (FH_BOTTOM_UP_BUILD && bvh.parent) ? pol.start_node() : 0u;
           up = start != 0u;
           if (up) { stack.set_anchor(start, 8u); stack.sp = 1; }
           group = make_uint2(start, 0x80000000u);  // (hit bit 7 of a group without inner-child bits: node group.x itself)
@@ -878,18 +898,19 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
     }
     uint2 tg = make_uint2(0u, 0u);
     float best_t = 0.0f;
-    if (busy) {
+    bool walk = busy && !(kSuspend && ((*alpha_suspended(cl) >> lane) & 1ull) != 0ull);  // (read again: a refill above has worked the ring off)
+    if (walk) {
       const unsigned long long k = cl.key[lane];
       best_t = __uint_as_float((uint32_t)(k >> 32));
-      if (MIXED && any && (uint32_t)k != 0xffffffffu) busy = false;
+      if (MIXED && any && (uint32_t)k != 0xffffffffu) busy = walk = false;
     }
     bool climbing = false;  // this visit is the parent of the subtree just finished
-    if (busy && (group.y & 0xff000000u) == 0u) {
+    if (walk && (group.y & 0xff000000u) == 0u) {
       if (stack.sp == (up ? 1 : 0)) {
-        if (!up) busy = false;
+        if (!up) busy = walk = false;
         else {
           const uint32_t link = bvh.parent[stack.anchor()];
-          if (link == 0xffffffffu) busy = false;  // the root's subtree is done
+          if (link == 0xffffffffu) busy = walk = false;  // the root's subtree is done
           else {
             stack.set_anchor(link >> 3, link & 7u);
             group = make_uint2(link >> 3, 0x80000000u);
@@ -900,7 +921,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
     }
 #if FH_NODE_FETCH_PAIR
     uint32_t ni = 0u;
-    if (busy) {
+    if (walk) {
       const uint32_t hits_imask = group.y;
       const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
       group.y &= ~(1u << bit);
@@ -911,12 +932,12 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
     }
     {
       uint4 n0, n1, n2, n3;
-      node8_fetch_pair(bvh, busy, ni, n0, n1, n2, n3);  // (all 64 lanes)
-      if (busy) node8_eval(r, ni, n0, n1, n2, n3, best_t, group, tg);
-      if (busy && climbing) group.y &= ~(1u << (24u + (stack.anchor_skip() ^ r.oct)));
+      node8_fetch_pair(bvh, walk, ni, n0, n1, n2, n3);  // (all 64 lanes)
+      if (walk) node8_eval(r, ni, n0, n1, n2, n3, best_t, group, tg);
+      if (walk && climbing) group.y &= ~(1u << (24u + (stack.anchor_skip() ^ r.oct)));
     }
 #else
-    if (busy) {
+    if (walk) {
       const uint32_t hits_imask = group.y;
       const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
       group.y &= ~(1u << bit);
