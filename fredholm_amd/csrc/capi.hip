@@ -441,6 +441,8 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_TAIL_PATHS", 64, 1 << 30, t.tail_paths);
     env_off("FH_SORT", t.sort_queues);
     env_off("FH_BOTTOM_UP", t.bottom_up);
+    env_uint("FH_SUBPASS", 1, 3, t.sub_passes);
+    env_uint("FH_SUBPASS_MIN", 1, 1 << 30, t.sub_pass_min_paths);
     t.debug_tail = getenv("FH_DEBUG_TAIL") != nullptr;
     if (const char* e = getenv("FH_NO_ALPHA")) t.ignore_alpha = e[0] == '1';
     if (const char* e = getenv("FH_FORCE_ALPHA")) t.force_alpha = e[0] == '1';

@@ -175,6 +175,8 @@ struct fh_ctx {
                                          // whose items are whole paths with two to four rays each, loses with more than 64: 113.9 -> 115.7 ms at 128)
     uint32_t tail_depth = 0;        // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail
     uint32_t tail_paths = 0;        // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail; 0 = 65536, 262144 for passes of at most 4 Mi paths
+    uint32_t sub_passes = 1;        // FH_SUBPASS=n (measured, profiles/README.md r5-4; off): a call that fits one pass is cut into n pixel sub-passes on the pass streams
+    uint32_t sub_pass_min_paths = 1u << 19;  // FH_SUBPASS_MIN: ... from this many camera paths on
     bool bottom_up = false;         // FH_BOTTOM_UP=1 (measured, profiles/README.md r5-2; off): rays that leave a surface start their traversal at the wide node that holds the face and climb
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
     bool debug_tail = false;        // FH_DEBUG_TAIL

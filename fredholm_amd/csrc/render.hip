@@ -2135,6 +2135,27 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const bool sort_queues = tun.sort_queues && (stream || tun.sort_small);
   const bool shade_three = tun.shade_wgs ? tun.shade_wgs == 3u : (stream && sc.n_textures > 0);  // (above, FH_SHADE_BLOCKS)
 
+  // ---- Small calls (the reference's callers: 1 sample per call in the GUI, controller.cpp:224, 16 in rtcamp8, rtcamp8.cpp:183-189).  A call that fits ONE pass is a chain of
+  // ~50 launches, each of which ends in its few longest rays with the chip nearly idle, and the chain is as long as those ends added up.  Such a call is cut into PIXEL
+  // sub-passes instead: the owned pixels in three contiguous ranges, each range a pass of its own in its own pool on its own stream.  Nothing orders them but what orders any
+  // two passes (below) -- they share no pixel -- so one range's ends run under another's bulk.  Sampler keys are per pixel: same bits.  MEASURED (r5-4) and OFF (FH_SUBPASS=3
+  // switches it on): 1-spp frames get SLOWER, configs[3] 6.45 -> 8.24 ms with three ranges and 7.56 with two, configs[2] 1.95 -> 2.59 / 1.95; 16-spp frames are unchanged
+  // (configs[1]: 13.6 -> 12.8 ms).  Three times the launches cost the host three times the submission, and the chains do not leave the chip as idle as their length suggests.
+  uint32_t n_sub = 1;
+  {
+    const bool one_pass = batch >= n_samples;
+    const bool serial_call = quirk || (ctx->flags & FH_FLAG_SERIAL_PASSES) != 0;
+    if (one_pass && !serial_call && !count && ctx->n_slots >= 2 && tun.sub_passes > 1u && (unsigned long long)n_px * n_samples >= (unsigned long long)tun.sub_pass_min_paths) n_sub = tun.sub_passes < (uint32_t)ctx->n_slots ? tun.sub_passes : (uint32_t)ctx->n_slots;
+  }
+  const uint32_t* const px_list_all = px_list;
+  const uint32_t* const xy_list_all = xy_list;
+  const uint32_t n_px_all = n_px;
+  for (uint32_t sub = 0; sub < n_sub; ++sub) {
+  if (n_sub > 1) {  // pixels [lo, hi) of the list (whole 64-pixel runs, so that a wave of k_generate does not straddle two sub-passes)
+    const uint32_t per = ((n_px_all + n_sub - 1u) / n_sub + 63u) & ~63u;
+    const uint32_t lo = sub * per < n_px_all ? sub * per : n_px_all, hi = lo + per < n_px_all ? lo + per : n_px_all;
+    px_list = px_list_all + lo; xy_list = xy_list_all + lo; n_px = hi - lo;
+  }
   for (uint32_t done = 0; done < n_samples && n_px; done += batch) {
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
     const uint32_t n_paths = n_px * nb;
@@ -2159,7 +2180,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     const bool single_pass = !serial && batch >= n_samples && n_samples == nb;
     // ... or, where the streaming kernels trace the scene, both in ONE launch (k_trace_merged_stream): one end instead of two, no second stream (FH_MERGE=0: the two-stream form)
     const bool merge = single_pass && stream && !count && tun.merge_trace;
-    const bool overlap = single_pass && tun.overlap_secondary && !merge;
+    const bool overlap = single_pass && tun.overlap_secondary && !merge && n_sub == 1;  // (pixel sub-passes: the other streams carry the other pixel ranges)
     hipStream_t sb = st;
     if (overlap) {
       sb = (st == ctx->aux_stream[0]) ? ctx->aux_stream[1] : ctx->aux_stream[0];
@@ -2340,6 +2361,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       ctx->counters_wave_depth[slot] = wave_depth;
     }
   }
+  }  // (pixel sub-passes)
   // join: later work on the main stream (pack, post-process, copies, the caller's clears) sees every pass of this call
   // (the accumulates form a chain across the streams, so the last one implies all the others)
   if (last_slot != 0 && n_px) FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_acc[last_slot], 0));
