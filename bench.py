@@ -82,6 +82,42 @@ def issue_model():
     return {"node": NODE_TEST_SIMD_CYCLES, "tri": TRI_TEST_SIMD_CYCLES, "source": ISSUE_MODEL_SOURCE, "stale": True}
 
 
+def fma_share_of(kernel):
+    """static share of FMA-class instructions among the VALU instructions of `kernel`'s code object: the newest profiles/r*_isa_fma_share.json (tools/isa_fma_share.py) that
+    lists it; None without one.  `stale`: counted on other device sources than this library's."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_fma_share.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+            k = j["kernels"].get(kernel)
+            if k:
+                return {"share": float(k["share"]), "source": os.path.relpath(f, ROOT), "stale": j.get("source_fingerprint") != source_fingerprint()}
+        except Exception:
+            continue
+    return None
+
+
+def scaling_model(cfg, spp):
+    """EMULATED strong scaling of the render phase: one GPU rendered each of the 8 tile shards of this configuration in turn (tools/shard_time.py -> profiles/r*_shard_times.jsonl);
+    whole frame / slowest shard.  Not a measurement of eight GPUs: no gather, no second device.  The row of the nearest frame length is quoted."""
+    import glob
+    rows = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_shard_times.jsonl")), reverse=True):
+        try:
+            rows = [dict(json.loads(ln), file=os.path.relpath(f, ROOT)) for ln in open(f) if ln.startswith("{")]
+        except Exception:
+            continue
+        rows = [x for x in rows if x.get("config") == cfg and x.get("tile") == 32]
+        if rows:
+            break
+    if not rows:
+        return None
+    x = min(rows, key=lambda x: abs(x["spp"] - spp))
+    return {"emulated": True, "world": x["world"], "spp": x["spp"], "whole_ms": x["whole_ms"], "slowest_shard_ms": x["max_ms"], "mean_shard_ms": x["mean_ms"], "max_over_mean": x["max_over_mean"],
+            "render_speedup": x["render_speedup_whole_over_max"], "efficiency": x["efficiency"], "from": x["file"],
+            "note": "one GPU rendered each rank's 32x32-tile shard in turn (tools/shard_time.py): render phase only -- the RCCL gather (4.15 MB per rank at 1080p) and rank 0's un-permutation are not in it"}
+
+
 def traversal_roofline(cnt, timed, key, steps, launches, avg_ms, avg_alone_ms, bytes_per_launch, kernel_name, where, bw, traffic):
     """bound: VALU issue.  `achieved` = SIMD issue cycles per second that went into the kernel's essential work -- its wave-level node tests and triangle tests (counted by the
     instrumented replay), each at the cycles it costs a SIMD when nothing but issue limits it -- `peak` = the issue cycles the chip has: 1024 SIMDs x the nominal 2.4 GHz.  Everything
@@ -327,24 +363,27 @@ def refuse_bad_fracs(obj, path=""):
     return bad
 
 
-def pass_size(r, torch, local_rank, n_owned, spp, pool_spp_arg=0):
-    """samples per pixel per pass of the path pool.  Big passes amortise what a pass pays once (its longest rays, the ends of the streaming launches): 64 / 96 / 128 spp of a 1080p
-    frame per pass measure 5874 / 6178 / 6312 Msamples/s on configs[2].  A step is split into equal passes of at most ~128 spp of a 1080p frame, of at most 3/4 of the device memory
-    still free for all pools together (minus 2 GiB for what RCCL and the bandwidth probe allocate later), and into at least three passes, so that the library's
-    three-passes-in-flight pipelining has something to overlap inside a step"""
+DEFAULT_POOL_GB = 72.0  # device memory of all path pools together in the default run: a quarter of an MI355X's HBM (profiles/r05_pool_sweep.json: within 1-2 % of what 218 GB buy)
+
+
+def pass_size(r, torch, local_rank, n_owned, spp, pool_spp_arg=0, pool_gb=0.0):
+    """samples per pixel per pass the path pools have room for (fh_set_path_pool takes owned pixels x this).  Big passes amortise what a pass pays once (its longest rays, the
+    ends of the streaming launches), at 284-436 bytes per path in flight and three pools.  The budget is a memory figure: --pool-gb, by default DEFAULT_POOL_GB, never more than
+    3/4 of the device memory still free (minus 2 GiB for what RCCL and the bandwidth probe allocate later).  The library cuts a step into equal passes of what fits (of the pixels
+    that can see the scene: where most pixels cannot, a pass takes more samples than this figure says) and allocates a pool for the paths its passes really start, so the memory
+    held afterwards (config.path_pools.gb) is at most the budget.  profiles/r05_pool_sweep.json has throughput against budget for configs[2] and [3]."""
     slot_bytes, n_pools = r.path_pool_bytes()
     if pool_spp_arg > 0:
         return pool_spp_arg, slot_bytes, n_pools
+    budget = (pool_gb if pool_gb > 0 else DEFAULT_POOL_GB) * 1e9
     try:
-        free_bytes = max(torch.cuda.mem_get_info(local_rank)[0] - (2 << 30), 1 << 30)
-    except Exception:  # (no memory query: the pass size of rounds 1-2, 64 spp of a 1080p frame, fits any MI355X)
-        free_bytes = int(1920 * 1080 * 64 * 1.02) * n_pools * slot_bytes / 0.75
-    cap = min(int(1920 * 1080 * 128 * 1.02), int(0.75 * free_bytes / (n_pools * slot_bytes)))  # 2 % slack: tile ownership is not perfectly even across ranks
-    passes = max(3, -(-n_owned * spp // cap))
-    return max(-(-spp // passes), 1), slot_bytes, n_pools
+        budget = min(budget, 0.75 * max(torch.cuda.mem_get_info(local_rank)[0] - (2 << 30), 1 << 30))
+    except Exception:  # (no memory query: the budget as given)
+        pass
+    return max(budget / (n_pools * slot_bytes) / max(n_owned, 1), 1.0 / max(n_owned, 1)), slot_bytes, n_pools
 
 
-def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1):
+def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1, pool_gb=0.0):
     """The general-scene leg of the default run (outside the headline's timed region): BASELINE.json configs[3] -- the Sponza-class textured interior, where every camera ray
     hits and a sample is 1.7 closest-hit + 4.6 secondary rays -- for `steps` frames of `spp` samples, plus the reference's own call pattern on it (1 and 16 samples per call,
     app/controller.cpp:205-230, app/rtcamp8.cpp:183-189), the dominant traversal kernel's roofline record and a parity crop against the CPU checker.  configs[2], the headline,
@@ -366,8 +405,8 @@ def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1):
     bufs = {n: torch.zeros((H, W) if n == "depth" else (H, W, 4), dtype=torch.float32, device=dev) for n in F.RenderLayer.NAMES}
     layers = F.RenderLayer(r, W, H, pointers={n: t.data_ptr() for n, t in bufs.items()})
     n_owned = r.owned_pixel_count()
-    pool_spp, slot_bytes, n_pools = pass_size(r, torch, local_rank, n_owned, spp)
-    r.set_path_pool(n_owned * pool_spp)
+    pool_spp, slot_bytes, n_pools = pass_size(r, torch, local_rank, n_owned, spp, 0, pool_gb)
+    r.set_path_pool(max(int(n_owned * pool_spp), 1))
     for _ in range(warmup):
         r.render(cam, w["bg"], layers, spp, D)
     r.wait_for_completion()
@@ -380,6 +419,7 @@ def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1):
         r.wait_for_completion()
     dt = time.perf_counter() - t0
     timed = r.stats()
+    pool_bytes_timed, pool_paths_timed = r.path_pool_allocated()
     r.set_flags(N.FLAG_TIME_KERNELS | N.FLAG_SERIAL_PASSES)
     r.reset_stats()
     r.render(cam, w["bg"], layers, spp, D)
@@ -410,8 +450,15 @@ def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1):
         roof["counters_stale"] = not (pmc_k.get("source_fingerprint") == source_fingerprint())
         if pmc_k.get("traffic_bytes_per_launch") and f["alone"] > 0:
             roof["frac_hbm_measured"] = round(pmc_k["traffic_bytes_per_launch"] / (f["alone"] / max(launches / steps, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        fs = fma_share_of(pmc_k.get("kernel", ""))
+        if fs and pmc_k.get("valu_insts_per_launch") and f["alone"] > 0:  # (as in the headline's record: executed VALU instructions per cycle and SIMD x the issue cycles of the kernel's static mix)
+            per_cycle = pmc_k["valu_insts_per_launch"] / N_SIMDS / (f["alone"] / max(launches / steps, 1) * 1e-3) / 1e9 / (roof.get("clock_ghz_in_kernel") or NOMINAL_CLOCK_GHZ)
+            cyc_mix = max(fs["share"] / VALU_FMA_PEAK_PER_CYCLE, (1.0 - fs["share"]) / VALU_OTHER_PEAK_PER_CYCLE)
+            roof["valu_busy_measured"] = round(per_cycle * cyc_mix, 4)
+            roof["valu_busy_formula"] = {"insts_per_cycle_per_simd": round(per_cycle, 4), "fma_class_share_static": fs["share"], "share_from": fs["source"], "share_stale": fs["stale"]}
     paths = max(cnt["paths"], 1)
-    out = {"workload": w["name"], "msamples_per_s": round(W * H * spp * steps / dt / 1e6, 2), "ms_per_step": round(dt / steps * 1e3, 3), "spp_per_step": spp, "spp_per_pass": pool_spp,
+    out = {"workload": w["name"], "msamples_per_s": round(W * H * spp * steps / dt / 1e6, 2), "ms_per_step": round(dt / steps * 1e3, 3), "spp_per_step": spp, "spp_per_pass": round(pool_spp, 3) if isinstance(pool_spp, float) else pool_spp,
+           "passes_per_step": round(timed["n_passes"] / max(steps, 1), 2), "path_pools": {"gb": round(pool_bytes_timed / 1e9, 1), "paths": int(pool_paths_timed)},
            "steps": steps, "warmup": warmup, "triangles": int(w["scene"]["indices"].shape[0]),
            "note": "BASELINE.json configs[3] at a shorter frame than its 4096 spp (throughput does not depend on the frame length beyond three passes: 512 / 4096 spp measure within 1 %)",
            "roofline": roof,
@@ -437,6 +484,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4), help="BASELINE.json configs[] index (default 2: the configuration the metric is quoted on)")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step; 0 = the configuration's (one fh_render call = one presented frame)")
     ap.add_argument("--pool-spp", type=int, default=0, help="samples per pixel per pass of the path pool; 0 = equal passes of at most ~128 spp of a 1080p frame and 3/4 of the free device memory, at least three per step")
+    ap.add_argument("--pool-gb", type=float, default=0.0, help="device memory of all path pools together in GB (the library then cuts a step into as many equal passes as that needs); 0 = see --pool-spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras of the N = 1 line (parity crop, small-launch latency)")
     ap.add_argument("--no-general-scene", action="store_true", help="skip the configs[3] leg the default (configs[2], N = 1) run appends as `general_scene`")
@@ -509,8 +557,8 @@ def main():
     if world > 1:  # wrong device binding, unequal shard shapes, a rendezvous the environment does not describe: fail here, not in step 1 (tools/rccl_gather_probe.py runs the same check alone)
         D.preflight(dist, dev, pad)
     # path-pool slots = owned pixels x samples per pass, one pool per pass in flight (pass_size above)
-    pool_spp, slot_bytes, n_pools = pass_size(r, torch, local_rank, n_owned, spp, args.pool_spp)
-    r.set_path_pool(n_owned * pool_spp)
+    pool_spp, slot_bytes, n_pools = pass_size(r, torch, local_rank, n_owned, spp, args.pool_spp, args.pool_gb)
+    r.set_path_pool(max(int(n_owned * pool_spp), 1))
     bw_read, bw_copy = r.measure_bandwidth(1 << 30, 6) if rank == 0 else (0.0, 0.0)  # measured HBM roofline of this GPU
     torch.cuda.synchronize()
 
@@ -572,6 +620,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     timed = r.stats()
+    pool_bytes_timed, pool_paths_timed = r.path_pool_allocated()
 
     # ---- which kernel dominates: with two passes in flight a HIP-event span also contains the other stream's work (the register-heavy shade
     # kernels wait for CUs the traversal kernels hold), so the ranking comes from one more, untimed step whose passes run one after the other
@@ -686,6 +735,14 @@ def main():
                 roof["frac_hbm_measured"] = roof["hbm_traffic_frac"] = round(traffic / (avg_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             if pmc_k.get("valu_insts_per_launch"):
                 per_cycle = pmc_k["valu_insts_per_launch"] / N_SIMDS / (avg_alone_ms * 1e-3) / 1e9 / (roof.get("clock_ghz_in_kernel") or NOMINAL_CLOCK_GHZ)
+                fs = fma_share_of(pmc_k.get("kernel", ""))
+                if fs:
+                    # MEASURED VALU busy share: executed VALU instructions per cycle and SIMD (SQ_INSTS_VALU of the counter run / this run's launch time alone x 1024 SIMDs x the clock held)
+                    # x the issue cycles an instruction of the kernel's static mix costs (FMA-class 2.2, everything else 4.1 cycles, the two classes side by side)
+                    cyc_mix = max(fs["share"] / VALU_FMA_PEAK_PER_CYCLE, (1.0 - fs["share"]) / VALU_OTHER_PEAK_PER_CYCLE)
+                    roof["valu_busy_measured"] = round(per_cycle * cyc_mix, 4)
+                    roof["valu_busy_formula"] = {"fma_class_share_static": fs["share"], "share_from": fs["source"], "share_stale": fs["stale"], "cycles_per_instruction_of_this_mix": round(cyc_mix, 3),
+                                                 "is": "SQ_INSTS_VALU per launch / (avg_launch_ms_alone x 1024 SIMDs x clock_ghz_in_kernel) x max(share x 2.2, (1 - share) x 4.1)"}
                 roof["valu"] = {"insts_per_launch": pmc_k["valu_insts_per_launch"], "insts_per_cycle_per_simd": round(per_cycle, 4),
                                 "peak_per_cycle_per_simd": {"fma_mul_add_f32": round(VALU_FMA_PEAK_PER_CYCLE, 3), "everything_else": round(VALU_OTHER_PEAK_PER_CYCLE, 3)},
                                 "lane_utilisation": pmc_k.get("valu_lane_utilisation"), "wait_any_frac_of_wave_cycles": pmc_k.get("wait_any_frac_of_wave_cycles")}
@@ -724,9 +781,10 @@ def main():
             "metric": "Msamples/s at 1920x1080, max_depth=8" if args.config in (1, 2, 3) else f"Msamples/s at {WIDTH}x{HEIGHT}, max_depth={MAX_DEPTH}", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": w["name"], "spp_per_step": spp, "spp_per_pass": pool_spp, "passes_per_step": round(timed["n_passes"] / max(steps, 1), 2),
+            "config": {"workload": w["name"], "spp_per_step": spp, "spp_per_pass": round(pool_spp, 3) if isinstance(pool_spp, float) else pool_spp, "passes_per_step": round(timed["n_passes"] / max(steps, 1), 2),
                        "sky_pixel_sample_share": round(timed["sky_pixel_samples"] / max(timed["paths"], 1), 4),  # samples of pixels no ray of which can reach the scene bounds: rendered by k_sky_pixels, outside the passes (the path pools hold the other pixels only, so a pass takes more samples of them than spp_per_pass)
-                       "path_pools": {"pools": n_pools, "bytes_per_path": slot_bytes, "gb": round(n_pools * slot_bytes * n_owned * pool_spp / 1e9, 1)}, "triangles": int(sc["indices"].shape[0]), "parallelism": f"pixel-tile x{world}" if world > 1 else "single GPU",
+                       "path_pools": {"pools": n_pools, "bytes_per_path": slot_bytes, "gb": round(pool_bytes_timed / 1e9, 1), "paths": int(pool_paths_timed), "budget_gb": round(n_pools * slot_bytes * n_owned * pool_spp / 1e9, 1),
+                                      "note": "gb = device memory the pools held after the timed region (fh_path_pool_allocated): a pool is allocated for the paths its passes start, pixels that can see the scene x samples per pass; budget_gb = what the caller allowed (fh_set_path_pool)"}, "triangles": int(sc["indices"].shape[0]), "parallelism": f"pixel-tile x{world}" if world > 1 else "single GPU",
                        "gather": "RCCL gather of packed float4 beauty tiles to rank 0 + fh_unpack_shard, inside the timed region" if world > 1 else "none",
                        "post": "bloom + chromatic aberration + tone map on the whole frame, inside the timed region" if post else "none"},
             "step_ms": {"min": round(sm[0], 3), "median": round(sm[len(sm) // 2], 3), "max": round(sm[-1], 3)},
@@ -746,6 +804,10 @@ def main():
                if post else {}),
             "bvh": {"build_ms": round(timed["bvh_build_ms"], 2), "nodes": timed["bvh_nodes"], "node_bytes": timed["bvh_node_bytes"], "tri_bytes": timed["bvh_tri_bytes"], "depth": timed["bvh_depth"]},
         }
+        if world == 1:
+            sm_ = scaling_model(args.config, spp)
+            if sm_:
+                out["scaling_model"] = sm_
         if extras:
             rows = (HEIGHT // 2 - 4, HEIGHT // 2 + 4)  # eight rows through the middle of the frame (every configuration has geometry there)
             out["parity"] = parity_block(r, w, cam, layers2, bufs2, rows, 2)
@@ -756,7 +818,7 @@ def main():
         if extras and args.config == 2 and not args.no_general_scene:
             r.close()  # (the headline's path pools go back to the device first)
             r = None
-            out["general_scene"] = general_scene_block(local_rank, tmp.name, (bw_read, bw_copy))
+            out["general_scene"] = general_scene_block(local_rank, tmp.name, (bw_read, bw_copy), pool_gb=args.pool_gb)
         refused = refuse_bad_fracs(out)
         if refused:
             out["fractions_refused"] = [{"field": k, "value": v} for k, v in refused]

@@ -540,6 +540,15 @@ int fh_path_pool_bytes(fh_ctx* ctx, uint64_t* bytes_per_path, uint32_t* pools)
   return FH_OK;
 }
 
+int fh_path_pool_allocated(fh_ctx* ctx, uint64_t* bytes, uint64_t* paths)
+{
+  CTX_CHECK(ctx);
+  if (!bytes || !paths) return fail(ctx, FH_E_INVALID, "fh_path_pool_allocated: null argument");
+  *bytes = 0; *paths = 0;
+  for (int k = 0; k < 3; ++k) { *bytes += ctx->pool_alloc_bytes[k]; *paths += ctx->pool[k].capacity; }
+  return FH_OK;
+}
+
 int fh_set_tail_depth(fh_ctx* ctx, uint32_t depth)
 {
   CTX_CHECK(ctx);

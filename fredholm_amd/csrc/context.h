@@ -125,6 +125,7 @@ struct fh_ctx {
   struct PoolShape { bool dir = false, lights = false; uint32_t classes = 0; };  // what the records of a pool have room for (render.hip: pool_ensure)
   PoolShape pool_shape[3];
   std::vector<void*> pool_allocs[3];
+  unsigned long long pool_alloc_bytes[3] = {0, 0, 0};  // device memory the allocations of each pool hold (fh_path_pool_allocated)
   // 32 Mi path slots per pool: 16 samples per pixel per pass at 1080p.  Three pools (one per pass in flight) of 284-436 bytes per path are 27-42 GB when a call brings enough
   // samples to fill them; unless the caller chose the size (fh_set_path_pool), fh_render keeps all pools together within half of the device memory that is free when the first one is made
   uint32_t pool_target_default = 1u << 25, pool_target = 1u << 25;  // (pool_target: the default as capped by the free device memory whenever a pool is (re)allocated, or the caller's size)

@@ -1712,6 +1712,7 @@ void pool_release(fh_ctx* ctx)
   for (int k = 0; k < 3; ++k) {
     for (void* p : ctx->pool_allocs[k]) (void)hipFree(p);
     ctx->pool_allocs[k].clear();
+    ctx->pool_alloc_bytes[k] = 0;
     ctx->pool[k] = PoolDev{};
     ctx->pool_shape[k] = fh_ctx::PoolShape{};
     ctx->counters_in_flight[k] = false;
@@ -1733,6 +1734,7 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
     for (int k = 0; k < 2; ++k) FH_HIP(hipStreamSynchronize(ctx->aux_stream[k]));
     for (void* p : ctx->pool_allocs[slot]) (void)hipFree(p);
     ctx->pool_allocs[slot].clear();
+    ctx->pool_alloc_bytes[slot] = 0;
     if (ctx->pool_target_by_caller && ctx->pool[slot].capacity > capacity) capacity = ctx->pool[slot].capacity;  // (a default-sized pool is re-made at the size the memory cap of this call allows)
     need.dir = need.dir || have.dir; need.lights = need.lights || have.lights; need.classes = need.classes > have.classes ? need.classes : have.classes;
     ctx->pool[slot] = PoolDev{};
@@ -1743,7 +1745,7 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
   auto alloc = [&](auto*& ptr, size_t count) -> hipError_t {
     void* raw = nullptr;
     hipError_t e = hipMalloc(&raw, count * sizeof(*ptr));
-    if (e == hipSuccess) { ctx->pool_allocs[slot].push_back(raw); ptr = (decltype(ptr))raw; }
+    if (e == hipSuccess) { ctx->pool_allocs[slot].push_back(raw); ctx->pool_alloc_bytes[slot] += count * sizeof(*ptr); ptr = (decltype(ptr))raw; }
     // FH_POISON=1 (tests): a new pool starts out full of 0xa5 instead of whatever the allocation held, so a kernel that reads a record or a queue entry nobody wrote shows at once
     if (e == hipSuccess && ctx->tun.poison_pools) e = hipMemsetAsync(raw, 0xa5, count * sizeof(*ptr), slot ? ctx->aux_stream[slot - 1] : ctx->stream);
     return e;
@@ -1779,6 +1781,7 @@ int pool_ensure(fh_ctx* ctx, int slot, uint32_t capacity)
   if (e != hipSuccess) {  // leave the slot empty rather than half allocated: the next call starts from scratch
     for (void* p : ctx->pool_allocs[slot]) (void)hipFree(p);
     ctx->pool_allocs[slot].clear();
+    ctx->pool_alloc_bytes[slot] = 0;
     P = PoolDev{};
     return fail(ctx, FH_E_HIP, std::string("path pool allocation: ") + hipGetErrorString(e));
   }
@@ -1896,7 +1899,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (max_depth > 64) return fail(ctx, FH_E_INVALID, "fh_render: max_depth > 64 is not supported");
   if (ctx->n_owned == 0 || n_samples == 0) return FH_OK;
   // The default pool size (32 Mi paths per pool) is a wish: whenever a pool has to be allocated -- the first frame, after fh_scene_upload changed what a path record
-  // holds, after a release -- all pools together are kept within half of what the device has free at that moment, counting what the pools already hold as free.
+  // holds, after a release -- all pools together are kept within A QUARTER of what the device has free at that moment, counting what the pools already hold as free.
+  // (A pool is allocated for the paths a pass really starts -- the pixels that can see the scene x the samples of the pass, pool_ensure -- so the cap is an upper bound.)
   if (!ctx->pool_target_by_caller) {
     bool allocating = false;
     unsigned long long held = 0;
@@ -1909,7 +1913,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       size_t free_b = 0, total_b = 0;
       ctx->pool_target = ctx->pool_target_default;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const unsigned long long cap = ((unsigned long long)free_b + held) / 2ull / ((unsigned long long)ctx->n_slots * pool_bytes_per_path(ctx));
+        const unsigned long long cap = ((unsigned long long)free_b + held) / 4ull / ((unsigned long long)ctx->n_slots * pool_bytes_per_path(ctx));
         if (cap < ctx->pool_target) ctx->pool_target = cap > ctx->n_owned ? (uint32_t)cap : ctx->n_owned;
       }
       // (pools that exist already keep their size unless they have to be re-made: pool_ensure only grows)
@@ -1985,8 +1989,12 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (batch > n_samples) batch = n_samples;
   if (batch > 65535u) batch = 65535u;  // (k_generate's grid has one row per sample of the pass)
   if (batch < 1) batch = 1;
+  if (batch < n_samples) {  // equal passes: a call of 1024 samples with room for 248 per pass runs five passes of 205, not four of 248 and a runt of 32
+    const uint32_t passes = (n_samples + batch - 1u) / batch;
+    batch = (n_samples + passes - 1u) / passes;
+  }
   // (the passes of a call overlap, three in flight: a big call that would fit two passes is cut into three of the same size)
-  if (n_sky && batch < n_samples && (n_samples + batch - 1u) / batch < (uint32_t)ctx->n_slots && (unsigned long long)n_samples * n_px >= 3ull << 24) batch = (n_samples + (uint32_t)ctx->n_slots - 1u) / (uint32_t)ctx->n_slots;
+  if ((n_samples + batch - 1u) / batch < (uint32_t)ctx->n_slots && n_samples >= (uint32_t)ctx->n_slots && (unsigned long long)n_samples * n_px >= 3ull << 24) batch = (n_samples + (uint32_t)ctx->n_slots - 1u) / (uint32_t)ctx->n_slots;
 
   const SceneDev sc = scene_dev(ctx);
   const bool count = (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) != 0;

@@ -195,6 +195,12 @@ class Renderer:
         self._ck(N.lib().fh_path_pool_bytes(self._ctx, C.byref(b), C.byref(n)), "fh_path_pool_bytes")
         return int(b.value), int(n.value)
 
+    def path_pool_allocated(self):
+        """(device bytes, path slots) the path pools hold right now, all pools together"""
+        b, n = C.c_uint64(0), C.c_uint64(0)
+        self._ck(N.lib().fh_path_pool_allocated(self._ctx, C.byref(b), C.byref(n)), "fh_path_pool_allocated")
+        return int(b.value), int(n.value)
+
     def set_tail_depth(self, depth):
         self._ck(N.lib().fh_set_tail_depth(self._ctx, C.c_uint32(depth)), "fh_set_tail_depth")
 

@@ -146,11 +146,14 @@ int fh_get_flags(fh_ctx* ctx, uint32_t* flags); /* (a caller that wants to chang
 /* target number of camera paths in flight per pass (path-pool slots); a pass starts floor(target / owned pixels) >= 1
  * samples per pixel.  Results do not depend on it.  Default 32 Mi paths per pool, three pools (one per pass in flight), 284-436 bytes per path.  Whenever a
  * default-sized pool has to be allocated (first frame, after fh_scene_upload changed what a path record holds) the default is lowered so that all pools together
- * stay within half of the device memory that is free at that moment (memory the pools already hold counts as free); a size set here is taken as given. */
+ * stay within a quarter of the device memory that is free at that moment (memory the pools already hold counts as free); a size set here is taken as given.
+ * The target is an upper bound: a pool is allocated for the paths its passes really start -- (owned pixels that can see the scene) x (samples per pass) -- and only grows. */
 int fh_set_path_pool(fh_ctx* ctx, uint32_t target_paths);
 /* device memory of the path pools with the scene and lights as they are now: bytes per path slot and the number of pools (one per pass in flight);
  * a caller that sizes the pools for a frame (bench.py) multiplies: pools x target_paths x bytes_per_path */
 int fh_path_pool_bytes(fh_ctx* ctx, uint64_t* bytes_per_path, uint32_t* pools);
+/* what the path pools hold right now: device bytes of all pools together and path slots (summed over the pools) */
+int fh_path_pool_allocated(fh_ctx* ctx, uint64_t* bytes, uint64_t* paths);
 /* number of bounces run as bounce-synchronous wavefront kernels before the surviving paths are finished by one
  * fused launch (k_tail).  Results do not depend on it.  0 (default) = adaptive: the depth at which fewer than 64 Ki
  * paths survived in earlier passes; a value >= max_depth disables the fused tail. */

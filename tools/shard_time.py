@@ -1,41 +1,47 @@
-"""Estimate strong scaling on ONE GPU: time the render of rank 0's tile shard for world sizes 1, 2, 4, 8 (no gather)."""
-import os, sys, time
+"""Emulated strong scaling on ONE GPU: the whole frame, then EACH of the 8 tile shards of an 8-way split rendered in turn (no gather; scene + BVH replicated as on 8 GPUs).
+The speed-up of the render phase is whole / max over shards; the gather (~0.6 ms at 1080p) and rank 0's un-permutation come on top.  One JSON line per case on stdout.
+    python tools/shard_time.py            env: CONFIGS="2,3" SPPS="1024,16" WORLD=8 TILES="32,16" STEPS=4"""
+import json, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+import torch
+import bench
 import fredholm_amd as F
-from fredholm_amd import scenes
-W, H, SPP, DEPTH = 1920, 1080, int(os.environ.get("SPP", "64")), 8
-sc = scenes.triangle_soup(1_000_000)
-POOL_SPP = int(os.environ.get('POOL_SPP', '64'))
-WORLDS = [int(x) for x in os.environ.get('WORLDS', '1,2,4,8').split(',')]
-for world in WORLDS:
-    r = F.Renderer(0); r.load_scene(sc); r.build_ias()
-    r.set_directional_light((0, 0, 0), scenes.SOUP_SUN, 0.0); r.clear_directional_light(); r.load_arhosek_sky(3.0, 0.3)
+
+WORLD = int(os.environ.get("WORLD", "8"))
+STEPS = int(os.environ.get("STEPS", "4"))
+tmp = tempfile.TemporaryDirectory()
+for cfg in [int(c) for c in os.environ.get("CONFIGS", "2,3").split(",")]:
+    w = bench.workload(cfg, tmp.name)
+    W, H, D = w["width"], w["height"], w["depth"]
+    r = F.Renderer(0); r.load_scene(w["scene"]); r.build_ias()
+    bench.apply_environment(r, w)
+    if w["sun"] is not None and not w["dir_le"]:
+        r.clear_directional_light()
     r.set_resolution(W, H)
-    if world > 1:
-        r.set_tile_shard(0, world, 32, 32)
-    if os.environ.get('BENCH_SIZING') == '1':  # passes as bench.py sizes them: equal passes of at most ~128 spp of a 1080p frame, at least three per step
-        cap = int(1920 * 1080 * 128 * 1.02)
-        passes = max(3, -(-r.owned_pixel_count() * SPP // cap))
-        r.set_path_pool(r.owned_pixel_count() * max(-(-SPP // passes), 1))
-    else:
-        r.set_path_pool(min(r.owned_pixel_count() * POOL_SPP, 160 * 1024 * 1024))
     L = F.RenderLayer(r, W, H)
-    cam = F.Camera(**scenes.SOUP_CAMERA)
-    for _ in range(3):
-        r.render(cam, (0, 0, 0), L, SPP, DEPTH)
-    r.wait_for_completion()
-    from fredholm_amd import native as N
-    r.set_flags(N.FLAG_TIME_KERNELS); r.reset_stats()
-    t0 = time.perf_counter()
-    n = 8
-    for _ in range(n):
-        r.render(cam, (0, 0, 0), L, SPP, DEPTH)
-        if os.environ.get('STEP_SYNC', '1') == '1':
-            r.wait_for_completion()
-    r.wait_for_completion()
-    dt = (time.perf_counter() - t0) / n
-    print(f"world {world}: rank-0 shard {r.owned_pixel_count()} px, {dt*1e3:.2f} ms per step", flush=True)
-    st = r.stats()
-    print('    ', {k: round(v / n, 3) for k, v in st.items() if k.endswith('_ms') and 'bvh' not in k}, {k: v // n for k, v in st.items() if k.startswith('n_')}, flush=True)
+    cam = F.Camera(**w["camera"])
+
+    def timed(spp):
+        pool_spp, _, _ = bench.pass_size(r, torch, 0, r.owned_pixel_count(), spp)
+        r.set_path_pool(max(int(r.owned_pixel_count() * pool_spp), 1))
+        for _ in range(2):
+            r.render(cam, w["bg"], L, spp, D); r.wait_for_completion()
+        ts = []
+        for _ in range(STEPS):
+            t0 = time.perf_counter(); r.render(cam, w["bg"], L, spp, D); r.wait_for_completion(); ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+
+    for spp in [int(s) for s in os.environ.get("SPPS", "1024,16").split(",")]:
+        spp = min(spp, 512) if cfg == 3 and spp > 512 else spp
+        r.set_tile_shard(0, 1, 32, 32)
+        whole = timed(spp)
+        for tile in [int(t) for t in os.environ.get("TILES", "32,16").split(",")]:
+            shards = []
+            for k in range(WORLD):
+                r.set_tile_shard(k, WORLD, tile, tile)
+                shards.append(round(timed(spp), 3))
+            mx, mean = max(shards), sum(shards) / len(shards)
+            print(json.dumps({"config": cfg, "workload": w["name"][:40], "spp": spp, "world": WORLD, "tile": tile, "whole_ms": round(whole, 3), "shard_ms": shards, "max_ms": mx, "mean_ms": round(mean, 3),
+                              "max_over_mean": round(mx / mean, 4), "render_speedup_whole_over_max": round(whole / mx, 3), "efficiency": round(whole / (WORLD * mx), 4),
+                              "note": "one GPU renders each rank's shard in turn (emulated): render phase only, no gather"}), flush=True)
     r.close()
