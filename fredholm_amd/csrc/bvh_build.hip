@@ -336,6 +336,12 @@ __global__ void k_emit_tris(const float4* face_rec, const uint8_t* face_cls, con
   if (i >= n) return;
   uint32_t f = sorted_face[i];
   if (ref_face) f = ref_face[f];  // split faces: the leaf is a reference
+  if (face_cls[f] & 0x20u) {  // a cut-out face whose any-hit test can never pass (capi.hip: footprint_class): a triangle no ray hits
+    tris[3 * i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
+    tris[3 * i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    tris[3 * i + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return;
+  }
   const float4 a = face_rec[7 * f], b = face_rec[7 * f + 1], c = face_rec[7 * f + 2];
   tris[3 * i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
   tris[3 * i + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);  // .w != 0: candidate hits need the alpha test
@@ -642,6 +648,7 @@ __global__ void k_emit_tris8(const float4* face_rec, const uint8_t* face_cls, co
   if (ref_face) f = ref_face[f];
   if (face_node) face_node[f] = (split_count && split_count[f] > 1u) ? 0u : tri_slot[i] >> 3;  // the wide node that holds the face; a face that entered the build as several references: the root
   const size_t t = 3 * (size_t)tri_slot[i];
+  if (face_cls[f] & 0x20u) return;  // never hit (above): the slot keeps the degenerate triangle k_clear_tris8 put there
   const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
   tris[t] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
   tris[t + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);

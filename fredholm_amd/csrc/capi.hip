@@ -122,6 +122,49 @@ int transform_faces(fh_ctx* ctx)
   return FH_OK;
 }
 
+// ---- Opacity classes of cut-out faces (round 5).  The any-hit programs (pt.cu:545-678) discard a candidate hit when the filtered alpha of the base-colour texture or the
+// filtered red of the alpha texture is below 0.5 at the hit's texture coordinate.  A filtered value is a convex combination of the four texels around the coordinate (weights
+// are products of 1.8 fixed-point fractions and sum to exactly 1, include/fh_texture_unit.h), so over the part of a texture a FACE can ever address the outcome is known in
+// advance when all of those texels agree: every byte >= 128 (0.50196) -- the test always passes, the face needs no test at all -- or every byte <= 127 (0.49804) -- it never
+// passes, the face can never be hit.  The footprint is the rectangle of texels the face's three texture coordinates span, one texel wider on every side for the bilinear taps
+// and a sixteenth more for the rounding of the interpolated coordinate, wrapped like the texture unit wraps; faces with a footprint of more than 2^18 texels are left to the
+// test.  0 = test as before, 1 = always passes, 2 = never passes.  FH_OPACITY_CLASSES=0 (read at upload): everything 0.
+static int texel_span(float lo, float hi, uint32_t n, int& first, int& count)
+{
+  // texel columns (rows) a fetch at normalised coordinates in [lo, hi] can read: floor(u * n - 0.5) and its successor, before wrapping
+  const double a = (double)lo * n - 0.5, b = (double)hi * n - 0.5;
+  const double slack = 0.0625 + 1e-5 * (std::fabs(a) > std::fabs(b) ? std::fabs(a) : std::fabs(b));
+  const double f0 = std::floor(a - slack), f1 = std::floor(b + slack) + 1.0;
+  if (!(f1 - f0 < (double)n)) { first = 0; count = (int)n; return 1; }
+  first = (int)(((long long)f0 % (long long)n + (long long)n) % (long long)n);
+  count = (int)(f1 - f0) + 1;
+  return 1;
+}
+// 1: every texel of the footprint passes the 0.5 threshold, 2: none does, 0: mixed (or not decided)
+static uint32_t footprint_class(const uint8_t* rgba8, uint32_t w, uint32_t h, uint32_t channel, const float* decode, const float uv[6])
+{
+  if (!rgba8 || w == 0 || h == 0) return 0u;
+  float ulo = uv[0], uhi = uv[0], vlo = uv[1], vhi = uv[1];
+  for (int k = 1; k < 3; ++k) { ulo = std::fmin(ulo, uv[2 * k]); uhi = std::fmax(uhi, uv[2 * k]); vlo = std::fmin(vlo, uv[2 * k + 1]); vhi = std::fmax(vhi, uv[2 * k + 1]); }
+  if (!(std::fabs(ulo) < 1e6f) || !(std::fabs(uhi) < 1e6f) || !(std::fabs(vlo) < 1e6f) || !(std::fabs(vhi) < 1e6f)) return 0u;  // (huge or non-finite coordinates: left to the test)
+  int x0, nx, y0, ny;
+  texel_span(ulo, uhi, w, x0, nx);
+  texel_span(vlo, vhi, h, y0, ny);
+  if ((long long)nx * ny > (1ll << 18)) return 0u;
+  bool all_pass = true, none_pass = true;
+  for (int j = 0; j < ny && (all_pass || none_pass); ++j) {
+    const size_t row = (size_t)((y0 + j) % (int)h) * w;
+    for (int i = 0; i < nx; ++i) {
+      const uint8_t b = rgba8[(row + (size_t)((x0 + i) % (int)w)) * 4u + channel];
+      const float v = decode ? decode[b] : (float)b * (1.0f / 255.0f);
+      if (v >= 0.50196f) none_pass = false;       // (byte 128 of a linear channel)
+      else if (v <= 0.49804f) all_pass = false;   // (byte 127)
+      else { all_pass = none_pass = false; }      // an sRGB-decoded value between the two: not decided
+    }
+  }
+  return all_pass ? 1u : (none_pass ? 2u : 0u);
+}
+
 // Rebuild everything derived from the flat scene + transforms: face records, classes, lights.
 int rebuild_device_scene(fh_ctx* ctx)
 {
@@ -164,6 +207,11 @@ int rebuild_device_scene(fh_ctx* ctx)
   std::vector<AreaLightDev> lights;
   std::vector<uint8_t> alpha_bits(nf, 0);  // bit 0: test the base-colour texture's alpha, bit 1: test the alpha texture's red
   bool any_alpha = false;
+  bool opacity_classes = true;
+  if (const char* e = getenv("FH_OPACITY_CLASSES")) opacity_classes = e[0] != '0';
+  for (int k = 0; k < 4; ++k) ctx->alpha_face_counts[k] = 0;
+  float srgb_table[256];
+  for (int i = 0; i < 256; ++i) srgb_table[i] = fht_srgb_to_linear((float)i * (1.0f / 255.0f));
   for (uint32_t f = 0; f < nf; ++f) {
     const uint32_t inst = ctx->h_instance_ids.empty() ? 0u : ctx->h_instance_ids[f];
     if (inst >= ni) return fail(ctx, FH_E_INVALID, "instance id out of range");
@@ -172,7 +220,7 @@ int rebuild_device_scene(fh_ctx* ctx)
     for (int k = 0; k < 3; ++k)
       if (ctx->h_indices[3ull * f + k] >= nv) return fail(ctx, FH_E_INVALID, "vertex index out of range");
     meta[f] = make_uint2(mid, inst);
-    bool alpha = mats[mid].alpha == 1u;
+    bool alpha = mats[mid].alpha == 1u, never = false;
     if (mats[mid].alpha) {
       bool wild = false;  // opaque textures: the test can only fail where the interpolated coordinate is NaN or overflows
       for (int k = 0; k < 3; ++k) {
@@ -182,8 +230,18 @@ int rebuild_device_scene(fh_ctx* ctx)
       alpha = alpha || wild;
       const int32_t bt = ctx->h_materials[mid].base_color_texture_id, at = ctx->h_materials[mid].alpha_texture_id;
       alpha_bits[f] = (uint8_t)(((bt >= 0 && (wild || ctx->h_tex_alpha_cuts[(size_t)bt])) ? 1u : 0u) | ((at >= 0 && (wild || ctx->h_tex_red_cuts[(size_t)at])) ? 2u : 0u));
+      if (alpha) ctx->alpha_face_counts[0]++;
+      if (alpha && !wild && opacity_classes && !ctx->h_tex_host.empty()) {  // what the face's own footprint says (above)
+        float uv[6];
+        for (int k = 0; k < 3; ++k) { const size_t v = ctx->h_indices[3ull * f + k]; uv[2 * k] = ctx->h_texcoords[2 * v]; uv[2 * k + 1] = ctx->h_texcoords[2 * v + 1]; }
+        uint32_t cb = 1u, ca = 1u;  // a texture the face does not test passes by itself
+        if (alpha_bits[f] & 1u) { const fh_ctx::HostTexture& t = ctx->h_tex_host[(size_t)bt]; cb = footprint_class(t.rgba8.data(), t.width, t.height, 3u, nullptr, uv); }
+        if (alpha_bits[f] & 2u) { const fh_ctx::HostTexture& t = ctx->h_tex_host[(size_t)at]; ca = footprint_class(t.rgba8.data(), t.width, t.height, 0u, t.srgb ? srgb_table : nullptr, uv); }
+        if (cb == 1u && ca == 1u) { alpha = false; alpha_bits[f] = 0; ctx->alpha_face_counts[1]++; }          // always passes: an ordinary opaque face
+        else if (cb == 2u || ca == 2u) { never = true; alpha = false; alpha_bits[f] = 0; ctx->alpha_face_counts[2]++; }  // never passes: no ray can hit it
+      }
     }
-    cls[f] = (uint8_t)(mats[mid].cls | (mats[mid].emissive ? 0x80u : 0u) | (alpha ? 0x40u : 0u));
+    cls[f] = (uint8_t)(mats[mid].cls | (mats[mid].emissive ? 0x80u : 0u) | (alpha ? 0x40u : 0u) | (never ? 0x20u : 0u));
     if (alpha) any_alpha = true;
     if (mats[mid].emissive) lights.push_back({f, mid});  // renderer.h:388-402, face order
   }
@@ -212,6 +270,10 @@ int rebuild_device_scene(fh_ctx* ctx)
   ctx->n_lights = (uint32_t)lights.size();
   ctx->n_materials = nm;
   ctx->has_alpha = any_alpha;
+  ctx->alpha_face_counts[3] = ctx->alpha_face_counts[0] - ctx->alpha_face_counts[1] - ctx->alpha_face_counts[2];
+  if (getenv("FH_DEBUG_BVH") && ctx->alpha_face_counts[0])
+    fprintf(stderr, "[alpha] %u faces whose textures can cut: %u always pass, %u never pass, %u keep their any-hit test\n", ctx->alpha_face_counts[0], ctx->alpha_face_counts[1], ctx->alpha_face_counts[2],
+            ctx->alpha_face_counts[3]);
   if (ctx->d_alpha_rec) { (void)hipFree(ctx->d_alpha_rec); ctx->d_alpha_rec = nullptr; }
   if (any_alpha) {
     // everything the any-hit test of a face reads, in one 64-byte line: the three texture coordinates and the two textures it may have to look at
@@ -259,6 +321,7 @@ int upload_textures(fh_ctx* ctx, uint32_t n, const fh_texture_desc* descs)
   ctx->h_tex_alpha_cuts.assign(n, 0);
   ctx->h_tex_red_cuts.assign(n, 0);
   ctx->h_tex_desc.clear();
+  ctx->h_tex_host.clear();
   if (n == 0) return FH_OK;
   size_t total = 0;
   for (uint32_t i = 0; i < n; ++i) {
@@ -274,6 +337,13 @@ int upload_textures(fh_ctx* ctx, uint32_t n, const fh_texture_desc* descs)
     const float red = descs[i].srgb ? fht_srgb_to_linear((float)min_r * (1.0f / 255.0f)) : (float)min_r * (1.0f / 255.0f);
     ctx->h_tex_alpha_cuts[i] = (float)min_a * (1.0f / 255.0f) < 0.501f ? 1 : 0;
     ctx->h_tex_red_cuts[i] = red < 0.501f ? 1 : 0;
+  }
+  // host copies of the textures that can cut: what the per-face opacity classes are decided from (rebuild_device_scene)
+  ctx->h_tex_host.resize(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    fh_ctx::HostTexture& t = ctx->h_tex_host[i];
+    t.width = descs[i].width; t.height = descs[i].height; t.srgb = descs[i].srgb ? 1u : 0u;
+    if (ctx->h_tex_alpha_cuts[i] || ctx->h_tex_red_cuts[i]) t.rgba8.assign(descs[i].rgba8, descs[i].rgba8 + (size_t)descs[i].width * descs[i].height * 4);
   }
   FH_HIP(hipMalloc((void**)&ctx->d_texels, total));
   std::vector<fht_texture> t(n);
@@ -537,6 +607,22 @@ int fh_path_pool_bytes(fh_ctx* ctx, uint64_t* bytes_per_path, uint32_t* pools)
   if (!bytes_per_path || !pools) return fail(ctx, FH_E_INVALID, "fh_path_pool_bytes: null argument");
   *bytes_per_path = pool_bytes_per_path(ctx);
   *pools = (uint32_t)ctx->n_slots;
+  return FH_OK;
+}
+
+int fh_kat_face_classes(fh_ctx* ctx, uint8_t* out, uint32_t n)
+{
+  CTX_CHECK(ctx);
+  if (!out || n != ctx->n_faces) return fail(ctx, FH_E_INVALID, "fh_kat_face_classes: one byte per face of the uploaded scene");
+  if (n) FH_HIP(hipMemcpy(out, ctx->d_face_cls, n, hipMemcpyDeviceToHost));
+  return FH_OK;
+}
+
+int fh_alpha_face_counts(fh_ctx* ctx, uint32_t counts[4])
+{
+  CTX_CHECK(ctx);
+  if (!counts) return fail(ctx, FH_E_INVALID, "fh_alpha_face_counts: null argument");
+  for (int k = 0; k < 4; ++k) counts[k] = ctx->alpha_face_counts[k];
   return FH_OK;
 }
 

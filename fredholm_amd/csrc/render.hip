@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(kBlock) k_route(SceneDev sc, PoolDev pool, uin
       if (i < count) {
         p[c] = q[i];
         const uint32_t prim = pool.q_prim[i];  // (= the face id bits of pool.hit[p].w, from a stream)
-        if (prim != 0xffffffffu) cls[c] = sc.face_cls[prim] & 0x3fu;
+        if (prim != 0xffffffffu) cls[c] = sc.face_cls[prim] & 0x1fu;
       }
     }
 #pragma unroll

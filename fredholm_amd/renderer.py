@@ -195,6 +195,12 @@ class Renderer:
         self._ck(N.lib().fh_path_pool_bytes(self._ctx, C.byref(b), C.byref(n)), "fh_path_pool_bytes")
         return int(b.value), int(n.value)
 
+    def alpha_face_counts(self):
+        """(faces whose textures can cut, always pass, never pass, still tested) of the uploaded scene"""
+        a = (C.c_uint32 * 4)()
+        self._ck(N.lib().fh_alpha_face_counts(self._ctx, a), "fh_alpha_face_counts")
+        return tuple(int(x) for x in a)
+
     def path_pool_allocated(self):
         """(device bytes, path slots) the path pools hold right now, all pools together"""
         b, n = C.c_uint64(0), C.c_uint64(0)

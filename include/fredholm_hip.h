@@ -152,6 +152,9 @@ int fh_set_path_pool(fh_ctx* ctx, uint32_t target_paths);
 /* device memory of the path pools with the scene and lights as they are now: bytes per path slot and the number of pools (one per pass in flight);
  * a caller that sizes the pools for a frame (bench.py) multiplies: pools x target_paths x bytes_per_path */
 int fh_path_pool_bytes(fh_ctx* ctx, uint64_t* bytes_per_path, uint32_t* pools);
+/* cut-out faces of the uploaded scene: [0] faces whose textures can discard a hit (pt.cu:545-678), [1] of them: the any-hit test passes wherever the face can be hit (no test
+ * at run time), [2] it never passes (no ray can hit the face), [3] faces that keep their test.  Decided per face at fh_scene_upload from the texels the face can address. */
+int fh_alpha_face_counts(fh_ctx* ctx, uint32_t counts[4]);
 /* what the path pools hold right now: device bytes of all pools together and path slots (summed over the pools) */
 int fh_path_pool_allocated(fh_ctx* ctx, uint64_t* bytes, uint64_t* paths);
 /* number of bounces run as bounce-synchronous wavefront kernels before the surviving paths are finished by one

@@ -42,6 +42,10 @@ int fh_kat_math(fh_ctx* ctx, int kind, uint32_t n, const float* in, float* out);
  * (number of disagreeing inputs; 0 expected), plus its results on `n_sample` given inputs for a comparison with the host's sqrtf */
 int fh_kat_sqrt(fh_ctx* ctx, unsigned long long* mismatches_over_all_inputs, uint32_t n_sample, const float* sample_in, float* sample_out);
 int fh_kat_tex2d(fh_ctx* ctx, const uint8_t* rgba8, const float* rgba32f, uint32_t width, uint32_t height, int srgb, uint32_t n, const float* uv2, float* out4);
+/* the class byte of every face of the uploaded scene (n = faces): bits 0-4 shading class, 0x20 a cut-out face whose any-hit test can never pass (no ray hits it),
+   0x40 the any-hit test runs for candidate hits on this face, 0x80 emissive.  A face of a material whose textures can cut with neither 0x20 nor 0x40 was
+   classified "always passes" from the texels it can address (capi.hip: footprint_class); the parity tests check both classes by brute force. */
+int fh_kat_face_classes(fh_ctx* ctx, uint8_t* out, uint32_t n);
 
 #ifdef __cplusplus
 }

@@ -952,6 +952,172 @@ def test_many_cut_out_layers_fill_the_ring_of_parked_any_hit_tests(oracle, monke
         _assert_image_parity(gpu[name], ref[name])
 
 
+def _np_filtered_channel(img, channel, srgb_lut, tu, tv):
+    """fht_tex2d_channel8 (include/fh_texture_unit.h) restated in numpy on float32: wrap, texel centres at +0.5, 1.8 fixed-point weights, the blend in its order"""
+    h, w = img.shape[:2]
+    f32 = np.float32
+    u = (tu - np.floor(tu)).astype(f32)
+    v = (tv - np.floor(tv)).astype(f32)
+    xb = (u * f32(w) - f32(0.5)).astype(f32)
+    yb = (v * f32(h) - f32(0.5)).astype(f32)
+    xf, yf = np.floor(xb), np.floor(yb)
+    a = (np.floor((xb - xf).astype(f32) * f32(256.0) + f32(0.5)) * f32(1.0 / 256.0)).astype(f32)
+    b = (np.floor((yb - yf).astype(f32) * f32(256.0) + f32(0.5)) * f32(1.0 / 256.0)).astype(f32)
+    i, j = xf.astype(np.int64), yf.astype(np.int64)
+    i0, i1 = np.where(i < 0, i + w, i), np.where(i + 1 >= w, i + 1 - w, i + 1)
+    j0, j1 = np.where(j < 0, j + h, j), np.where(j + 1 >= h, j + 1 - h, j + 1)
+    dec = (lambda t: srgb_lut[t]) if srgb_lut is not None else (lambda t: (t.astype(f32) * f32(1.0 / 255.0)).astype(f32))
+    t00, t10, t01, t11 = dec(img[j0, i0, channel]), dec(img[j0, i1, channel]), dec(img[j1, i0, channel]), dec(img[j1, i1, channel])
+    one = f32(1.0)
+    return ((((one - a) * (one - b)).astype(f32) * t00).astype(f32) + ((a * (one - b)).astype(f32) * t10).astype(f32) + (((one - a) * b).astype(f32) * t01).astype(f32) + ((a * b).astype(f32) * t11).astype(f32)).astype(f32)
+
+
+def _brute_force_face_classes(sc, flags, n_grid=96):
+    """for every face the library classified -- 'always passes' (a material whose textures can cut, yet neither 0x40 nor 0x20) or 'never passes' (0x20) -- evaluate the any-hit
+    test of pt.cu:545-678 on a dense barycentric grid (corners and edges included) with the numpy restatement of the texture unit; returns (checked always, checked never)"""
+    mats, tex = sc["materials"], sc.get("textures", [])
+    idx, tc, mid = np.asarray(sc["indices"]), np.asarray(sc["texcoords"], np.float32), np.asarray(sc["material_ids"])
+    g = np.linspace(0.0, 1.0, n_grid, dtype=np.float32)
+    bu, bv = np.meshgrid(g, g)
+    keep = bu + bv <= 1.0
+    bu, bv = bu[keep].astype(np.float32), bv[keep].astype(np.float32)
+    bw = (np.float32(1.0) - bu - bv).astype(np.float32)
+    lut = np.array([c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4 for c in (np.arange(256) / 255.0)], np.float32)
+    n_always = n_never = 0
+    for f in range(idx.shape[0]):
+        m = mats[mid[f]]
+        bt, at = int(m["base_color_texture_id"]), int(m["alpha_texture_id"])
+        red_min = int(np.asarray(tex[at]["rgba8"])[..., 0].min()) if at >= 0 else 255
+        can_cut = (bt >= 0 and (np.asarray(tex[bt]["rgba8"])[..., 3] < 128).any()) or (at >= 0 and (lut[red_min] if tex[at]["srgb"] else np.float32(red_min) / np.float32(255.0)) < np.float32(0.501))
+        never, tested = bool(flags[f] & 0x20), bool(flags[f] & 0x40)
+        if not can_cut or tested:
+            assert not never
+            continue
+        uv0, uv1, uv2 = tc[idx[f, 0]], tc[idx[f, 1]], tc[idx[f, 2]]
+        tu = (bw * uv0[0] + bu * uv1[0] + bv * uv2[0]).astype(np.float32)
+        tv = (bw * uv0[1] + bu * uv1[1] + bv * uv2[1]).astype(np.float32)
+        ok = np.ones(tu.shape, bool)
+        if bt >= 0:
+            ok &= _np_filtered_channel(np.asarray(tex[bt]["rgba8"]), 3, None, tu, tv) >= np.float32(0.5)
+        if at >= 0:
+            ok &= _np_filtered_channel(np.asarray(tex[at]["rgba8"]), 0, lut if tex[at]["srgb"] else None, tu, tv) >= np.float32(0.5)
+        if never:
+            assert not ok.any(), f"face {f} is classified 'never passes' but {ok.sum()} of {ok.size} grid points pass"
+            n_never += 1
+        else:
+            assert ok.all(), f"face {f} is classified 'always passes' but {(~ok).sum()} of {ok.size} grid points fail"
+            n_always += 1
+    return n_always, n_never
+
+
+def _fence_scene():
+    """the textured Cornell box plus a fence of small cut-out quads: each quad's texture coordinates sit inside ONE 8 x 8-texel cell of an alpha checker (two texels in from
+    the cell's edge), half of the cells opaque and half transparent, in the base colour's alpha for one half of the fence and in an alpha texture for the other; and a row of
+    large quads that span several cells and must keep their test"""
+    base = scenes.textured_cornell_box()
+    tex = list(base["textures"])
+    n_cells, cell = 8, 8
+    size = n_cells * cell
+    yy, xx = np.mgrid[0:size, 0:size]
+    on = ((xx // cell + yy // cell) % 2) == 0
+    rgba = np.zeros((size, size, 4), np.uint8)
+    rgba[..., 0], rgba[..., 1], rgba[..., 2] = 60, 160, 70
+    rgba[..., 3] = np.where(on, 255, 0)
+    t_base = len(tex); tex.append({"rgba8": rgba, "srgb": True})
+    red = np.zeros((size, size, 4), np.uint8)
+    red[..., 0] = np.where(on, 230, 20)
+    red[..., 3] = 255
+    t_alpha = len(tex); tex.append({"rgba8": red, "srgb": False})
+    mats = np.concatenate([base["materials"], default_materials(2)])
+    nm = base["materials"].shape[0]
+    mats["base_color_texture_id"][nm] = t_base
+    mats["base_color"][nm + 1] = (0.8, 0.7, 0.2)
+    mats["alpha_texture_id"][nm + 1] = t_alpha
+    v, n, t, tri, mid = [], [], [], [], []
+    rng = np.random.default_rng(11)
+
+    def quad(x0, y0, x1, y1, z, u0, v0, u1, v1, m):
+        b = len(v)
+        v.extend([[x0, y0, z], [x1, y0, z], [x1, y1, z], [x0, y1, z]])
+        n.extend([[0.0, 0.0, 1.0]] * 4)
+        t.extend([[u0, v0], [u1, v0], [u1, v1], [u0, v1]])
+        tri.extend([[b, b + 1, b + 2], [b, b + 2, b + 3]])
+        mid.extend([m, m])
+
+    k = 0
+    for gy in range(12):
+        for gx in range(16):
+            ci, cj = rng.integers(0, n_cells, 2)
+            wrap_u, wrap_v = rng.integers(-2, 3, 2)  # whole turns of the wrap
+            u0, v0 = (ci * cell + 2.0) / size + wrap_u, (cj * cell + 2.0) / size + wrap_v
+            u1, v1 = (ci * cell + cell - 2.0) / size + wrap_u, (cj * cell + cell - 2.0) / size + wrap_v
+            x0, y0 = -0.8 + 0.1 * gx, 0.3 + 0.1 * gy
+            quad(x0, y0, x0 + 0.09, y0 + 0.09, 0.2 + 0.001 * k, u0, v0, u1, v1, nm + (k % 2))
+            k += 1
+    for gx in range(4):  # large quads over several cells: mixed footprints
+        quad(-0.8 + 0.4 * gx, 1.55, -0.45 + 0.4 * gx, 1.9, 0.1, 0.1 * gx, 0.0, 0.1 * gx + 0.45, 0.4, nm + (gx % 2))
+    nv = base["vertices"].shape[0]
+    sc = dict(base)
+    sc["vertices"] = np.concatenate([base["vertices"], np.asarray(v, np.float32)])
+    sc["normals"] = np.concatenate([base["normals"], np.asarray(n, np.float32)])
+    sc["texcoords"] = np.concatenate([base["texcoords"], np.asarray(t, np.float32)])
+    sc["indices"] = np.concatenate([base["indices"], (nv + np.asarray(tri, np.uint32))])
+    sc["material_ids"] = np.concatenate([base["material_ids"], np.asarray(mid, np.uint32)])
+    sc["materials"] = mats
+    sc["textures"] = tex
+    return sc
+
+
+def _face_classes(r, n_faces):
+    out = np.zeros(n_faces, np.uint8)
+    N.check(r._ctx, N.lib().fh_kat_face_classes(r._ctx, out.ctypes.data_as(C.c_void_p), C.c_uint32(n_faces)), "fh_kat_face_classes")
+    return out
+
+
+def test_opacity_classes_of_cut_out_faces_are_exact(oracle, monkeypatch):
+    """fh_scene_upload decides per cut-out face, from the texels the face can address, whether its any-hit test (pt.cu:545-678) always passes (then no test runs), never
+    passes (then no ray hits the face) or has to run.  (1) every classified face is checked by brute force: the test evaluated on a dense barycentric grid with a numpy
+    restatement of the texture unit; (2) hits, occlusion and images are those of the checker, which tests every candidate; (3) with the classes switched off
+    (FH_OPACITY_CLASSES=0) the library returns the same bits."""
+    sc = _fence_scene()
+    nf = sc["indices"].shape[0]
+    r = F.Renderer(0)
+    r.load_scene(sc)
+    r.build_ias()
+    cuts, always, never, tested = r.alpha_face_counts()
+    assert always >= 80 and never >= 80 and tested >= 8 and cuts == always + never + tested, (cuts, always, never, tested)
+    flags = _face_classes(r, nf)
+    assert int((flags & 0x20 != 0).sum()) == never and int((flags & 0x40 != 0).sum()) == tested
+    got = _brute_force_face_classes(sc, flags)
+    assert got == (always, never), (got, always, never)
+    S = oracle.Scene(sc)
+    rays = _rays(np.random.default_rng(12), 40000, -0.9, 0.9)
+    rays[:, 1] += 1.0
+    tuv_g, prim_g = r.trace_rays(rays)
+    tuv_o, prim_o = S.trace(rays)
+    assert np.array_equal(prim_g, prim_o) and np.array_equal(_bits(tuv_g), _bits(tuv_o))
+    assert np.array_equal(r.trace_rays(rays, any_hit=True)[1] != 0xFFFFFFFF, prim_o != 0xFFFFFFFF)
+    hit_faces = np.unique(prim_o[prim_o != 0xFFFFFFFF])
+    assert not (flags[hit_faces] & 0x20).any() and (flags[hit_faces] & 0x40).any()  # no ray hits a 'never' face; rays do hit faces that keep their test
+    r.close()
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    for streaming in ("0", "1"):
+        monkeypatch.setenv("FH_STREAM", streaming)
+        monkeypatch.delenv("FH_OPACITY_CLASSES", raising=False)
+        gpu, ref = _render_pair(oracle, sc, cam, 96, 72, launches=2, spp_per_launch=2, depth=4)
+        for name in F.RenderLayer.NAMES:
+            _assert_image_parity(gpu[name], ref[name])
+        monkeypatch.setenv("FH_OPACITY_CLASSES", "0")
+        r0 = F.Renderer(0)
+        r0.load_scene(sc)
+        assert r0.alpha_face_counts()[1:3] == (0, 0)
+        r0.close()
+        off, _ = _render_pair(oracle, sc, cam, 96, 72, launches=2, spp_per_launch=2, depth=4)
+        for name in F.RenderLayer.NAMES:
+            assert _same(gpu[name], off[name])
+    monkeypatch.delenv("FH_OPACITY_CLASSES", raising=False)
+
+
 def test_wild_texture_coordinates_on_opaque_textures_still_take_the_any_hit_test(oracle):
     """Faces whose textures cannot cut (every texel opaque) skip the any-hit test -- unless a texture coordinate is NaN, infinite or about to overflow: the
     texture unit fetches 0 there and the reference's any-hit program discards the hit (pt.cu:545-678).  Same hits and same images as the checker."""
