@@ -377,12 +377,33 @@ FH_D void node8_eval(const Ray8& r, uint32_t ni, const uint4 n0, const uint4 n1,
 #ifndef FH_ANYHIT_UNORDERED
 #define FH_ANYHIT_UNORDERED 0  // (experiment: a streaming launch whose rays ALL stop at their first hit visits the children in slot order and saves the octant permutation)
 #endif
-template <bool ORDERED = true>
-FH_D void node8_visit(const Bvh8Dev& bvh, const Ray8& r, uint32_t ni, float tmax, uint2& group, uint2& tg)
+// The top of the tree in LDS (streaming kernels, FH_TOP_LDS).  Every ray visits the root and one or two of its children: 2.5 of a secondary ray's 15 node visits on the
+// soup, 17 % of the node fetches -- each of them four vector-L1 look-ups per lane, and the look-up rate of the L1 (one line per cycle and CU) is one of the two limits
+// the kernels sit on.  A workgroup stages nodes 0 .. 8 (the root and its inner children, which the breadth-first collapse numbers 1 ..) once, 576 bytes,
+// and a visit of one of them reads LDS (8 cycles per 64-lane ds_read_b128) instead.  Secondary and merged launches only; alone on the GPU the secondary launch takes
+// 103.3 -> 100.7 ms per configs[2] frame and 783 -> 743 ms per 512 spp of configs[3] (profiles/README.md r5-7).
+#ifndef FH_TOP_LDS
+#define FH_TOP_LDS 1
+#endif
+constexpr uint32_t kTopNodes = 9;
+constexpr uint32_t kTopLdsBytes = FH_TOP_LDS ? kTopNodes * 64u : 0u;
+FH_D void stage_top_nodes(const Bvh8Dev& bvh, uint4* lds_top)  // every thread of the workgroup; ends with its barrier
 {
-  // (a 32-bit byte offset -- the builder refuses trees of 2^23 nodes -- lets the four loads share the base in scalar registers)
-  const uint4* nd = (const uint4*)((const char*)bvh.nodes + (ni << 6));
-  const uint4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+  if (threadIdx.x < kTopNodes * 4u) lds_top[threadIdx.x] = (threadIdx.x >> 2) < bvh.n_nodes ? bvh.nodes[threadIdx.x] : make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+}
+template <bool ORDERED = true>
+FH_D void node8_visit(const Bvh8Dev& bvh, const Ray8& r, uint32_t ni, float tmax, uint2& group, uint2& tg, const uint4* top = nullptr)
+{
+  uint4 n0, n1, n2, n3;
+  if (FH_TOP_LDS && top && ni < kTopNodes) {
+    const uint4* nd = top + 4u * ni;
+    n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3];
+  } else {
+    // (a 32-bit byte offset -- the builder refuses trees of 2^23 nodes -- lets the four loads share the base in scalar registers)
+    const uint4* nd = (const uint4*)((const char*)bvh.nodes + (ni << 6));
+    n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3];
+  }
   const uint32_t hm = node8_test(r, n0, n1, n2, n3, tmax);
   const uint32_t imask = n0.w & 0xffu;
   if (!ORDERED) {
@@ -811,7 +832,7 @@ struct ChunkFeed {
 // ---------------------------------------------------------------------------------------------
 template <bool MIXED, bool COUNT, bool LDS, bool ALPHA, class Policy>
 FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws, const CoopLds& cl, uint32_t flush, uint32_t refill,
-                          uint2* lds_column, int lds_stride, const SceneDev* sc, StackSpill spill = StackSpill{nullptr, 0u})
+                          uint2* lds_column, int lds_stride, const SceneDev* sc, StackSpill spill = StackSpill{nullptr, 0u}, const uint4* top = nullptr)
 {
   const uint32_t lane = __lane_id();
   GroupStack<LDS> stack(lds_column, spill.lds_entries ? (int)spill.lds_entries : lds_stride, spill.area, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x);
@@ -946,7 +967,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       const uint32_t slot = ordered ? (bit - 24u) ^ r.oct : bit - 24u;
       const uint32_t ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
-      node8_visit<ordered>(bvh, r, ni, best_t, group, tg);
+      node8_visit<ordered>(bvh, r, ni, best_t, group, tg, top);
       if (climbing) group.y &= ~(1u << (24u + (ordered ? (stack.anchor_skip() ^ r.oct) : stack.anchor_skip())));  // the child the ray came up through has been walked
     }
 #endif

@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : FH_STREAM_BLOCKS_CLOSEST) 
   WaveSteps ws;
   ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, stream_chunk_for(count, chunk)), tc.hist);
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // the traversal stack of every lane: [entry][thread], as many entries as the BVH has levels
+  // (no LDS copy of the top nodes here, fh_trace.h FH_TOP_LDS: the closest-hit launch gained 0.9 % alone on configs[2] and LOST 1.7 % on configs[3], where the ring of parked any-hit tests already takes its LDS)
   traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill);
   stamp.commit(tc.clk);
   if (COUNT) {
@@ -1273,7 +1274,9 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)), tc.hist);
-  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill);
+  __shared__ uint4 lds_top[FH_TOP_LDS ? kTopNodes * 4 : 1];
+  if (FH_TOP_LDS) stage_top_nodes(sc.bvh8, lds_top);
+  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr);
   pol.finish();
   stamp.commit(tc.clk);
   if (COUNT) {
@@ -1342,7 +1345,9 @@ __global__ void __launch_bounds__(kBlock, LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : (
   AlphaLds<AlphaDefer<true, ALPHA>::value>::attach(cl);  // candidates waiting for their any-hit test (fh_trace.h: alpha_ring): LDS of the kernels with the test compiled in only
   uint32_t nn = 0, nt = 0;
   MergedStream<LIGHTS> pol(sc, fr, ps, pn, pn.q_rad[(depth + 1u) & 1u], n_sec, ChunkFeed(ps.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)));
-  traverse_stream<true, false, true, ALPHA>(sc.bvh8, pol, nn, nt, nullptr, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill);
+  __shared__ uint4 lds_top[FH_TOP_LDS ? kTopNodes * 4 : 1];
+  if (FH_TOP_LDS) stage_top_nodes(sc.bvh8, lds_top);
+  traverse_stream<true, false, true, ALPHA>(sc.bvh8, pol, nn, nt, nullptr, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr);
   pol.sec.finish();
   stamp.commit(tc.clk);
 }
@@ -1989,8 +1994,11 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   if (batch > n_samples) batch = n_samples;
   if (batch > 65535u) batch = 65535u;  // (k_generate's grid has one row per sample of the pass)
   if (batch < 1) batch = 1;
-  if (batch < n_samples) {  // equal passes: a call of 1024 samples with room for 248 per pass runs five passes of 205, not four of 248 and a runt of 32
-    const uint32_t passes = (n_samples + batch - 1u) / batch;
+  if (batch < n_samples) {  // equal passes, and whole rounds of the passes in flight: a call of 1024 samples with room for 248 per pass runs six passes of 171, not four of
+    // 248 and a runt of 32 -- the last pass of an incomplete round has nothing to overlap with (configs[2]: 3 / 4 / 5 / 6 passes measure 7700 / 7577 / 7578 / 7598 Msamples/s, r5-5)
+    uint32_t passes = (n_samples + batch - 1u) / batch;
+    const uint32_t slots = (uint32_t)ctx->n_slots;
+    if (slots > 1u && passes > slots && passes % slots != 0u && (passes / slots + 1u) * slots <= n_samples) passes = (passes / slots + 1u) * slots;
     batch = (n_samples + passes - 1u) / passes;
   }
   // (the passes of a call overlap, three in flight: a big call that would fit two passes is cut into three of the same size)
@@ -2058,7 +2066,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const uint32_t stream_need = stack_entries + (sc.bvh8.parent ? 1u : 0u);
   // static LDS of a streaming kernel's workgroup: the cooperative-test records and, where candidates are parked for their any-hit test (AlphaDefer), the ring
   const uint32_t static_lds_closest = kCoopLdsBytesPerBlock + (sc.has_alpha && AlphaDefer<false, true>::value ? kAlphaLdsBytesPerBlock : 0u);
-  const uint32_t static_lds_secondary = kCoopLdsBytesPerBlock + (sc.has_alpha && AlphaDefer<true, true>::value ? kAlphaLdsBytesPerBlock : 0u);
+  const uint32_t static_lds_secondary = kCoopLdsBytesPerBlock + kTopLdsBytes + (sc.has_alpha && AlphaDefer<true, true>::value ? kAlphaLdsBytesPerBlock : 0u);
   if (stream) {  // what the runtime says really fits (LDS granularity, registers of the variant in use): a grid above it would leave blocks queued behind the resident ones
     const uint32_t key = stack_bytes | (count ? 1u : 0u) | (sc.has_alpha ? 2u : 0u) | (sc.n_lights > 0 ? 4u : 0u) | (sc.bvh8.parent ? 8u : 0u) | (tun.stack_lds_entries << 20);
     if (ctx->occupancy_key != key) {
