@@ -363,7 +363,10 @@ def refuse_bad_fracs(obj, path=""):
     return bad
 
 
-DEFAULT_POOL_GB = 72.0  # device memory of all path pools together in the default run: a quarter of an MI355X's HBM (profiles/r05_pool_sweep.json: within 1-2 % of what 218 GB buy)
+# device memory of all path pools together in the default run: a third of an MI355X's HBM.  profiles/r05_pool_sweep.json has the curve: configs[2] holds 88 GB at this budget (three
+# passes of the pixels that can see the scene; the 204 GB round 4 printed was the nominal figure, never allocated) and loses 1.4 % at 44 GB (six passes), 3.5 % at 29 GB, 7 % at
+# 16 GB; configs[3] loses 1 % against the 218 GB it took in round 4, 3 % at 64 GB, 9 % at 16 GB.
+DEFAULT_POOL_GB = 96.0
 
 
 def pass_size(r, torch, local_rank, n_owned, spp, pool_spp_arg=0, pool_gb=0.0):
