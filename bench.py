@@ -386,7 +386,7 @@ def pass_size(r, torch, local_rank, n_owned, spp, pool_spp_arg=0, pool_gb=0.0):
     return max(budget / (n_pools * slot_bytes) / max(n_owned, 1), 1.0 / max(n_owned, 1)), slot_bytes, n_pools
 
 
-def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1, pool_gb=0.0):
+def general_scene_block(local_rank, tmpdir, bw, spp=540, steps=2, warmup=1, pool_gb=0.0):
     """The general-scene leg of the default run (outside the headline's timed region): BASELINE.json configs[3] -- the Sponza-class textured interior, where every camera ray
     hits and a sample is 1.7 closest-hit + 4.6 secondary rays -- for `steps` frames of `spp` samples, plus the reference's own call pattern on it (1 and 16 samples per call,
     app/controller.cpp:205-230, app/rtcamp8.cpp:183-189), the dominant traversal kernel's roofline record and a parity crop against the CPU checker.  configs[2], the headline,
@@ -463,7 +463,7 @@ def general_scene_block(local_rank, tmpdir, bw, spp=512, steps=2, warmup=1, pool
     out = {"workload": w["name"], "msamples_per_s": round(W * H * spp * steps / dt / 1e6, 2), "ms_per_step": round(dt / steps * 1e3, 3), "spp_per_step": spp, "spp_per_pass": round(pool_spp, 3) if isinstance(pool_spp, float) else pool_spp,
            "passes_per_step": round(timed["n_passes"] / max(steps, 1), 2), "path_pools": {"gb": round(pool_bytes_timed / 1e9, 1), "paths": int(pool_paths_timed)},
            "steps": steps, "warmup": warmup, "triangles": int(w["scene"]["indices"].shape[0]),
-           "note": "BASELINE.json configs[3] at a shorter frame than its 4096 spp (throughput does not depend on the frame length beyond three passes: 512 / 4096 spp measure within 1 %)",
+           "note": "BASELINE.json configs[3] at a shorter frame than its 4096 spp (throughput does not depend on the frame length beyond three passes: 512 / 4096 spp measure within 1 %); 540 = twelve passes of 45 samples, the pass the 4096-spp run submits and its counter file was collected with",
            "roofline": roof,
            "kernel_ms_per_step_alone": {"trace_closest": round(alone["trace_closest_ms"], 3), "trace_secondary": round(alone["trace_shadow_ms"], 3), "shade": round(alone["shade_ms"], 3),
                                         "generate": round(alone["generate_ms"], 3), "route_and_sort": round(alone["queue_ms"], 3), "accumulate": round(alone["accumulate_ms"], 3),
