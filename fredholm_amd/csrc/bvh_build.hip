@@ -739,6 +739,16 @@ __global__ void k_ploc_compact(int n, const uint32_t* valid, const uint32_t* off
   chi_out[o] = chi[i];
 }
 
+// 1 + the wide node that holds a face into the free lane of the face's record (.z of its last vector; 0: unknown, rays start at the root): the shade kernels, which read that
+// vector for the material id, find there where the rays that leave the face start their traversal (fh_trace.h: bottom-up start)
+__global__ void k_face_node_to_rec(const uint32_t* face_node, uint32_t n, float4* face_rec)
+{
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const uint32_t node = face_node[f];
+  face_rec[7 * (size_t)f + 6].z = __uint_as_float(node == 0xffffffffu ? 0u : node + 1u);
+}
+
 // surface-area-heuristic cost of a binary tree: sum over inner nodes of area(node) (the leaves are the same triangles in both builders)
 __global__ void k_sah_sum(int n_inner, const float4* node_lo, const float4* node_hi, double* sum)
 {
@@ -1069,6 +1079,7 @@ int bvh_build_device(fh_ctx* ctx)
     double area = 0.0;
     { const int rc = refit_levels(ctx, pad, 1, &area); if (rc) return rc; }
     if (area <= 1.5 * ctx->bvh8_area_built) {
+      if (ctx->d_face_node) hipLaunchKernelGGL(k_face_node_to_rec, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_face_node, n, ctx->d_face_rec);  // (k_face_records has just rewritten the records)
       for (int k = 0; k < 3; ++k) { ctx->scene_lo[k] = order_float(hb[k]) - 2.0f * pad; ctx->scene_hi[k] = order_float(hb[3 + k]) + 2.0f * pad; }
       ctx->bvh_valid = true;
       ctx->n_refits++;
@@ -1080,6 +1091,7 @@ int bvh_build_device(fh_ctx* ctx)
     if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[bvh] refit discarded: node area %.4f > 1.5 x %.4f, rebuilding\n", area, ctx->bvh8_area_built);
   }
   ctx->refit_ok = false;
+  ctx->bu_choice = 0; ctx->bu_toggle = 0; ctx->bu_cost[0] = ctx->bu_cost[1] = ctx->bu_items[0] = ctx->bu_items[1] = 0.0;  // a new tree: where its rays should start is measured again (render.hip)
   if (ctx->d_bvh8_box) { (void)hipFree(ctx->d_bvh8_box); ctx->d_bvh8_box = nullptr; }
   ctx->bvh8_level_start.clear();
   if (ctx->d_bvh2_nodes) { (void)hipFree(ctx->d_bvh2_nodes); ctx->d_bvh2_nodes = nullptr; }
@@ -1441,6 +1453,7 @@ int bvh_build_device(fh_ctx* ctx)
     FH_HIP(hipMalloc((void**)&ctx->d_bvh8_tris, sizeof(float4) * 3ull * n_slots));
     hipLaunchKernelGGL(k_clear_tris8, dim3((n_slots + 255) / 256), dim3(256), 0, st, ctx->d_bvh8_tris, n_slots);
     hipLaunchKernelGGL(k_emit_tris8, dim3(rblocks), dim3(256), 0, st, ctx->d_face_rec, ctx->d_face_cls, vals_b.p, tri_slot.p, nr, ctx->d_bvh8_tris, ref_face, ctx->d_face_node, ref_face ? split_count.p : (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_face_node_to_rec, dim3(blocks), dim3(256), 0, st, ctx->d_face_node, n, ctx->d_face_rec);
     FH_HIP(hipGetLastError());
     FH_HIP(hipStreamSynchronize(st));
     ctx->bvh8_n_nodes = final_counters[0];

@@ -139,6 +139,10 @@ struct fh_ctx {
   hipEvent_t ev_counters[3] = {nullptr, nullptr, nullptr};
   bool counters_in_flight[3] = {false, false, false};
   uint32_t counters_wave_depth[3] = {0, 0, 0};  // wave depth used by the pass the snapshot comes from
+  int counters_bu[3] = {-1, -1, -1};            // ... and, while the scene is being probed, where its first-hit rays started (0: the root, 1: the node of their face; -1: not a probing pass)
+  int bu_choice = 0;                            // 0: probing, 1: rays start at the root, 2: first-hit rays start at the node of the face they leave (render.hip; reset by every full BVH build)
+  uint32_t bu_toggle = 0;
+  double bu_cost[2] = {0.0, 0.0}, bu_items[2] = {0.0, 0.0};
   unsigned long long pass_seq = 0;           // passes submitted so far
   hipEvent_t ev_gen[3] = {nullptr, nullptr, nullptr}, ev_acc[3] = {nullptr, nullptr, nullptr}, ev_enter = nullptr;
   bool gen_valid[3] = {false, false, false}, acc_valid[3] = {false, false, false};
@@ -181,7 +185,8 @@ struct fh_ctx {
     uint32_t tail_paths = 0;        // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail; 0 = 65536, 262144 for passes of at most 4 Mi paths
     uint32_t sub_passes = 1;        // FH_SUBPASS=n (measured, profiles/README.md r5-4; off): a call that fits one pass is cut into n pixel sub-passes on the pass streams
     uint32_t sub_pass_min_paths = 1u << 19;  // FH_SUBPASS_MIN: ... from this many camera paths on
-    bool bottom_up = false;         // FH_BOTTOM_UP=1 (measured, profiles/README.md r5-2; off): rays that leave a surface start their traversal at the wide node that holds the face and climb
+    uint32_t bottom_up = 2;         // FH_BOTTOM_UP=0: every ray starts its traversal at the root; =1: first-hit rays of scenes without cut-outs start at the wide node that holds the face
+                                    // they leave and climb; default (2): the first passes after a build try both and the counted test rounds per shaded path decide (render.hip)
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
     bool debug_tail = false;        // FH_DEBUG_TAIL
     bool force_alpha = false;       // FH_FORCE_ALPHA=1 (timing experiments): the kernels with the any-hit path compiled in, whatever the scene

@@ -155,6 +155,8 @@ enum : uint32_t {
   CNT_CUR_CLOSEST = 2,  // work cursor of the persistent closest-hit kernel
   CNT_CUR_SEC = 3,      // work cursor of the persistent secondary kernel
   CNT_CLS = 4,        // kMaxClasses class-queue counts
+  CNT_COST_NODE = 12, // wave-level node-test rounds of this bounce's secondary (or merged) streaming launch, summed over its waves ...
+  CNT_COST_TRI = 13,  // ... and its wave-level triangle-test rounds: what the library weighs rays that start at the root against rays that start at their face with (render.hip)
   kCounterStride = 16,
 };
 static_assert(CNT_CLS + kMaxClasses <= kCounterStride, "counter block too small");

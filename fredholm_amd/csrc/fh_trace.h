@@ -450,6 +450,7 @@ struct GroupStack<false> {
   FH_D void push(uint2 g) { if (sp < kBvh8Stack) spill[sp++] = g; }
   FH_D uint2 pop() { return spill[--sp]; }
   FH_D void set_anchor(uint32_t node, uint32_t skip) { spill[0] = make_uint2(node, skip); }
+  FH_D void set_anchor_word(uint32_t v) { spill[0].x = v; }
   FH_D uint32_t anchor() const { return spill[0].x; }
   FH_D uint32_t anchor_skip() const { return spill[0].y; }
 };
@@ -486,6 +487,7 @@ struct GroupStack<true> {
   // entry 0 of a ray that started below the root (traverse_stream: bottom-up start) is not a group: it holds the node the ray climbs from next and, while that node's
   // parent is being visited, the child slot of the parent the ray came up through (always in LDS: every configuration keeps at least one level there)
   FH_D void set_anchor(uint32_t node, uint32_t skip) { word[0] = node; mask[0] = (uint8_t)skip; }
+  FH_D void set_anchor_word(uint32_t v) { word[0] = v; }
   FH_D uint32_t anchor() const { return word[0]; }
   FH_D uint32_t anchor_skip() const { return mask[0]; }
 };
@@ -764,7 +766,7 @@ FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float t
 #define FH_HANDOVER_SCAN 1
 #endif
 #ifndef FH_BOTTOM_UP_BUILD
-#define FH_BOTTOM_UP_BUILD 0  // (1: the streaming kernels can start rays below the root, traverse_stream; FH_BOTTOM_UP=1 then switches it on)
+#define FH_BOTTOM_UP_BUILD 1  // (the launches of first-hit rays in scenes without cut-outs can start rays below the root, traverse_stream; FH_BOTTOM_UP=1 switches it on)
 #endif
 #ifndef FH_HANDOVER_SCAN_ALPHA
 #define FH_HANDOVER_SCAN_ALPHA 1  // (0: the kernels with the any-hit test keep the ballot rounds -- the scan's registers can push them into scratch)
@@ -832,9 +834,10 @@ struct ChunkFeed {
 // ---------------------------------------------------------------------------------------------
 template <bool MIXED, bool COUNT, bool LDS, bool ALPHA, class Policy>
 FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, uint32_t& n_tris, WaveSteps* ws, const CoopLds& cl, uint32_t flush, uint32_t refill,
-                          uint2* lds_column, int lds_stride, const SceneDev* sc, StackSpill spill = StackSpill{nullptr, 0u}, const uint4* top = nullptr)
+                          uint2* lds_column, int lds_stride, const SceneDev* sc, StackSpill spill = StackSpill{nullptr, 0u}, const uint4* top = nullptr, uint32_t* cost = nullptr)
 {
   const uint32_t lane = __lane_id();
+  uint32_t cost_node = 0, cost_tri = 0;  // wave-uniform: rounds of node tests / of triangle tests this wave ran (added to cost[0] / cost[1] at the end, one atomic each per wave)
   GroupStack<LDS> stack(lds_column, spill.lds_entries ? (int)spill.lds_entries : lds_stride, spill.area, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x);
   // ---- Bottom-up start.  A ray that leaves a surface (every secondary ray, every closest-hit ray after the first bounce) starts INSIDE the tree: at the wide node that holds
   // the face it leaves (bvh.parent != null; the policy says which node).  It walks that node's subtree first, then climbs: the parent is visited with the child it came up
@@ -847,8 +850,11 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   // neighbours of the face the ray leaves come first) and is 10 % slower.  Hits do not depend on the order nodes are visited in (closest: minimum over the
   // accepted candidates, none of which a conservative node test can cull; first-hit: a yes / no), so the bits do not change.
   // State: `up` (the lane's ray still has levels to climb) and entry 0 of the lane's stack (GroupStack::set_anchor); the groups of the subtree being walked sit above it.
-  // Compiled in with -DFH_BOTTOM_UP_BUILD=1 only (tools/build_variant.sh): even switched off the climb costs the kernels with the any-hit test registers they do not have.
-  bool up = false;
+  // Second form (r5-8): no dependent load.  Entry 0 holds the LINK to climb through next (parent << 3 | child slot, bvh.parent[node]), and the link of every node a ray
+  // starts at or climbs to is fetched NEXT TO that node's own four loads (`fresh` / `climbing` visits) and put there after the node test.
+  // Compiled into the launches of rays that stop at their first hit in scenes without cut-outs (kUp below): the kernels with the any-hit test have no register for it.
+  constexpr bool kUp = FH_BOTTOM_UP_BUILD != 0 && MIXED && !ALPHA && LDS;
+  bool up = false, fresh = false;
   Ray8 r;
   r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct = 0u; r.nx = r.ny = r.nz = false;
   uint2 group = make_uint2(0u, 0u);
@@ -869,6 +875,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       // every candidate of a finished ray must be tested before the ray is committed: drain the queue
       while (q_count) {
         const uint32_t n = q_count < 64u ? q_count : 64u;
+        ++cost_tri;
         if (lane < n) coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
         q_head = (q_head + n) & (kCoopQueue - 1u);
         q_count -= n;
@@ -903,9 +910,9 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
           cl.uv[lane] = make_float2(0.0f, 0.0f);
           stack.sp = 0;
           have = true;
-          const uint32_t start = (FH_BOTTOM_UP_BUILD && bvh.parent) ? pol.start_node() : 0u;
-          up = start != 0u;
-          if (up) { stack.set_anchor(start, 8u); stack.sp = 1; }
+          const uint32_t start = (kUp && bvh.parent && any) ? pol.start_node() : 0u;  // (a ray that wants its closest hit climbs every level anyway: from the root)
+          up = fresh = start != 0u;
+          if (up) stack.sp = 1;  // (entry 0: the link to climb through, written when the start node has been visited)
           group = make_uint2(start, 0x80000000u);  // (hit bit 7 of a group without inner-child bits: node group.x itself)
           busy = bvh.n_nodes != 0u;
           if (COUNT) ray_n0 = n_nodes;
@@ -927,19 +934,20 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
     }
     bool climbing = false;  // this visit is the parent of the subtree just finished
     if (walk && (group.y & 0xff000000u) == 0u) {
-      if (stack.sp == (up ? 1 : 0)) {
-        if (!up) busy = walk = false;
+      if (stack.sp == ((kUp && up) ? 1 : 0)) {
+        if (!(kUp && up)) busy = walk = false;
         else {
-          const uint32_t link = bvh.parent[stack.anchor()];
+          const uint32_t link = stack.anchor();  // (fetched while the node below was visited)
           if (link == 0xffffffffu) busy = walk = false;  // the root's subtree is done
           else {
-            stack.set_anchor(link >> 3, link & 7u);
+            stack.set_anchor(link, link & 7u);
             group = make_uint2(link >> 3, 0x80000000u);
             climbing = true;
           }
         }
       } else group = stack.pop();
     }
+    if (__ballot(walk) != 0ull) ++cost_node;
 #if FH_NODE_FETCH_PAIR
     uint32_t ni = 0u;
     if (walk) {
@@ -967,8 +975,11 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       const uint32_t slot = ordered ? (bit - 24u) ^ r.oct : bit - 24u;
       const uint32_t ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
+      uint32_t next_link = 0u;
+      if (kUp && (climbing || fresh)) next_link = bvh.parent[ni];  // this node's own way up, in flight next to its four loads
       node8_visit<ordered>(bvh, r, ni, best_t, group, tg, top);
-      if (climbing) group.y &= ~(1u << (24u + (ordered ? (stack.anchor_skip() ^ r.oct) : stack.anchor_skip())));  // the child the ray came up through has been walked
+      if (kUp && climbing) group.y &= ~(1u << (24u + (ordered ? (stack.anchor_skip() ^ r.oct) : stack.anchor_skip())));  // the child the ray came up through has been walked
+      if (kUp && (climbing || fresh)) { stack.set_anchor_word(next_link); fresh = false; }
     }
 #endif
     if (FH_HANDOVER_SCAN && (!ALPHA || FH_HANDOVER_SCAN_ALPHA)) {
@@ -988,6 +999,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       }
       q_count += total;
       while (q_count >= 64u) {
+        ++cost_tri;
         coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
         q_head = (q_head + 64u) & (kCoopQueue - 1u);
         q_count -= 64u;
@@ -1006,6 +1018,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       }
       q_count += (uint32_t)__popcll(m);
       if (q_count >= 64u) {
+        ++cost_tri;
         coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
         q_head = (q_head + 64u) & (kCoopQueue - 1u);
         q_count -= 64u;
@@ -1013,12 +1026,14 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
     }
     if (q_count >= flush) {
       const uint32_t n = q_count;  // < 64 here
+      ++cost_tri;
       if (lane < n) coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
       q_head = (q_head + n) & (kCoopQueue - 1u);
       q_count = 0u;
     }
     if (AlphaDefer<MIXED, ALPHA>::value) alpha_flush<MIXED>(cl, sc, kAlphaFlush);
   }
+  if (cost && lane == 0u) { atomicAdd(cost, cost_node); atomicAdd(cost + 1, cost_tri); }
 }
 
 template <bool ANY_HIT, bool COUNT>

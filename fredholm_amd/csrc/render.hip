@@ -716,6 +716,7 @@ struct ShadeOut {      // register sink (k_tail)
   FH_D void secondary(uint32_t slot, f3 o, float tmax, f3 d, bool active, f3 c) { shaded = true; sec[slot] = SecRay{o, tmax, d, active, c}; }
   FH_D void light_pending(f3 t, float c, f3 f, float pdf) { lp_T = t; lp_cos = c; lp_f = f; lp_pdf = pdf; }
   FH_D void next(f3 o, f3 d, f3 t) { cont = true; next_o = o; next_d = d; T = t; }
+  FH_D void start_node(uint32_t) {}  // (the fused tail's rays start at the root)
 };
 
 struct PoolSink {      // memory sink (k_shade): path slot p of the pool
@@ -735,6 +736,7 @@ struct PoolSink {      // memory sink (k_shade): path slot p of the pool
     pool.flags[p] |= 1u;
   }
   FH_D void emissive(f3 l) { pool.rad[p] = mk4(l, 0.0f); }
+  FH_D void start_node(uint32_t bits) { start_bits = bits ? bits : 1u; }
   FH_D void secondary(uint32_t slot, f3 o, float tmax, f3 d, bool active, f3 c)
   {
     store_secondary(pool, slot, p, o, tmax, d, active, c, start_bits);
@@ -765,6 +767,8 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows<4>& 
   const float4 r0 = sc.face_rec[7 * (size_t)prim], r1 = sc.face_rec[7 * (size_t)prim + 1], r2 = sc.face_rec[7 * (size_t)prim + 2];
   const float4 r3 = sc.face_rec[7 * (size_t)prim + 3], r4 = sc.face_rec[7 * (size_t)prim + 4], r5 = sc.face_rec[7 * (size_t)prim + 5];
   const float4 r6 = sc.face_rec[7 * (size_t)prim + 6];
+  // (.z of the record's last vector: 1 + the wide node that holds the face, written by the BVH build -- where this bounce's first-hit rays start their traversal, fh_trace.h)
+  out.start_node(sc.face_node ? __float_as_uint(r6.z) : 0u);
   const f3 p0 = mk3(r0), p1 = mk3(r1), p2 = mk3(r2);
   const float bw = 1.0f - bu - bv;
   const f3 x = bw * p0 + bu * p1 + bv * p2;
@@ -1022,8 +1026,7 @@ __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : BLOCKS)) k_shade
     if (valid) {
       p = q[i];
       const float4 hit = pool.hit[p];
-      // the rays of this bounce leave the face that was hit: they start their traversal at the wide node that holds it (fh_trace.h: bottom-up start)
-      PoolSink o(pool, p, hit.x, sc.face_node ? sc.face_node[__float_as_uint(hit.w)] + 1u : 1u);
+      PoolSink o(pool, p, hit.x);
       const bool first = depth != 0 || (pool.flags[p] & 4u) == 0u;
       const f3 L = depth == 0u ? mk3(pool.rad[p]) : mk3(0.0f);  // the radiance so far only enters at a directly visible emitter (first hit): later bounces skip the load
       shade_hit<LOBES>(sc, fr, rows, bs, depth, hit, mk3(pool.ray_d[p]), mk3(pool.thr[p]), L, pool.pixel[p], pool.nspp[p], o, first);
@@ -1276,7 +1279,8 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
   SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)), tc.hist);
   __shared__ uint4 lds_top[FH_TOP_LDS ? kTopNodes * 4 : 1];
   if (FH_TOP_LDS) stage_top_nodes(sc.bvh8, lds_top);
-  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr);
+  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr,
+                                            pool.counters + depth * kCounterStride + CNT_COST_NODE);
   pol.finish();
   stamp.commit(tc.clk);
   if (COUNT) {
@@ -1347,7 +1351,8 @@ __global__ void __launch_bounds__(kBlock, LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : (
   MergedStream<LIGHTS> pol(sc, fr, ps, pn, pn.q_rad[(depth + 1u) & 1u], n_sec, ChunkFeed(ps.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)));
   __shared__ uint4 lds_top[FH_TOP_LDS ? kTopNodes * 4 : 1];
   if (FH_TOP_LDS) stage_top_nodes(sc.bvh8, lds_top);
-  traverse_stream<true, false, true, ALPHA>(sc.bvh8, pol, nn, nt, nullptr, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr);
+  traverse_stream<true, false, true, ALPHA>(sc.bvh8, pol, nn, nt, nullptr, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr,
+                                            ps.counters + depth * kCounterStride + CNT_COST_NODE);
   pol.sec.finish();
   stamp.commit(tc.clk);
 }
@@ -1680,8 +1685,9 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.bvh8.depth = stack_entries_for(ctx->bvh8_depth);
   s.use_bvh8 = ctx->use_bvh8 ? 1u : 0u;
   // bottom-up start (fh_trace.h): rays that leave a surface begin at the wide node that holds the face.  Only the streaming kernels climb; they trace trees of 4096 nodes and more
-  const bool bottom_up = ctx->tun.bottom_up && ctx->use_bvh8 && ctx->d_bvh8_parent && ctx->d_face_node && ctx->tun.coop && ctx->tun.stream && (ctx->tun.stream_forced || ctx->bvh8_n_nodes >= 4096u) &&
-                         ctx->bvh8_n_tris < kCoopMaxTris;
+  // (what the scene CAN do; render_submit switches it per pass: forced by FH_BOTTOM_UP, else by what the first passes of the scene measure)
+  const bool bottom_up = ctx->tun.bottom_up != 0 && ctx->use_bvh8 && ctx->d_bvh8_parent && ctx->d_face_node && ctx->tun.coop && ctx->tun.stream && (ctx->tun.stream_forced || ctx->bvh8_n_nodes >= 4096u) &&
+                         ctx->bvh8_n_tris < kCoopMaxTris && !(((ctx->has_alpha && !ctx->tun.ignore_alpha) || ctx->tun.force_alpha));
   s.bvh8.parent = bottom_up ? ctx->d_bvh8_parent : nullptr;
   s.face_node = bottom_up ? ctx->d_face_node : nullptr;
   return s;
@@ -2004,7 +2010,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   // (the passes of a call overlap, three in flight: a big call that would fit two passes is cut into three of the same size)
   if ((n_samples + batch - 1u) / batch < (uint32_t)ctx->n_slots && n_samples >= (uint32_t)ctx->n_slots && (unsigned long long)n_samples * n_px >= 3ull << 24) batch = (n_samples + (uint32_t)ctx->n_slots - 1u) / (uint32_t)ctx->n_slots;
 
-  const SceneDev sc = scene_dev(ctx);
+  const SceneDev sc_all = scene_dev(ctx);
+  const SceneDev& sc = sc_all;  // (the passes below shadow this with their own copy: where rays start is a per-pass choice)
   const bool count = (ctx->flags & FH_FLAG_COUNT_TRAVERSAL) != 0;
   const bool clocks = (ctx->flags & FH_FLAG_TIME_KERNELS) != 0;
   TraceCounters tc_closest{ctx->d_trace_counters, ctx->d_trace_counters + 1, ctx->d_trace_counters + 2, ctx->d_trace_counters + 6, ctx->d_trace_counters + 7, ctx->d_trace_counters + 10,
@@ -2219,6 +2226,19 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     { const int rc = pool_ensure(ctx, slot, n_px * batch); if (rc) return rc; }
     const PoolDev& pool = ctx->pool[slot];
     FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
+    // ---- where this pass's first-hit rays start their traversal (fh_trace.h: bottom-up start): forced by FH_BOTTOM_UP=0 / 1; else the first passes after a build alternate and
+    // the device's own count of test rounds per shaded path decides (above): a dense scene gains (1M-triangle soup: -12 %), an interior of long rays does not (-0.4 %)
+    int pass_bu = -1;  // -1: not a probing pass
+    bool use_bu = false;
+    if (sc_all.bvh8.parent && stream) {
+      if (tun.bottom_up == 1u) use_bu = true;
+      else if (tun.bottom_up == 2u) {
+        if (ctx->bu_choice == 0 && !count) { use_bu = (ctx->bu_toggle++ & 1u) != 0u; pass_bu = use_bu ? 1 : 0; }
+        else use_bu = ctx->bu_choice == 2;
+      }
+    }
+    SceneDev sc = sc_all;
+    if (!use_bu) { sc.bvh8.parent = nullptr; sc.face_node = nullptr; }
     if (prev != slot && ctx->gen_valid[prev]) FH_HIP(hipStreamWaitEvent(st, ctx->ev_gen[prev], 0));
     {
       Span sp(ctx, st, 4);
@@ -2257,6 +2277,17 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         pick = wd + more;
       }
       ctx->auto_wave_depth = pick;
+      if (ctx->counters_bu[k] >= 0 && ctx->bu_choice == 0) {  // (a pass of the scene's probing phase: what its secondary launches cost, by the issue model's weights)
+        double cost = 0.0, items = 0.0;
+        for (uint32_t d = 0; d < wd; ++d) { cost += 510.0 * hc[d * kCounterStride + CNT_COST_NODE] + 175.0 * hc[d * kCounterStride + CNT_COST_TRI]; items += hc[d * kCounterStride + CNT_SEC]; }
+        ctx->bu_cost[ctx->counters_bu[k]] += cost; ctx->bu_items[ctx->counters_bu[k]] += items;
+        if (ctx->bu_items[0] >= 65536.0 && ctx->bu_items[1] >= 65536.0) {
+          const double off = ctx->bu_cost[0] / ctx->bu_items[0], on = ctx->bu_cost[1] / ctx->bu_items[1];
+          ctx->bu_choice = on < 0.95 * off ? 2 : 1;
+          if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[trace] rays that leave a surface start at %s: %.0f against %.0f SIMD cycles of tests per shaded path (from the root / from the face)\n", ctx->bu_choice == 2 ? "the node of their face" : "the root", off, on);
+        }
+      }
+      ctx->counters_bu[k] = -1;
       if (tun.debug_tail) { fprintf(stderr, "[tail] slot %d wd %u pick %u survivors:", k, wd, pick); for (uint32_t d = 0; d <= wd; ++d) fprintf(stderr, " %u", ctx->h_counters[k][d * kCounterStride + CNT_RAD]); fprintf(stderr, "\n"); }
     }
     uint32_t wave_depth = ctx->tail_depth ? ctx->tail_depth : ctx->auto_wave_depth;
@@ -2375,6 +2406,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       FH_HIP(hipEventRecord(ctx->ev_counters[slot], st));
       ctx->counters_in_flight[slot] = true;
       ctx->counters_wave_depth[slot] = wave_depth;
+      ctx->counters_bu[slot] = pass_bu;
     }
   }
   }  // (pixel sub-passes)
