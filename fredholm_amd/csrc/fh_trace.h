@@ -492,7 +492,8 @@ struct GroupStack<true> {
   FH_D uint32_t anchor_skip() const { return mask[0]; }
 };
 // where the streaming kernels put stack entries beyond the LDS part (null: everything in LDS)
-struct StackSpill { uint2* area; uint32_t lds_entries; };  // lds_entries: levels kept in LDS when area is set
+struct StackSpill { uint2* area; uint32_t lds_entries; uint32_t probe = 0; };  // lds_entries: levels the launch keeps in LDS; probe: the launch adds its test rounds to the bounce's
+                                                                              // CNT_COST_* words (two atomics per wave: only the passes that decide where rays start ask for it, render.hip)
 // dynamic LDS of one 256-thread workgroup whose lanes keep `depth` stack entries there
 FH_HD uint32_t lds_stack_bytes(uint32_t depth) { return (depth * 256u * 5u + 15u) & ~15u; }
 // Entries a traversal stack needs for a tree of `levels` node levels: a group is pushed while the ray descends into one of its nodes with siblings still to
@@ -853,7 +854,9 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   // Second form (r5-8): no dependent load.  Entry 0 holds the LINK to climb through next (parent << 3 | child slot, bvh.parent[node]), and the link of every node a ray
   // starts at or climbs to is fetched NEXT TO that node's own four loads (`fresh` / `climbing` visits) and put there after the node test.
   // Compiled into the launches of rays that stop at their first hit in scenes without cut-outs (kUp below): the kernels with the any-hit test have no register for it.
-  constexpr bool kUp = FH_BOTTOM_UP_BUILD != 0 && MIXED && !ALPHA && LDS;
+  // ... and only into the secondary launch (Policy::can_climb): the merged launch of one-pass calls carries two policies' state and has no register to give either
+  // (with the climb and the two round counters compiled in it went to 12-32 bytes of scratch and a 16-spp call of configs[3] from 51.6 to 56.2 ms).
+  constexpr bool kUp = FH_BOTTOM_UP_BUILD != 0 && MIXED && !ALPHA && LDS && Policy::can_climb;
   bool up = false, fresh = false;
   Ray8 r;
   r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct = 0u; r.nx = r.ny = r.nz = false;
@@ -875,7 +878,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       // every candidate of a finished ray must be tested before the ray is committed: drain the queue
       while (q_count) {
         const uint32_t n = q_count < 64u ? q_count : 64u;
-        ++cost_tri;
+        if (kUp) ++cost_tri;
         if (lane < n) coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
         q_head = (q_head + n) & (kCoopQueue - 1u);
         q_count -= n;
@@ -947,7 +950,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
         }
       } else group = stack.pop();
     }
-    if (__ballot(walk) != 0ull) ++cost_node;
+    if (kUp && __ballot(walk) != 0ull) ++cost_node;
 #if FH_NODE_FETCH_PAIR
     uint32_t ni = 0u;
     if (walk) {
@@ -999,7 +1002,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       }
       q_count += total;
       while (q_count >= 64u) {
-        ++cost_tri;
+        if (kUp) ++cost_tri;
         coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
         q_head = (q_head + 64u) & (kCoopQueue - 1u);
         q_count -= 64u;
@@ -1018,7 +1021,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       }
       q_count += (uint32_t)__popcll(m);
       if (q_count >= 64u) {
-        ++cost_tri;
+        if (kUp) ++cost_tri;
         coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
         q_head = (q_head + 64u) & (kCoopQueue - 1u);
         q_count -= 64u;
@@ -1026,14 +1029,14 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
     }
     if (q_count >= flush) {
       const uint32_t n = q_count;  // < 64 here
-      ++cost_tri;
+      if (kUp) ++cost_tri;
       if (lane < n) coop_test<MIXED, COUNT, ALPHA, AlphaDefer<MIXED, ALPHA>::value>(bvh, cl, cl.queue[(q_head + lane) & (kCoopQueue - 1u)], n_tris, ws, sc);
       q_head = (q_head + n) & (kCoopQueue - 1u);
       q_count = 0u;
     }
     if (AlphaDefer<MIXED, ALPHA>::value) alpha_flush<MIXED>(cl, sc, kAlphaFlush);
   }
-  if (cost && lane == 0u) { atomicAdd(cost, cost_node); atomicAdd(cost + 1, cost_tri); }
+  if (kUp && cost && lane == 0u) { atomicAdd(cost, cost_node); atomicAdd(cost + 1, cost_tri); }
 }
 
 template <bool ANY_HIT, bool COUNT>

@@ -485,6 +485,7 @@ FH_D uint32_t start_node_of(const float4& d4) { const uint32_t b = __float_as_ui
 template <bool COUNT>
 struct ClosestStream {
   static constexpr bool all_any = false;
+  static constexpr bool can_climb = false;
   const PoolDev& pool;
   const uint32_t* q;
   ChunkFeed feed;
@@ -1192,6 +1193,7 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? 5 : 6)) k_trace_
 template <bool COUNT, bool LIGHTS>
 struct SecondaryStream {
   static constexpr bool all_any = !LIGHTS;  // without emitters every secondary ray stops at its first hit
+  static constexpr bool can_climb = true;   // first-hit rays may start at the node of the face they leave (fh_trace.h: bottom-up start)
   const SceneDev& sc;
   const FrameDev& fr;
   const PoolDev& pool;
@@ -1280,7 +1282,7 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
   __shared__ uint4 lds_top[FH_TOP_LDS ? kTopNodes * 4 : 1];
   if (FH_TOP_LDS) stage_top_nodes(sc.bvh8, lds_top);
   traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr,
-                                            pool.counters + depth * kCounterStride + CNT_COST_NODE);
+                                            spill.probe ? pool.counters + depth * kCounterStride + CNT_COST_NODE : nullptr);
   pol.finish();
   stamp.commit(tc.clk);
   if (COUNT) {
@@ -1301,6 +1303,7 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
 template <bool LIGHTS>
 struct MergedStream {
   static constexpr bool all_any = false;
+  static constexpr bool can_climb = false;
   SecondaryStream<false, LIGHTS> sec;
   const PoolDev& next;        // the view whose radiance queue of bounce b + 1 is traced
   const uint32_t* q_closest;
@@ -1352,7 +1355,7 @@ __global__ void __launch_bounds__(kBlock, LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : (
   __shared__ uint4 lds_top[FH_TOP_LDS ? kTopNodes * 4 : 1];
   if (FH_TOP_LDS) stage_top_nodes(sc.bvh8, lds_top);
   traverse_stream<true, false, true, ALPHA>(sc.bvh8, pol, nn, nt, nullptr, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr,
-                                            ps.counters + depth * kCounterStride + CNT_COST_NODE);
+                                            spill.probe ? ps.counters + depth * kCounterStride + CNT_COST_NODE : nullptr);
   pol.sec.finish();
   stamp.commit(tc.clk);
 }
@@ -2351,7 +2354,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
           hipLaunchKernelGGL((k_trace_merged_stream<decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stream_stack_bytes_secondary, st, sc,
                              fr, ps, pd, depth, tc_shadow, coop_flush, stream_refill, stream_chunk, tun.stream_min_rays,
-                             StackSpill{spill_entries_secondary ? ctx->d_stack_spill + (size_t)(2 * slot + 1) * spill_region : nullptr, stream_entries_secondary});
+                             StackSpill{spill_entries_secondary ? ctx->d_stack_spill + (size_t)(2 * slot + 1) * spill_region : nullptr, stream_entries_secondary, pass_bu >= 0 ? 1u : 0u});
         }); });
         ctx->stats.n_shadow_launches++;
         ctx->stats.n_closest_launches++;
@@ -2362,7 +2365,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
             hipLaunchKernelGGL((k_trace_secondary_stream<decltype(C)::value, decltype(Li)::value, decltype(A)::value>), dim3(grid < stream_grid_secondary ? grid : stream_grid_secondary), dim3(kBlock), stream_stack_bytes_secondary, sb, sc,
                                fr, ps, depth, tc_shadow, coop_flush, stream_refill, stream_chunk, tun.stream_min_rays,
-                               StackSpill{spill_entries_secondary ? ctx->d_stack_spill + (size_t)(2 * slot + 1) * spill_region : nullptr, stream_entries_secondary});
+                               StackSpill{spill_entries_secondary ? ctx->d_stack_spill + (size_t)(2 * slot + 1) * spill_region : nullptr, stream_entries_secondary, pass_bu >= 0 ? 1u : 0u});
           }); }); });
         } else if (coop) {
           with_bool(count, [&](auto C) { with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
