@@ -550,11 +550,17 @@ def test_reference_firsthit_bug_compat_mode(oracle, scene_name):
     r.close()
 
 
-def test_moving_instances_refit_the_tree_and_match_checker_and_rebuild(oracle, monkeypatch):
-    """Renderer::set_time only moves instances (renderer.h:614-640: the reference rebuilds its IAS, never a GAS).  The flattened tree is
+@pytest.mark.parametrize("start", ["auto", "face"])
+def test_moving_instances_refit_the_tree_and_match_checker_and_rebuild(oracle, monkeypatch, start):
+    """(start = "face": the streaming kernels forced, first-hit rays forced to start at the node of the face they leave -- the start node rides in the face records, which
+    fh_set_transforms rewrites and the refit has to fill in again.)
+    Renderer::set_time only moves instances (renderer.h:614-640: the reference rebuilds its IAS, never a GAS).  The flattened tree is
     refitted then (bvh_build.hip: face records re-derived on the device, triangle copies refreshed, boxes recomputed bottom up) -- at three
     animation times the refitted tree, a tree rebuilt from scratch and the checker agree bit for bit, on rays and on rendered frames; a
     motion that blows the boxes up falls back to the rebuild by itself."""
+    if start == "face":
+        monkeypatch.setenv("FH_STREAM", "1")
+        monkeypatch.setenv("FH_BOTTOM_UP", "1")
     base = scenes.triangle_soup(24000, 0.06)
     nf = base["indices"].shape[0]
     inst = (np.arange(nf) * 4 // nf).astype(np.uint32)  # four rigid bodies
@@ -581,6 +587,8 @@ def test_moving_instances_refit_the_tree_and_match_checker_and_rebuild(oracle, m
     r.build_ias()
     r.load_arhosek_sky(3.0, 0.3)
     r.set_resolution(w, h)
+    if start == "face":
+        r.set_path_pool(w * h)  # two passes per call: the secondary launch proper (the merged launch of one-pass calls never climbs)
     L = F.RenderLayer(r, w, h)
     rng = np.random.default_rng(8)
     rays = _rays(rng, 30000, -1.4, 1.4)
@@ -784,7 +792,8 @@ def test_rays_that_start_at_the_node_of_their_face_do_not_change_results(oracle,
         x.load_arhosek_sky(3.0, 0.3)
 
     for sc in (scenes.triangle_soup(30000, 0.08), scenes.soup_with_emitters(30000, 0.08)):
-        gpu, ref = _render_pair(oracle, sc, cam, 96, 54, launches=5, spp_per_launch=2, depth=6, setup=setup)
+        # (a pool of one sample per pixel: every call is two passes, so the secondary launch proper runs -- the merged launch of one-pass calls never climbs)
+        gpu, ref = _render_pair(oracle, sc, cam, 96, 54, launches=5, spp_per_launch=2, depth=6, setup=setup, pool=96 * 54)
         for name in ("beauty", "position", "albedo"):
             _assert_image_parity(gpu[name], ref[name])
 
