@@ -856,6 +856,28 @@ def test_fractions_outside_0_1_are_never_printed():
     assert bench.refuse_bad_fracs(out) == []
 
 
+def test_scaling_model_and_static_instruction_mix_come_from_committed_files():
+    """bench.py quotes two more things it cannot measure in its own run: the emulated 8-shard scaling of the render phase (tools/shard_time.py ->
+    profiles/r*_shard_times.jsonl: one GPU rendered EVERY shard in turn) and the static FMA-class share of the dominant kernel's code object
+    (tools/isa_fma_share.py -> profiles/r*_isa_fma_share.json), which turns executed VALU instructions into `roofline.valu_busy_measured`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for cfg, spp in ((2, 1024), (3, 540), (2, 16)):
+        m = bench.scaling_model(cfg, spp)
+        assert m and m["emulated"] is True and m["world"] == 8 and m["from"].startswith("profiles/") and os.path.exists(os.path.join(ROOT, m["from"]))
+        assert 1.0 < m["render_speedup"] <= 8.0 and abs(m["render_speedup"] - m["whole_ms"] / m["slowest_shard_ms"]) < 0.01 and 1.0 <= m["max_over_mean"] < 1.08
+        assert abs(m["efficiency"] - m["render_speedup"] / 8.0) < 1e-3
+    assert bench.scaling_model(2, 1024)["spp"] == 1024 and bench.scaling_model(2, 16)["spp"] == 16 and bench.scaling_model(1, 256) is None
+    for kernel in ("k_trace_secondary_stream<false, false, false>", "k_trace_secondary_stream<false, false, true>", "k_trace_closest_stream<false, false>", "k_shade<68u, 2>"):
+        f = bench.fma_share_of(kernel)
+        assert f and 0.15 < f["share"] < 0.6 and f["stale"] in (True, False) and os.path.exists(os.path.join(ROOT, f["source"]))
+    assert bench.fma_share_of("k_no_such_kernel") is None
+    # the two issue classes side by side: an instruction of a mix with share s of the fast class costs max(s x 2.2, (1 - s) x 4.1) cycles
+    s_ = bench.fma_share_of("k_trace_secondary_stream<false, false, false>")["share"]
+    cyc = max(s_ / bench.VALU_FMA_PEAK_PER_CYCLE, (1.0 - s_) / bench.VALU_OTHER_PEAK_PER_CYCLE)
+    assert 2.2 <= cyc <= 4.1
+
+
 def test_committed_issue_model_file_is_well_formed():
     sys.path.insert(0, ROOT)
     import glob
