@@ -9,7 +9,10 @@
 //   5. bottom-up box refit with arrival counters               (k_refit)
 //   6. emit the traversal layout: 64-byte two-child nodes whose children are inner nodes or leaves of
 //      <= 4 Morton-contiguous triangles, and the triangle array in leaf order (k_emit2 / k_emit_tris)
-//   7. collapse to the 8-wide quantised layout the traversal kernels prefer (bvh8 section)
+//   6a. optionally PLOC instead of the radix tree (chosen per scene by summed inner-node area) and SAH refinement by parallel reinsertion (FH_SAH_ITERS; off: it lowers
+//      the area and not the visits, profiles/README.md r5-1)
+//   7. collapse to the 8-wide quantised layout the traversal kernels prefer (bvh8 section), with the way up -- per wide node parent << 3 | child slot, per face the node
+//      that holds it (also written into the face record) -- for rays that start at their face (fh_trace.h)
 // Triangle order is the Morton order, so leaf reads are contiguous 48-byte records.
 #include <hip/hip_runtime.h>
 

@@ -840,23 +840,20 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   const uint32_t lane = __lane_id();
   uint32_t cost_node = 0, cost_tri = 0;  // wave-uniform: rounds of node tests / of triangle tests this wave ran (added to cost[0] / cost[1] at the end, one atomic each per wave)
   GroupStack<LDS> stack(lds_column, spill.lds_entries ? (int)spill.lds_entries : lds_stride, spill.area, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x);
-  // ---- Bottom-up start.  A ray that leaves a surface (every secondary ray, every closest-hit ray after the first bounce) starts INSIDE the tree: at the wide node that holds
-  // the face it leaves (bvh.parent != null; the policy says which node).  It walks that node's subtree first, then climbs: the parent is visited with the child it came up
-  // through masked out, the siblings' subtrees are walked with the ordinary stack, and so on to the root -- the same nodes a walk from the root visits for a ray that reaches
-  // nothing, in the order nearest first.  A ray that stops at its first hit and finds one near its origin (1M-triangle soup: mean free path 0.05 in a scene of size 2) never
-  // sees the upper levels, which a walk from the root pays for every ray (9 of its 15 node visits); a closest-hit ray climbs with its limit already at the near hit, so the
-  // siblings are culled by their parent's node test instead of being popped one by one.  MEASURED (profiles/README.md r5-2) and OFF by default (FH_BOTTOM_UP=1): on the soup a
-  // secondary ray visits 11.8 nodes instead of 15.3 and the kernel takes the same 29.6 ms per 256 spp (one more dependent load per level climbed, shorter rays = more refills;
-  // the kernel sits on the vector L1's look-up rate as much as on issue); on the Sponza-class interior, where rays are long, it tests 15 % more triangles (the coplanar
-  // neighbours of the face the ray leaves come first) and is 10 % slower.  Hits do not depend on the order nodes are visited in (closest: minimum over the
-  // accepted candidates, none of which a conservative node test can cull; first-hit: a yes / no), so the bits do not change.
-  // State: `up` (the lane's ray still has levels to climb) and entry 0 of the lane's stack (GroupStack::set_anchor); the groups of the subtree being walked sit above it.
-  // Second form (r5-8): no dependent load.  Entry 0 holds the LINK to climb through next (parent << 3 | child slot, bvh.parent[node]), and the link of every node a ray
-  // starts at or climbs to is fetched NEXT TO that node's own four loads (`fresh` / `climbing` visits) and put there after the node test.
-  // Compiled into the launches of rays that stop at their first hit in scenes without cut-outs (kUp below): the kernels with the any-hit test have no register for it.
-  // ... and only into the secondary launch (Policy::can_climb): the merged launch of one-pass calls carries two policies' state and has no register to give either
-  // (with the climb and the two round counters compiled in it went to 12-32 bytes of scratch and a 16-spp call of configs[3] from 51.6 to 56.2 ms).
-  constexpr bool kUp = FH_BOTTOM_UP_BUILD != 0 && MIXED && !ALPHA && LDS && Policy::can_climb;
+  // ---- Where a ray starts (round 5, profiles/README.md r5-2 / r5-8).  A first-hit ray that leaves a surface may start INSIDE the tree: at the wide node that holds the face
+  // it leaves (bvh.parent != null; the policy says which node).  It walks that node's subtree first, then climbs: the parent is visited with the child the ray came up
+  // through masked out, its other children are walked with the ordinary stack, and so on to the root -- the nodes a walk from the root visits for a ray that reaches nothing,
+  // nearest first, and only the near ones for a ray that is stopped near its origin (1M-triangle soup: mean free path 0.05 in a scene of size 2; a walk from the root pays
+  // nine levels for it: 15.3 -> 11.8 node visits per secondary ray).  Hits do not depend on the order nodes are visited in (first-hit: a yes / no), so the bits do not change.
+  // State: `up` (the ray still has levels to climb) and entry 0 of the lane's stack, which holds the LINK to climb through next (parent << 3 | child slot, bvh.parent[node]);
+  // the groups of the subtree being walked sit above it.  No load depends on another: the link of every node a ray starts at (`fresh`) or climbs to (`climbing`) is fetched
+  // NEXT TO that node's own four loads and put into entry 0 after the node test.  (First form, r5-2: the link loaded when the climb happens -- 23 % fewer visits and not a
+  // microsecond gained.)  Rays that want their closest hit start at the root: they climb every level anyway.
+  // Compiled into the secondary launch of scenes without cut-outs only (kUp): the kernels with the any-hit test have no register for it, and neither has the merged launch of
+  // one-pass calls, which carries two policies' state (with the climb and the round counters compiled in it went to 12-32 bytes of scratch and a 16-spp call of configs[3]
+  // from 51.6 to 56.2 ms); not with the pair fetch (FH_NODE_FETCH_PAIR), whose visit does not fetch links.  Whether a scene starts its rays this way is decided per scene by
+  // the host from the round counters below (render.hip; FH_BOTTOM_UP=0 / 1 forces either): dense scenes gain 2-5 % of a frame, interiors of long rays lose 2 %.
+  constexpr bool kUp = FH_BOTTOM_UP_BUILD != 0 && FH_NODE_FETCH_PAIR == 0 && MIXED && !ALPHA && LDS && Policy::can_climb;
   bool up = false, fresh = false;
   Ray8 r;
   r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct = 0u; r.nx = r.ny = r.nz = false;
@@ -966,7 +963,6 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       uint4 n0, n1, n2, n3;
       node8_fetch_pair(bvh, walk, ni, n0, n1, n2, n3);  // (all 64 lanes)
       if (walk) node8_eval(r, ni, n0, n1, n2, n3, best_t, group, tg);
-      if (walk && climbing) group.y &= ~(1u << (24u + (stack.anchor_skip() ^ r.oct)));
     }
 #else
     if (walk) {
