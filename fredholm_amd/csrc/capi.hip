@@ -140,12 +140,12 @@ static int texel_span(float lo, float hi, uint32_t n, int& first, int& count)
   count = (int)(f1 - f0) + 1;
   return 1;
 }
-// 1: every texel of the footprint passes the 0.5 threshold, 2: none does, 0: mixed (or not decided)
-static uint32_t footprint_class(const uint8_t* rgba8, uint32_t w, uint32_t h, uint32_t channel, const float* decode, const float uv[6])
+// 1: every texel of the footprint passes the 0.5 threshold, 2: none does, 0: mixed (or not decided).  uv: n_pts texture coordinates whose bounding rectangle is the footprint
+static uint32_t footprint_class(const uint8_t* rgba8, uint32_t w, uint32_t h, uint32_t channel, const float* decode, const float* uv, int n_pts = 3)
 {
   if (!rgba8 || w == 0 || h == 0) return 0u;
   float ulo = uv[0], uhi = uv[0], vlo = uv[1], vhi = uv[1];
-  for (int k = 1; k < 3; ++k) { ulo = std::fmin(ulo, uv[2 * k]); uhi = std::fmax(uhi, uv[2 * k]); vlo = std::fmin(vlo, uv[2 * k + 1]); vhi = std::fmax(vhi, uv[2 * k + 1]); }
+  for (int k = 1; k < n_pts; ++k) { ulo = std::fmin(ulo, uv[2 * k]); uhi = std::fmax(uhi, uv[2 * k]); vlo = std::fmin(vlo, uv[2 * k + 1]); vhi = std::fmax(vhi, uv[2 * k + 1]); }
   if (!(std::fabs(ulo) < 1e6f) || !(std::fabs(uhi) < 1e6f) || !(std::fabs(vlo) < 1e6f) || !(std::fabs(vhi) < 1e6f)) return 0u;  // (huge or non-finite coordinates: left to the test)
   int x0, nx, y0, ny;
   texel_span(ulo, uhi, w, x0, nx);
@@ -210,6 +210,7 @@ int rebuild_device_scene(fh_ctx* ctx)
   bool opacity_classes = true;
   if (const char* e = getenv("FH_OPACITY_CLASSES")) opacity_classes = e[0] != '0';
   for (int k = 0; k < 4; ++k) ctx->alpha_face_counts[k] = 0;
+  for (int k = 0; k < 3; ++k) ctx->alpha_cell_counts[k] = 0;
   float srgb_table[256];
   for (int i = 0; i < 256; ++i) srgb_table[i] = fht_srgb_to_linear((float)i * (1.0f / 255.0f));
   for (uint32_t f = 0; f < nf; ++f) {
@@ -277,28 +278,60 @@ int rebuild_device_scene(fh_ctx* ctx)
   if (ctx->d_alpha_rec) { (void)hipFree(ctx->d_alpha_rec); ctx->d_alpha_rec = nullptr; }
   if (any_alpha) {
     // everything the any-hit test of a face reads, in one 64-byte line: the three texture coordinates and the two textures it may have to look at
-    std::vector<uint4> rec(4ull * nf, make_uint4(0u, 0u, 0u, 0u));
+    // ... and, behind them (second 64-byte line), the face's OPACITY MICROMAP: the face cut into 16 x 16 cells of its barycentrics (cell = (floor(16 u), floor(16 v)), the
+    // v1 / v2 weights of a hit), two bits per cell -- 0: test, 1: the test passes everywhere in the cell, 2: nowhere -- decided like the per-face classes above from the texels
+    // the cell can address (the cell's four corners, moved out by 10^-4 for the rounding of the barycentrics and of the cell index).  alpha_pass looks the cell of a candidate up
+    // before anything else (one dword).  Exact: same hits, same images.  FH_OPACITY_MICROMAP=0 (read at upload): all cells 0.
+    bool micromap = opacity_classes;
+    if (const char* e = getenv("FH_OPACITY_MICROMAP")) micromap = micromap && e[0] != '0';
+    unsigned long long cells_total = 0, cells_pass = 0, cells_never = 0;
+    std::vector<uint4> rec(8ull * nf, make_uint4(0u, 0u, 0u, 0u));
     auto bits = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u; };
     for (uint32_t f = 0; f < nf; ++f) {
       if (!alpha_bits[f]) continue;
       const fh_material& m = ctx->h_materials[ctx->h_material_ids[f]];
       const float* tc = ctx->h_texcoords.data();
       const size_t v0 = ctx->h_indices[3ull * f], v1 = ctx->h_indices[3ull * f + 1], v2 = ctx->h_indices[3ull * f + 2];
-      rec[4ull * f] = make_uint4(bits(tc[2 * v0]), bits(tc[2 * v0 + 1]), bits(tc[2 * v1]), bits(tc[2 * v1 + 1]));
+      rec[8ull * f] = make_uint4(bits(tc[2 * v0]), bits(tc[2 * v0 + 1]), bits(tc[2 * v1]), bits(tc[2 * v1 + 1]));
       uint32_t flags = alpha_bits[f];
       if ((flags & 2u) && ctx->h_tex_desc[(size_t)m.alpha_texture_id].srgb) flags |= 4u;
-      rec[4ull * f + 1] = make_uint4(bits(tc[2 * v2]), bits(tc[2 * v2 + 1]), flags, 0u);
+      rec[8ull * f + 1] = make_uint4(bits(tc[2 * v2]), bits(tc[2 * v2 + 1]), flags, 0u);
       if (flags & 1u) {
         const fht_texture& t = ctx->h_tex_desc[(size_t)m.base_color_texture_id];
         const unsigned long long p = (unsigned long long)(uintptr_t)t.rgba8;
-        rec[4ull * f + 2] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), t.width, t.height);
+        rec[8ull * f + 2] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), t.width, t.height);
       }
       if (flags & 2u) {
         const fht_texture& t = ctx->h_tex_desc[(size_t)m.alpha_texture_id];
         const unsigned long long p = (unsigned long long)(uintptr_t)t.rgba8;
-        rec[4ull * f + 3] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), t.width, t.height);
+        rec[8ull * f + 3] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), t.width, t.height);
+      }
+      const bool finite_uv = std::fabs(tc[2 * v0]) < 1e6f && std::fabs(tc[2 * v0 + 1]) < 1e6f && std::fabs(tc[2 * v1]) < 1e6f && std::fabs(tc[2 * v1 + 1]) < 1e6f && std::fabs(tc[2 * v2]) < 1e6f &&
+                             std::fabs(tc[2 * v2 + 1]) < 1e6f;
+      if (micromap && finite_uv && !ctx->h_tex_host.empty()) {
+        uint32_t words[16] = {};
+        const double u0 = tc[2 * v0], w0 = tc[2 * v0 + 1], du1 = (double)tc[2 * v1] - u0, dw1 = (double)tc[2 * v1 + 1] - w0, du2 = (double)tc[2 * v2] - u0, dw2 = (double)tc[2 * v2 + 1] - w0;
+        for (int cj = 0; cj < 16; ++cj)
+          for (int ci = 0; ci + cj <= 16 && ci < 16; ++ci) {  // (cells beyond the hypotenuse are never addressed: they stay 0)
+            // barycentric range of the cell, widened: the last cell of a row / column also takes weights of 1 (and a hair more), the first a hair below 0
+            const double a0 = ci / 16.0 - 1e-4, a1 = (ci == 15 ? 1.0 : (ci + 1) / 16.0) + 1e-4, b0 = cj / 16.0 - 1e-4, b1 = (cj == 15 ? 1.0 : (cj + 1) / 16.0) + 1e-4;
+            const double cb[4][2] = {{a0, b0}, {a1, b0}, {a0, b1}, {a1, b1}};
+            float uv[8];
+            for (int k = 0; k < 4; ++k) { uv[2 * k] = (float)(u0 + cb[k][0] * du1 + cb[k][1] * du2); uv[2 * k + 1] = (float)(w0 + cb[k][0] * dw1 + cb[k][1] * dw2); }
+            uint32_t cb_ = 1u, ca_ = 1u;
+            if (flags & 1u) { const fh_ctx::HostTexture& t = ctx->h_tex_host[(size_t)m.base_color_texture_id]; cb_ = footprint_class(t.rgba8.data(), t.width, t.height, 3u, nullptr, uv, 4); }
+            if (flags & 2u) { const fh_ctx::HostTexture& t = ctx->h_tex_host[(size_t)m.alpha_texture_id]; ca_ = footprint_class(t.rgba8.data(), t.width, t.height, 0u, t.srgb ? srgb_table : nullptr, uv, 4); }
+            const uint32_t st = (cb_ == 1u && ca_ == 1u) ? 1u : ((cb_ == 2u || ca_ == 2u) ? 2u : 0u);
+            const int cell = cj * 16 + ci;
+            words[cell >> 4] |= st << (2 * (cell & 15));
+            ++cells_total; cells_pass += st == 1u; cells_never += st == 2u;
+          }
+        for (int k = 0; k < 4; ++k) rec[8ull * f + 4 + k] = make_uint4(words[4 * k], words[4 * k + 1], words[4 * k + 2], words[4 * k + 3]);
       }
     }
+    ctx->alpha_cell_counts[0] = cells_total; ctx->alpha_cell_counts[1] = cells_pass; ctx->alpha_cell_counts[2] = cells_never;
+    if (getenv("FH_DEBUG_BVH") && cells_total)
+      fprintf(stderr, "[alpha] micromap: %llu cells of the faces that keep their test: %.1f %% always pass, %.1f %% never pass\n", cells_total, 100.0 * cells_pass / cells_total, 100.0 * cells_never / cells_total);
     FH_HIP(hipMalloc((void**)&ctx->d_alpha_rec, rec.size() * sizeof(uint4)));
     FH_HIP(hipMemcpy(ctx->d_alpha_rec, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice));
   }
@@ -623,6 +656,23 @@ int fh_alpha_face_counts(fh_ctx* ctx, uint32_t counts[4])
   CTX_CHECK(ctx);
   if (!counts) return fail(ctx, FH_E_INVALID, "fh_alpha_face_counts: null argument");
   for (int k = 0; k < 4; ++k) counts[k] = ctx->alpha_face_counts[k];
+  return FH_OK;
+}
+
+int fh_alpha_cell_counts(fh_ctx* ctx, uint64_t counts[3])
+{
+  CTX_CHECK(ctx);
+  if (!counts) return fail(ctx, FH_E_INVALID, "fh_alpha_cell_counts: null argument");
+  for (int k = 0; k < 3; ++k) counts[k] = ctx->alpha_cell_counts[k];
+  return FH_OK;
+}
+
+int fh_kat_alpha_records(fh_ctx* ctx, uint32_t* out, uint32_t n_faces)
+{
+  CTX_CHECK(ctx);
+  if (!out || n_faces != ctx->n_faces) return fail(ctx, FH_E_INVALID, "fh_kat_alpha_records: 32 words per face of the uploaded scene");
+  if (!ctx->d_alpha_rec) { std::memset(out, 0, 128ull * n_faces); return FH_OK; }
+  FH_HIP(hipMemcpy(out, ctx->d_alpha_rec, 128ull * n_faces, hipMemcpyDeviceToHost));
   return FH_OK;
 }
 

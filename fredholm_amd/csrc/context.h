@@ -52,8 +52,9 @@ struct fh_ctx {
   std::vector<fht_texture> h_tex_desc;  // the descriptors as uploaded (device pointers)
   struct HostTexture { uint32_t width = 0, height = 0, srgb = 0; std::vector<uint8_t> rgba8; };
   std::vector<HostTexture> h_tex_host;  // texels of the textures that can cut, kept on the host: per-face opacity classes (capi.hip: footprint_class)
+  unsigned long long alpha_cell_counts[3] = {0, 0, 0};  // micromap cells of the faces that keep their test; of them: always pass, never pass (fh_alpha_cell_counts)
   uint32_t alpha_face_counts[4] = {0, 0, 0, 0};  // faces whose textures can cut; of them: always pass, never pass, still tested (fh_alpha_face_counts)
-  uint4* d_alpha_rec = nullptr;         // 4 x 16 bytes per face when the scene has cut-outs: what the any-hit test of that face reads (fh_trace.h: alpha_pass)
+  uint4* d_alpha_rec = nullptr;         // 8 x 16 bytes per face when the scene has cut-outs: what the any-hit test of that face reads (4) and the face's opacity micromap (4) (fh_trace.h: alpha_pass)
   uint8_t* d_texels = nullptr;
   fht_texture* d_textures = nullptr;
   float* d_srgb_lut = nullptr;

@@ -59,7 +59,7 @@ struct SceneDev {
   const fht_texture* textures;  // software texture unit (include/fh_texture_unit.h)
   const float* srgb_lut;        // 256-entry sRGB -> linear table
   uint32_t n_textures;
-  const uint4* alpha_rec;       // per face, scenes with cut-outs only: (uv0, uv1), (uv2, flags), (alpha-carrying base texture), (alpha texture)
+  const uint4* alpha_rec;       // per face (8 vectors), scenes with cut-outs only: (uv0, uv1), (uv2, flags), (alpha-carrying base texture), (alpha texture), 4 x opacity micromap
   uint32_t has_alpha;           // some faces carry an alpha cut-out (pt.cu:545-678): traversal runs the any-hit test for them
   Bvh2Dev bvh2;
   Bvh8Dev bvh8;

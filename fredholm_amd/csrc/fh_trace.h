@@ -112,6 +112,9 @@ FH_D float4 tex_rgba(const SceneDev& sc, int id, float u, float v)
   fht_tex2d(&sc.textures[id], sc.srgb_lut, u, v, o);
   return make_float4(o[0], o[1], o[2], o[3]);
 }
+#ifndef FH_OPACITY_MICROMAP
+#define FH_OPACITY_MICROMAP 1
+#endif
 __device__ __attribute__((noinline)) bool alpha_pass(const SceneDev& sc, uint32_t prim, float bu, float bv)
 {
   // one 64-byte record per face (capi.hip: rebuild_device_scene): texture coordinates of the three vertices + the textures that can actually cut
@@ -119,7 +122,16 @@ __device__ __attribute__((noinline)) bool alpha_pass(const SceneDev& sc, uint32_
 #if defined(FH_ALPHA_STUB) && FH_ALPHA_STUB == 1
   return true;  // (measurement only: the kernels with the any-hit test compiled in, every candidate accepted without a look at its texture)
 #endif
-  const uint4* r = sc.alpha_rec + 4 * (size_t)prim;
+  const uint4* r = sc.alpha_rec + 8 * (size_t)prim;
+#if FH_OPACITY_MICROMAP
+  {  // the face's opacity micromap (capi.hip: rebuild_device_scene): 16 x 16 cells of the hit's barycentrics, two bits each -- decided at upload for every point of the cell
+    const uint32_t ci = (uint32_t)fminf(fmaxf(bu, 0.0f) * 16.0f, 15.0f), cj = (uint32_t)fminf(fmaxf(bv, 0.0f) * 16.0f, 15.0f);
+    const uint32_t cell = cj * 16u + ci;
+    const uint32_t st = (((const uint32_t*)(r + 4))[cell >> 4] >> (2u * (cell & 15u))) & 3u;
+    if (st == 1u) return true;
+    if (st == 2u) return false;
+  }
+#endif
   const uint4 q0 = r[0], q1 = r[1], q2 = r[2];  // (the alpha texture's entry, r[3], is read where a face has one: most cut-outs sit in the base colour's alpha)
   const float bw = 1.0f - bu - bv;
   const float tu = bw * __uint_as_float(q0.x) + bu * __uint_as_float(q0.z) + bv * __uint_as_float(q1.x);

@@ -201,6 +201,12 @@ class Renderer:
         self._ck(N.lib().fh_alpha_face_counts(self._ctx, a), "fh_alpha_face_counts")
         return tuple(int(x) for x in a)
 
+    def alpha_cell_counts(self):
+        """(micromap cells of the faces that keep their any-hit test, always pass, never pass)"""
+        a = (C.c_uint64 * 3)()
+        self._ck(N.lib().fh_alpha_cell_counts(self._ctx, a), "fh_alpha_cell_counts")
+        return tuple(int(x) for x in a)
+
     def path_pool_allocated(self):
         """(device bytes, path slots) the path pools hold right now, all pools together"""
         b, n = C.c_uint64(0), C.c_uint64(0)

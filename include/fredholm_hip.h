@@ -155,6 +155,9 @@ int fh_path_pool_bytes(fh_ctx* ctx, uint64_t* bytes_per_path, uint32_t* pools);
 /* cut-out faces of the uploaded scene: [0] faces whose textures can discard a hit (pt.cu:545-678), [1] of them: the any-hit test passes wherever the face can be hit (no test
  * at run time), [2] it never passes (no ray can hit the face), [3] faces that keep their test.  Decided per face at fh_scene_upload from the texels the face can address. */
 int fh_alpha_face_counts(fh_ctx* ctx, uint32_t counts[4]);
+/* the opacity micromaps of the faces that keep their test (16 x 16 cells of a face's barycentrics, decided at upload like the faces themselves): [0] cells, [1] of them: the
+ * test passes everywhere in the cell, [2] nowhere; candidates in such cells are decided by a two-bit look-up */
+int fh_alpha_cell_counts(fh_ctx* ctx, uint64_t counts[3]);
 /* what the path pools hold right now: device bytes of all pools together and path slots (summed over the pools) */
 int fh_path_pool_allocated(fh_ctx* ctx, uint64_t* bytes, uint64_t* paths);
 /* number of bounces run as bounce-synchronous wavefront kernels before the surviving paths are finished by one

@@ -46,6 +46,9 @@ int fh_kat_tex2d(fh_ctx* ctx, const uint8_t* rgba8, const float* rgba32f, uint32
    0x40 the any-hit test runs for candidate hits on this face, 0x80 emissive.  A face of a material whose textures can cut with neither 0x20 nor 0x40 was
    classified "always passes" from the texels it can address (capi.hip: footprint_class); the parity tests check both classes by brute force. */
 int fh_kat_face_classes(fh_ctx* ctx, uint8_t* out, uint32_t n);
+/* the any-hit record of every face (n_faces x 32 words: texture coordinates, flags, texture pointers, then 16 words of opacity micromap: two bits per cell, cell = 16 * floor(16 v) + floor(16 u));
+   all zero for scenes without cut-outs */
+int fh_kat_alpha_records(fh_ctx* ctx, uint32_t* out, uint32_t n_faces);
 
 #ifdef __cplusplus
 }

@@ -1038,6 +1038,57 @@ def _brute_force_face_classes(sc, flags, n_grid=96):
     return n_always, n_never
 
 
+def _brute_force_micromap(sc, flags, recs, pts=7):
+    """every decided cell of the opacity micromap of every face that keeps its any-hit test (fh_kat_alpha_records: words 16 .. 31 of a face's record, two bits per cell,
+    cell = 16 * floor(16 v) + floor(16 u)): the test of pt.cu:545-678 evaluated with the numpy texture unit on a pts x pts grid of the cell (edges included, clipped to
+    the triangle); returns (cells decided 'passes', cells decided 'never passes')"""
+    mats, tex = sc["materials"], sc.get("textures", [])
+    idx, tc, mid = np.asarray(sc["indices"]), np.asarray(sc["texcoords"], np.float32), np.asarray(sc["material_ids"])
+    lut = np.array([c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4 for c in (np.arange(256) / 255.0)], np.float32)
+    g = np.linspace(0.0, 1.0, pts)
+    n_pass = n_never = 0
+    for f in np.nonzero(flags & 0x40)[0]:
+        words = recs[f, 16:32]
+        m = mats[mid[f]]
+        bt, at = int(m["base_color_texture_id"]), int(m["alpha_texture_id"])
+        rec_flags = int(recs[f, 6])
+        uv0, uv1, uv2 = tc[idx[f, 0]], tc[idx[f, 1]], tc[idx[f, 2]]
+        for cell in range(256):
+            st = (int(words[cell >> 4]) >> (2 * (cell & 15))) & 3
+            if st == 0:
+                continue
+            ci, cj = cell & 15, cell >> 4
+            bu, bv = np.meshgrid((ci + g) / 16.0, (cj + g) / 16.0)
+            keep = bu + bv <= 1.0 + 1e-9
+            if not keep.any():
+                continue  # (a cell on the hypotenuse of which only rounding could address a point)
+            bu, bv = bu[keep].astype(np.float32), bv[keep].astype(np.float32)
+            # the cell the device derives from these weights is this cell (or, on a shared edge, its neighbour: those points are checked with the neighbour)
+            mine = (np.minimum(np.maximum(bu, 0) * np.float32(16), 15).astype(np.uint32) == ci) & (np.minimum(np.maximum(bv, 0) * np.float32(16), 15).astype(np.uint32) == cj)
+            bu, bv = bu[mine], bv[mine]
+            bw = (np.float32(1.0) - bu - bv).astype(np.float32)
+            tu = (bw * uv0[0] + bu * uv1[0] + bv * uv2[0]).astype(np.float32)
+            tv = (bw * uv0[1] + bu * uv1[1] + bv * uv2[1]).astype(np.float32)
+            ok = np.ones(tu.shape, bool)
+            if rec_flags & 1:
+                ok &= _np_filtered_channel(np.asarray(tex[bt]["rgba8"]), 3, None, tu, tv) >= np.float32(0.5)
+            if rec_flags & 2:
+                ok &= _np_filtered_channel(np.asarray(tex[at]["rgba8"]), 0, lut if (rec_flags & 4) else None, tu, tv) >= np.float32(0.5)
+            if st == 1:
+                assert ok.all(), f"face {f} cell {cell}: decided 'passes', {(~ok).sum()} of {ok.size} points fail"
+                n_pass += 1
+            else:
+                assert not ok.any(), f"face {f} cell {cell}: decided 'never passes', {ok.sum()} of {ok.size} points pass"
+                n_never += 1
+    return n_pass, n_never
+
+
+def _alpha_records(r, n_faces):
+    out = np.zeros((n_faces, 32), np.uint32)
+    N.check(r._ctx, N.lib().fh_kat_alpha_records(r._ctx, out.ctypes.data_as(C.c_void_p), C.c_uint32(n_faces)), "fh_kat_alpha_records")
+    return out
+
+
 def _fence_scene():
     """the textured Cornell box plus a fence of small cut-out quads: each quad's texture coordinates sit inside ONE 8 x 8-texel cell of an alpha checker (two texels in from
     the cell's edge), half of the cells opaque and half transparent, in the base colour's alpha for one half of the fence and in an alpha texture for the other; and a row of
@@ -1118,6 +1169,11 @@ def test_opacity_classes_of_cut_out_faces_are_exact(oracle, monkeypatch):
     assert int((flags & 0x20 != 0).sum()) == never and int((flags & 0x40 != 0).sum()) == tested
     got = _brute_force_face_classes(sc, flags)
     assert got == (always, never), (got, always, never)
+    # the faces that keep their test carry a micromap: the large quads span several cells of the checker, so some of their 16 x 16 cells lie inside one texture cell
+    cells, c_pass, c_never = r.alpha_cell_counts()
+    assert cells > 0 and c_pass > 0 and c_never > 0 and c_pass + c_never < cells
+    got_cells = _brute_force_micromap(sc, flags, _alpha_records(r, nf))
+    assert got_cells[0] > 0 and got_cells[1] > 0 and got_cells[0] <= c_pass and got_cells[1] <= c_never
     S = oracle.Scene(sc)
     rays = _rays(np.random.default_rng(12), 40000, -0.9, 0.9)
     rays[:, 1] += 1.0
@@ -1138,7 +1194,7 @@ def test_opacity_classes_of_cut_out_faces_are_exact(oracle, monkeypatch):
         monkeypatch.setenv("FH_OPACITY_CLASSES", "0")
         r0 = F.Renderer(0)
         r0.load_scene(sc)
-        assert r0.alpha_face_counts()[1:3] == (0, 0)
+        assert r0.alpha_face_counts()[1:3] == (0, 0) and r0.alpha_cell_counts()[1:] == (0, 0)
         r0.close()
         off, _ = _render_pair(oracle, sc, cam, 96, 72, launches=2, spp_per_launch=2, depth=4)
         for name in F.RenderLayer.NAMES:
