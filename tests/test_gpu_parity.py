@@ -1158,6 +1158,8 @@ def test_opacity_classes_of_cut_out_faces_are_exact(oracle, monkeypatch):
     passes (then no ray hits the face) or has to run.  (1) every classified face is checked by brute force: the test evaluated on a dense barycentric grid with a numpy
     restatement of the texture unit; (2) hits, occlusion and images are those of the checker, which tests every candidate; (3) with the classes switched off
     (FH_OPACITY_CLASSES=0) the library returns the same bits."""
+    monkeypatch.delenv("FH_OPACITY_CLASSES", raising=False)   # (tools/r5_call30.sh runs this file with the classes switched off as well: here they are the subject)
+    monkeypatch.delenv("FH_OPACITY_MICROMAP", raising=False)
     sc = _fence_scene()
     nf = sc["indices"].shape[0]
     r = F.Renderer(0)
