@@ -641,10 +641,16 @@ def main():
     r.render(cam, w["bg"], layers, spp, MAX_DEPTH)
     r.wait_for_completion()
     cnt = r.stats()
+    # ... and once more with every ray started at the root (FH_FLAG_ROOT_START): what the same hits cost in tests when no ray starts at the node of its face
+    r.set_flags(N.FLAG_COUNT_TRAVERSAL | N.FLAG_ROOT_START)
+    r.reset_stats()
+    r.render(cam, w["bg"], layers, spp, MAX_DEPTH)
+    r.wait_for_completion()
+    cnt_root = r.stats()
     r.set_flags(0)
 
     if args.check_frame and world > 1 and rank == 0:
-        total_spp = spp * (warmup + steps + 2)  # + the serial step + the counting replay, which only the local layers saw
+        total_spp = spp * (warmup + steps + 3)  # + the serial step + the two counting replays, which only the local layers saw
         r2 = F.Renderer(local_rank)
         r2.load_scene(sc)
         r2.build_ias()
@@ -657,14 +663,14 @@ def main():
         others["beauty"] = full
         layers2 = F.RenderLayer(r2, WIDTH, HEIGHT, pointers={n: t.data_ptr() for n, t in others.items()})
         # 1. the frame assembled from every rank's tiles after the last timed step against an unsharded render of as many samples
-        r2.render(cam, w["bg"], layers2, total_spp - 2 * spp, MAX_DEPTH)
+        r2.render(cam, w["bg"], layers2, total_spp - 3 * spp, MAX_DEPTH)
         r2.wait_for_completion()
         whole = bool((full.view(torch.int32) == frame.view(torch.int32)).all().item())
         print(f"check-frame: frame gathered from {world} ranks bit-identical to the unsharded render: {whole}", file=sys.stderr, flush=True)
         if not whole:
             raise SystemExit("gathered frame differs from the unsharded one")
-        # 2. this rank's tiles after the serial step and the counting replay (two more steps that only the local layers saw)
-        r2.render(cam, w["bg"], layers2, 2 * spp, MAX_DEPTH)
+        # 2. this rank's tiles after the serial step and the counting replays (three more steps that only the local layers saw)
+        r2.render(cam, w["bg"], layers2, 3 * spp, MAX_DEPTH)
         r2.wait_for_completion()
         own0 = torch.from_numpy(D.tile_ownership(WIDTH, HEIGHT, 0, world).astype(np.int64)).to(dev)
         r.pack_owned(bufs["beauty"].data_ptr(), 4, packed.data_ptr())
@@ -732,6 +738,19 @@ def main():
                             "(BSDF, software transcendentals), so the algorithmic figure is a lower bound of what moves"}
         if dom.startswith("k_trace"):
             roof["kernel_info"] = r.kernel_info(0 if f.get("key") == "closest" else 1)  # registers / LDS / scratch / workgroups per CU of the variant that ran
+            # `frac` counts the tests that were DONE.  Where the library starts first-hit rays at the node of the face they leave, the same hits need fewer
+            # tests than a walk from the root: the replay with FH_FLAG_ROOT_START counts those, and the same launch time priced with them is what `frac` would be if the
+            # avoided tests still counted as work
+            im_, key_ = issue_model(), f["key"]
+            ck_ = "closest" if key_ == "closest" else "shadow"
+            wn0, wt0 = cnt_root[f"wave_node_steps_{key_}"], cnt_root[f"wave_tri_steps_{key_}"]
+            cyc0 = (wn0 * im_["node"] + wt0 * im_["tri"]) * steps / launches
+            roof["from_root"] = {"nodes_per_ray": round(cnt_root[f"nodes_{ck_}"] / max(cnt_root[f"rays_{ck_}"], 1), 2), "triangles_per_ray": round(cnt_root[f"tris_{ck_}"] / max(cnt_root[f"rays_{ck_}"], 1), 2),
+                                 "wave_node_tests_per_launch": int(wn0 * steps / launches), "wave_tri_tests_per_launch": int(wt0 * steps / launches),
+                                 "share_of_those_tests_done": round((cnt[f"wave_node_steps_{key_}"] * im_["node"] + cnt[f"wave_tri_steps_{key_}"] * im_["tri"]) / max(wn0 * im_["node"] + wt0 * im_["tri"], 1.0), 4),
+                                 "frac_priced_with_these_tests": round(min(cyc0 / (avg_ms * 1e-3) / 1e9 / (N_SIMDS * NOMINAL_CLOCK_GHZ), 1.0), 5) if avg_ms > 0 else None,
+                                 "note": "the counting replay with every ray started at the root (FH_FLAG_ROOT_START): the tests a walk from the root needs for the same hits; frac counts the tests done, "
+                                         "so it falls when tests are avoided -- frac_priced_with_these_tests is this run's launch time priced with the root-start test counts"}
         if pmc_k and avg_alone_ms > 0:  # the counters are collected with the kernels serialised, so they are priced against the kernel's time alone
             if traffic:
                 # what the fabric-side counters saw of this kernel against the HBM peak (2 x FETCH_SIZE + WRITE_SIZE of the counter run over this run's launch time alone)

@@ -2233,7 +2233,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     // the device's own count of test rounds per shaded path decides (above): a dense scene gains (1M-triangle soup: -12 %), an interior of long rays does not (-0.4 %)
     int pass_bu = -1;  // -1: not a probing pass
     bool use_bu = false;
-    if (sc_all.bvh8.parent && stream) {
+    if (sc_all.bvh8.parent && stream && (ctx->flags & FH_FLAG_ROOT_START) == 0u) {
       if (tun.bottom_up == 1u) use_bu = true;
       else if (tun.bottom_up == 2u) {
         if (ctx->bu_choice == 0 && !count) { use_bu = (ctx->bu_toggle++ & 1u) != 0u; pass_bu = use_bu ? 1 : 0; }

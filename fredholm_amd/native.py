@@ -11,6 +11,7 @@ FH_OK = 0
 FLAG_TIME_KERNELS = 1
 FLAG_COUNT_TRAVERSAL = 2
 FLAG_SERIAL_PASSES = 8
+FLAG_ROOT_START = 16  # (measurements) every ray starts its traversal at the root
 FLAG_REFERENCE_FIRSTHIT = 4  # one fh_render(n_samples = k) = ONE reference launch of k samples, firsthit quirk included (pt.cu:432-433)
 
 MATERIAL_DTYPE = np.dtype([

@@ -136,6 +136,9 @@ typedef struct fh_stats {
 /* run the passes of fh_render one after the other on the main stream instead of two in flight: slower, but every kernel then runs alone
  * on the GPU, so the HIP-event times of FH_FLAG_TIME_KERNELS are kernel times (with passes in flight they include the other stream's work) */
 #define FH_FLAG_SERIAL_PASSES 8u
+/* measurements: every ray starts its traversal at the root, whatever the library decided for the scene (render.hip: where a pass's first-hit rays start); results do not
+ * depend on it -- bench.py counts with it what a walk from the root would have tested */
+#define FH_FLAG_ROOT_START 16u
 
 /* -- context: replaces optwl::Context + Renderer ctor/dtor (optwl.h:41-81, renderer.h:32-122) */
 int fh_ctx_create(int device, fh_ctx** out);

@@ -34,7 +34,7 @@ try:
             "peak_accesses_per_cycle_per_cu": 1.0, "source": f"profiles/{tag}_l1_summary.txt; peak: profiles/r03_issue_peak.txt (64 lanes in 64 L1-resident lines: 64 cycles per load instruction and CU)"}
 except Exception as e:
     print("no vector-memory passes:", e)
-renders = 4  # --warmup 1 --steps 1 + the serial step + the counting replay
+renders = 5  # --warmup 1 --steps 1 + the serial step + the two counting replays (the second with every ray started at the root)
 pmc_line = [ln for ln in open(f"gpurun_out/{tag}_sqa.log") if ln.startswith("{")][-1]
 pmc_cfg = json.loads(pmc_line)["config"]
 pmc_pass_spp = pmc_cfg["spp_per_pass"]  # the nominal launch size the counters belong to: bench.py quotes them only for runs with the same samples per pass
