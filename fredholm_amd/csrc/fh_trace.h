@@ -482,7 +482,12 @@ struct GroupStack<true> {
   FH_D GroupStack(uint2* block_lds, int depth) : word((uint32_t*)block_lds + threadIdx.x), mask((uint8_t*)((uint32_t*)block_lds + depth * 256) + threadIdx.x) {}
   FH_D GroupStack(uint2* block_lds, int depth, uint2* spill, uint32_t threads, uint32_t)
       : word((uint32_t*)block_lds + threadIdx.x), mask((uint8_t*)((uint32_t*)block_lds + depth * 256) + threadIdx.x), cap(spill ? depth : kBvh8Stack), over(spill), ostride(threads) {}
-  FH_D uint2* over_at(int level) const { return over + ((size_t)(uint32_t)(level - cap) * ostride + (blockIdx.x * blockDim.x + threadIdx.x)); }
+  FH_D uint2* over_at(int level) const
+  {
+    uint32_t column = blockIdx.x * blockDim.x + threadIdx.x;
+    asm volatile("" : "+v"(column));  // (formed HERE: hoisted out of the traversal loop, the thread's column pointer was a 64-bit value the any-hit kernels kept in 8 bytes of scratch)
+    return over + ((size_t)(uint32_t)(level - cap) * ostride + column);
+  }
   FH_D void push(uint2 g)
   {
     if (sp < cap) { word[sp * 256] = (g.x << 8) | (g.y >> 24); mask[sp * 256] = (uint8_t)g.y; }
