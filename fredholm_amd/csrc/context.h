@@ -159,7 +159,7 @@ struct fh_ctx {
   struct Tunables {
     uint32_t n_cus = 256;
     uint32_t lds_per_cu = 160u * 1024u, lds_per_block = 160u * 1024u;  // LDS of a CU / the most one workgroup may take, from the device attributes (gfx950: 160 KB both)
-    uint32_t coop_flush = 32;       // FH_COOP_T: queued candidate triangles that trigger a cooperative test round
+    uint32_t coop_flush = 48;       // FH_COOP_T: queued candidate triangles that trigger a cooperative test round (r5-12: 32 -> 48, configs[3] +1.6 %, configs[2] +0.5 %)
     bool coop = true;               // FH_COOP=0: per-lane triangle loop
     bool stream = true;             // FH_STREAM=0: one fixed batch per wave; FH_STREAM=1: streaming whatever the size of the tree
     bool stream_forced = false;
@@ -174,7 +174,7 @@ struct fh_ctx {
     bool poison_pools = false;      // FH_POISON=1: new path pools are filled with 0xa5 before their first use (tests: nothing may read what nobody wrote)
     bool merge_trace = true;        // FH_MERGE=0: single-pass calls trace secondary rays and the next bounce's closest-hit rays in two launches (two streams) instead of one
     uint32_t shade_stream = 0;      // FH_SHADE_STREAM=1|2 (experiment, profiles/README.md r4): the shade-side launches of a pass on their own stream, 2: of high priority
-    uint32_t shade_wgs = 0;         // FH_SHADE_WGS=2|3: workgroups per CU the shade kernels are compiled for (0: three for textured scenes that stream)
+    uint32_t shade_wgs = 0;         // FH_SHADE_WGS=2|3: workgroups per CU the shade kernels are compiled for (0: three; until r5-12 for textured scenes that stream only)
     uint32_t stack_lds_entries = 0; // FH_STACK_LDS=n: stack levels the streaming kernels keep in LDS (0: as many as cost no workgroup; 99: all)
     bool sort_small = false;        // FH_SORT_SMALL=1: cell-order the bounce queues of trees the fixed-batch kernels trace as well
     uint32_t stream_chunk = 64;     // FH_STREAM_CHUNK: queue entries a wave takes per global atomic (setting it also switches the adaptive maximum off)

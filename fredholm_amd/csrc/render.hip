@@ -64,9 +64,10 @@ constexpr uint32_t kMatLds = 32;  // material records staged in LDS by the shade
 #ifndef FH_SHADE_BLOCKS
 #define FH_SHADE_BLOCKS 2  // resident workgroups per CU the specialised shade kernels are compiled for (register budget = 512 / that per lane): they take 159-182 registers
 #endif                     // since their products go to memory as they are made (PoolSink); the generic seven-lobe kernel keeps one wave per SIMD (350 registers).
-// A second set is compiled for THREE workgroups per CU (168 registers, 6-7 of them spilled: 28-32 B of scratch).  It is what textured scenes get (render_submit): their hits wait for
-// texels, and a third wave per SIMD covers that -- configs[3]: shade 3.87 -> 3.53 s alone, frame 525 -> 542 Msamples/s; the untextured configurations lose with it next to the
-// other passes' kernels (configs[1] 2210 -> 2025: three shade workgroups hold 80 KB of a CU's LDS), so they keep two.  FH_SHADE_WGS=2|3 forces either.
+// A second set is compiled for THREE workgroups per CU (168 registers, 6-7 of them spilled: 28-44 B of scratch), and it is the set every scene gets (render_submit;
+// FH_SHADE_WGS=2|3 forces either).  Round 3 gave it to textured scenes only -- their hits wait for texels and a third wave per SIMD covers that (configs[3]: shade 3.87 -> 3.53 s
+// alone; with two, today, 676 -> 644 Msamples/s) -- because the untextured ones lost with it then (configs[1] 2210 -> 2025).  On round 5's build they gain as well
+// (profiles/r05_tunables.log: configs[1] 2751 -> 2823, configs[2] 7841 -> 7972, configs[4] with the flush threshold below 5559 -> 5772).
 
 // generator matrices of the N Sobol' dimensions a kernel draws from, staged in LDS in their byte-indexed form (4 KB per dimension, FrameDev::sobol_bytes):
 // the XOR over the 32 index bits is four LDS reads instead of 32 bit tests (~85 instructions less per draw; the shade kernels draw three or four per hit)
@@ -2159,7 +2160,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   // cell-ordered queues pay where rays of one cell share the nodes they fetch; a tree the fixed-batch kernels trace (under 4096 nodes) sits in the caches whatever
   // the order, and there the six sort launches per bounce are what a small frame waits for (Cornell box, 1 spp: 0.33 of 2.15 ms)
   const bool sort_queues = tun.sort_queues && (stream || tun.sort_small);
-  const bool shade_three = tun.shade_wgs ? tun.shade_wgs == 3u : (stream && sc.n_textures > 0);  // (above, FH_SHADE_BLOCKS)
+  const bool shade_three = tun.shade_wgs ? tun.shade_wgs == 3u : true;  // (above, FH_SHADE_BLOCKS)
 
   // ---- Small calls (the reference's callers: 1 sample per call in the GUI, controller.cpp:224, 16 in rtcamp8, rtcamp8.cpp:183-189).  A call that fits ONE pass is a chain of
   // ~50 launches, each of which ends in its few longest rays with the chip nearly idle, and the chain is as long as those ends added up.  Such a call is cut into PIXEL
