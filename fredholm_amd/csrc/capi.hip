@@ -512,6 +512,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     auto env_uint = [](const char* name, int lo, int hi, uint32_t& dst) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) dst = (uint32_t)v; } };
     auto env_off = [](const char* name, bool& dst) { if (const char* e = getenv(name)) dst = e[0] != '0'; };
     env_uint("FH_COOP_T", 1, 64, t.coop_flush);
+    t.coop_flush_fixed = getenv("FH_COOP_T") != nullptr;
     env_off("FH_COOP", t.coop);
     env_off("FH_STREAM", t.stream);
     t.stream_forced = t.stream && getenv("FH_STREAM") != nullptr;

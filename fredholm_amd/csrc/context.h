@@ -160,6 +160,7 @@ struct fh_ctx {
     uint32_t n_cus = 256;
     uint32_t lds_per_cu = 160u * 1024u, lds_per_block = 160u * 1024u;  // LDS of a CU / the most one workgroup may take, from the device attributes (gfx950: 160 KB both)
     uint32_t coop_flush = 48;       // FH_COOP_T: queued candidate triangles that trigger a cooperative test round (r5-12: 32 -> 48, configs[3] +1.6 %, configs[2] +0.5 %)
+    bool coop_flush_fixed = false;  // FH_COOP_T was given: no per-call choice (render_submit)
     bool coop = true;               // FH_COOP=0: per-lane triangle loop
     bool stream = true;             // FH_STREAM=0: one fixed batch per wave; FH_STREAM=1: streaming whatever the size of the tree
     bool stream_forced = false;

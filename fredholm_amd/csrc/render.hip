@@ -2058,7 +2058,10 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
 
   // device facts and developer switches were read once at fh_ctx_create (context.h: Tunables)
   const fh_ctx::Tunables& tun = ctx->tun;
-  const uint32_t coop_flush = tun.coop_flush;  // wave-cooperative triangle tests (default for the wide BVH): queued candidates that trigger a round
+  // wave-cooperative triangle tests (default for the wide BVH): queued candidates that trigger a round.  48 (r5-12) -- but ONE-PASS calls of scenes without cut-outs keep 32
+  // (r5-13, profiles/r05_latency_defaults.log: the soup's fh_render(1 / 4 / 16) take 2.02 / 3.37 / 7.02 ms with 32 and 2.21 / 3.62 / 7.32 with 48 -- a launch of few rays
+  // waits longer for 48 candidates; the interior with cut-outs is 1 % faster with 48 there too).  FH_COOP_T fixes it for every call.
+  const uint32_t coop_flush = (!tun.coop_flush_fixed && batch >= n_samples && !sc.has_alpha && tun.coop_flush > 32u) ? 32u : tun.coop_flush;
   const bool coop = sc.use_bvh8 != 0 && sc.bvh8.n_tris < kCoopMaxTris && tun.coop;
   // streaming form (FH_STREAM=0: one fixed batch per wave).  Through a small tree every ray takes the same few steps: nothing to rebalance, and the fixed
   // batches run without the refill machinery (1000-triangle soup: closest 7.4 -> 4.6 ms, secondary 2.6 -> 1.0 ms per 256 spp; even at ~2 K nodes; behind at 20 K)

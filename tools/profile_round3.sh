@@ -18,8 +18,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_ser
 find $R/gpurun_out/${tag}_serial_stats -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${tag}_serial_kernel_stats.csv \;
 find $R/gpurun_out/${tag}_stats $R/gpurun_out/${tag}_serial_stats -name "*kernel_trace.csv" -delete
 fi
-run() { name=$1; shift
-  timeout -k 5 300 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_$name -- $B --steps 1 --warmup 1 --spp $pspp --no-cpu-baseline --no-extras > $R/gpurun_out/${tag}_$name.log 2>&1; echo "pmc $name rc=$?"
+run() { name=$1; shift   # (FH_COOP_T: the counter passes render ONE pass as one call, and a one-pass call of a scene without cut-outs would pick the small calls' flush threshold, render.hip r5-13; they measure the multi-pass run's launches)
+  FH_COOP_T=${FH_COOP_T:-48} timeout -k 5 300 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_$name -- $B --steps 1 --warmup 1 --spp $pspp --no-cpu-baseline --no-extras > $R/gpurun_out/${tag}_$name.log 2>&1; echo "pmc $name rc=$?"
 }
 if [ "$only" = all ]; then
 run sqa SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD
