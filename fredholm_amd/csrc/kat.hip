@@ -100,13 +100,14 @@ FH_D MatParams params_of(const MaterialDev& m)
 }
 
 template <uint32_t LOBES>
-__global__ void k_bsdf(MaterialDev mat, int entering, BsdfTables lut, uint32_t n, const float* wo, const float* wi, const float* u1, const float* u2, float* out)
+__global__ void k_bsdf(MaterialDev mat, int entering, float eta_given, BsdfTables lut, uint32_t n, const float* wo, const float* wi, const float* u1, const float* u2, float* out)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const f3 o = mk3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), in = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
   Bsdf<LOBES> b;
   b.init(o, params_of(mat), entering != 0, lut);
+  if (eta_given > 0.0f) { b.ni = 1.0f; b.nt = eta_given; b.eta = eta_given; }  // fh_kat_bsdf_ior: the lobes at a relative index other than the constructor's
   const f3 e = b.eval(o, in);
   f3 f;
   float pdf;
@@ -366,7 +367,7 @@ int fh_kat_warp(fh_ctx* ctx, int kind, uint32_t n, const float* u2, const float*
   FH_HIP(o.down(out));
   return FH_OK;
 }
-int fh_kat_bsdf(fh_ctx* ctx, const fh_material* material, int entering, uint32_t lobes_mask, uint32_t n, const float* wo3, const float* wi3, const float* u1, const float* u2, float* out18)
+static int kat_bsdf(fh_ctx* ctx, const fh_material* material, int entering, float eta_given, uint32_t lobes_mask, uint32_t n, const float* wo3, const float* wi3, const float* u1, const float* u2, float* out18)
 {
   KCTX(ctx);
   if (!material) return FH_E_INVALID;
@@ -377,15 +378,24 @@ int fh_kat_bsdf(fh_ctx* ctx, const fh_material* material, int entering, uint32_t
   FH_HIP(a.up(wo3, 3ull * n)); FH_HIP(b.up(wi3, 3ull * n)); FH_HIP(c.up(u1, n)); FH_HIP(d.up(u2, 2ull * n)); FH_HIP(o.up(nullptr, 18ull * n));
   const dim3 g(blocks(n)), t(256);
   switch (lobes_mask) {
-    case L_DIFF: hipLaunchKernelGGL(k_bsdf<L_DIFF>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
-    case L_METAL: hipLaunchKernelGGL(k_bsdf<L_METAL>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
-    case L_SPEC | L_DIFF: hipLaunchKernelGGL(k_bsdf<L_SPEC | L_DIFF>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
-    case L_METAL | L_SPEC | L_DIFF: hipLaunchKernelGGL(k_bsdf<L_METAL | L_SPEC | L_DIFF>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
-    default: hipLaunchKernelGGL(k_bsdf<L_ALL>, g, t, 0, ctx->stream, m, entering, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+    case L_DIFF: hipLaunchKernelGGL(k_bsdf<L_DIFF>, g, t, 0, ctx->stream, m, entering, eta_given, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+    case L_METAL: hipLaunchKernelGGL(k_bsdf<L_METAL>, g, t, 0, ctx->stream, m, entering, eta_given, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+    case L_SPEC | L_DIFF: hipLaunchKernelGGL(k_bsdf<L_SPEC | L_DIFF>, g, t, 0, ctx->stream, m, entering, eta_given, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+    case L_METAL | L_SPEC | L_DIFF: hipLaunchKernelGGL(k_bsdf<L_METAL | L_SPEC | L_DIFF>, g, t, 0, ctx->stream, m, entering, eta_given, lut, n, a.p, b.p, c.p, d.p, o.p); break;
+    default: hipLaunchKernelGGL(k_bsdf<L_ALL>, g, t, 0, ctx->stream, m, entering, eta_given, lut, n, a.p, b.p, c.p, d.p, o.p); break;
   }
   FH_HIP(hipStreamSynchronize(ctx->stream));
   FH_HIP(o.down(out18));
   return FH_OK;
+}
+int fh_kat_bsdf(fh_ctx* ctx, const fh_material* material, int entering, uint32_t lobes_mask, uint32_t n, const float* wo3, const float* wi3, const float* u1, const float* u2, float* out18)
+{
+  return kat_bsdf(ctx, material, entering, 0.0f, lobes_mask, n, wo3, wi3, u1, u2, out18);
+}
+int fh_kat_bsdf_ior(fh_ctx* ctx, const fh_material* material, float eta, uint32_t lobes_mask, uint32_t n, const float* wo3, const float* wi3, const float* u1, const float* u2, float* out18)
+{
+  if (!(eta > 0.0f)) return FH_E_INVALID;
+  return kat_bsdf(ctx, material, 1, eta, lobes_mask, n, wo3, wi3, u1, u2, out18);
 }
 int fh_kat_sky(fh_ctx* ctx, uint32_t n, const float* dirs3, float* out3)
 {

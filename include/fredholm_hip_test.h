@@ -22,6 +22,9 @@ int fh_kat_elementary(fh_ctx* ctx, int fn, uint32_t n, const float* x, const flo
 int fh_kat_warp(fh_ctx* ctx, int kind, uint32_t n, const float* u2, const float* wo3, const float* alpha2, float* out);
 /* BSDF: 18 floats per item {eval.rgb, pdf, sample.wi, sample.f, sample.pdf, lobe weights-as-pmf[7]} */
 int fh_kat_bsdf(fh_ctx* ctx, const fh_material* material, int entering, uint32_t lobes_mask, uint32_t n, const float* wo3, const float* wi3, const float* u1, const float* u2, float* out18);
+/* the same with the interface's relative index of refraction GIVEN (eta > 0) instead of the constructor's 1.5 (bsdf.cu:16-18), entering = true: the lobe classes take it as
+   an argument (bxdf.cu:433-442, :620-627) and the reference's REFLECTION_IOR1_LUT (lut.cu:94-916) tabulates the dielectric reflection lobe over eta in (0, 1) */
+int fh_kat_bsdf_ior(fh_ctx* ctx, const fh_material* material, float eta, uint32_t lobes_mask, uint32_t n, const float* wo3, const float* wi3, const float* u1, const float* u2, float* out18);
 int fh_kat_sky(fh_ctx* ctx, uint32_t n, const float* dirs3, float* out3);          /* uses the context's Hosek state */
 int fh_kat_hosek_state(fh_ctx* ctx, float* out30);                                  /* cooked cfg[3][9] + rad[3] */
 int fh_kat_camera(fh_ctx* ctx, const fh_camera* cam, uint32_t width, uint32_t height, uint32_t seed, uint32_t n, const uint32_t* pixel_idx, const uint32_t* n_spp, float* out6);

@@ -894,6 +894,29 @@ void orc_bsdf(const void* material180, int entering, int n, const float* wo, con
     for (int k = 0; k < 7; ++k) r[11 + k] = b.dist.pmf(k);
   }
 }
+// the same known answers with the interface's relative index of refraction GIVEN instead of the constructor's 1.5 or 1 / 1.5 (bsdf.cu:16-18): the lobe classes take
+// it as a constructor argument (bxdf.cu:433-442, :620-627), and the reference's REFLECTION_IOR1_LUT (lut.cu:94-916) tabulates the dielectric reflection lobe over
+// eta in (0, 1) -- tests/test_lut_integral_pin.py replays that table through this entry.  Everything else as orc_bsdf with entering = true.
+void orc_bsdf_ior(const void* material180, float eta, int n, const float* wo, const float* wi, const float* u1, const float* u2, float* out)
+{
+  Scene dummy;
+  const ShadingParams sp = shading_params(dummy, *(const Material*)material180, v2(0.0f, 0.0f));
+  for (int i = 0; i < n; ++i) {
+    const V3 o = v3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), in = v3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+    Bsdf b(o, sp, true);
+    b.ni = 1.0f; b.nt = eta; b.eta = eta;
+    b.coat_l.init(eta, b.p.coat_roughness);
+    b.spec_l.init(eta, b.p.specular_roughness);
+    b.trans_l.init(1.0f, eta, b.p.specular_roughness);
+    const V3 e = b.eval(o, in);
+    V3 f; float pdf;
+    const V3 swi = b.sample(o, u1[i], v2(u2[2 * i], u2[2 * i + 1]), f, pdf);
+    float* r = out + 18 * i;
+    r[0] = e.x; r[1] = e.y; r[2] = e.z; r[3] = b.eval_pdf(o, in);
+    r[4] = swi.x; r[5] = swi.y; r[6] = swi.z; r[7] = f.x; r[8] = f.y; r[9] = f.z; r[10] = pdf;
+    for (int k = 0; k < 7; ++k) r[11 + k] = b.dist.pmf(k);
+  }
+}
 void orc_hosek_cook(float turbidity, float albedo, const float* sun_dir, float* out30)
 {
   const float elevation = (float)(0.5f * M_PI - oe::acos(clampf(sun_dir[1], -1.0f, 1.0f)));  // renderer.h:592-601

@@ -107,6 +107,19 @@ def bsdf(material, entering, wo, wi, u1, u2):
     return out
 
 
+def bsdf_ior(material, eta, wo, wi, u1, u2):
+    """orc_bsdf with the relative index of refraction given (the reference's constructor fixes 1.5 / (1 / 1.5), bsdf.cu:16-18)"""
+    m = np.ascontiguousarray(material)
+    assert m.dtype.itemsize == 180
+    wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+    wi = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+    u1 = np.ascontiguousarray(u1, dtype=np.float32)
+    u2 = np.ascontiguousarray(u2, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((wo.shape[0], 18), dtype=np.float32)
+    lib().orc_bsdf_ior(_p(m), C.c_float(eta), int(wo.shape[0]), _p(wo), _p(wi), _p(u1), _p(u2), _p(out))
+    return out
+
+
 def hosek_cook(turbidity, albedo, sun_dir):
     out = np.zeros(30, dtype=np.float32)
     lib().orc_hosek_cook(C.c_float(turbidity), C.c_float(albedo), _p(np.asarray(sun_dir, dtype=np.float32)), _p(out))
@@ -221,6 +234,16 @@ def ref_math(kind, x):
             R.ref_tone_map_tail(int(rgb.shape[0]), C.c_float(float(v)), _p(rgb), _p(o)); out[m] = o
     else:
         raise KeyError(kind)
+    return out
+
+
+def ref_albedo_reflection_ior1(x):
+    """the reference's compute_directional_albedo_reflection_ior1 (lut.cu:1038-1045) for rows (w.y, roughness, eta)"""
+    R = ref_lut_math_post()
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3)
+    a, b, c = (np.ascontiguousarray(x[:, j]) for j in range(3))
+    out = np.zeros(x.shape[0], dtype=np.float32)
+    R.ref_albedo_reflection_ior1(int(x.shape[0]), _p(a), _p(b), _p(c), _p(out))
     return out
 
 

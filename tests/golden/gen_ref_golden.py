@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/ref_lut_math_post.npz by RUNNING the reference's own functions, built for the host from its sources by
 oracle/Makefile into oracle/_ref/libref_lut_math_post.so:
-  fredholm/modules/lut.cu:957-1081   compute_directional_albedo_reflection / _sheen (+ the raw tables)
+  fredholm/modules/lut.cu:957-1081   compute_directional_albedo_reflection / _reflection_ior1 / _sheen (+ the three raw tables, :5-955)
   fredholm/modules/math.cu:7-35,90-118   orthonormal_basis, world_to_local, local_to_world, rgb_to_luminance, cartesian_to_spherical
   fredholm/kernels/include/kernels/post-process.h:13-124   rgb_to_luminance, uchimura, linear_to_srgb, compute_EV100,
                                                            convert_EV100_to_exposure, and the tail of tone_mapping_kernel
@@ -54,6 +54,14 @@ def main():
         data["out_" + kind] = O.ref_math(kind, x)
     refl, sheen = O.ref_lut_tables()
     data["table_reflection"], data["table_sheen"] = refl, sheen
+    # REFLECTION_IOR1_LUT (lut.cu:94-916), 16^3: the reference's own trilinear fetcher (lut.cu:1006-1045) returns the raw entry [i + 16 j + 256 k] at
+    # (w.y, roughness, eta) = (i, j, k) / 16 (all three fractions are exactly 0 there); plus the fetcher itself at random points
+    g = (np.arange(16) / 16.0).astype(np.float32)
+    kk, jj, ii = np.meshgrid(g, g, g, indexing="ij")
+    data["table_reflection_ior1"] = O.ref_albedo_reflection_ior1(np.stack([ii.ravel(), jj.ravel(), kk.ravel()], 1))
+    rng = np.random.default_rng(20261005)
+    x = rng.uniform(-0.1, 1.1, (2000, 3)).astype(np.float32)
+    data["in_albedo_reflection_ior1"], data["out_albedo_reflection_ior1"] = x, O.ref_albedo_reflection_ior1(x)
     out = os.path.join(ROOT, "tests", "golden", "ref_lut_math_post.npz")
     np.savez_compressed(out, **data)
     print({k: v.shape for k, v in data.items()}, "->", out, os.path.getsize(out), "bytes")

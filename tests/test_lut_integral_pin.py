@@ -1,8 +1,8 @@
 """A pin of the lobes to reference DATA: the reference's albedo tables are integrals of its own lobes.
 
-`fredholm/modules/lut.cu:5-93` (REFLECTION_LUT, 16 x 16 x 2) and `:917-955` (SHEEN_LUT, 16 x 16) are the only numbers in the reference tree that were
-produced BY the GGX reflection lobe (`bxdf.cu:428-518`) and the sheen lobe (`bxdf.cu:743-822`): directional albedos over (cos theta_o, roughness).  The
-baking code is not in the tree; what the tables hold was found by trying:
+`fredholm/modules/lut.cu:5-93` (REFLECTION_LUT, 16 x 16 x 2), `:917-955` (SHEEN_LUT, 16 x 16) and `:94-916` (REFLECTION_IOR1_LUT, 16^3, declared but never
+fetched on the live path) are the numbers in the reference tree that were produced BY the GGX reflection lobe (`bxdf.cu:428-518`) and the sheen lobe
+(`bxdf.cu:743-822`): directional albedos over (cos theta_o, roughness[, eta]).  The baking code is not in the tree; what the tables hold was found by trying:
 
   * every entry is the Monte-Carlo mean of  f(wo, wi) |cos theta_i| / pdf  over the lobe's OWN `sample()` -- half vector from the visible-normal /
     cosine distribution, wi = reflect(wo, wh) -- WITHOUT rejecting reflected directions below the horizon (the lobes use |cos|, so such samples
@@ -20,6 +20,14 @@ Observed (and asserted with a little room):
               i.e. the 0.99 itself and nothing else; down to -9 % at cos 0.031
   reflection  0.04 x + 0.96 y against the dielectric lobe at ior 1.5: -6 % ... +29 % -- the table's Schlick Fresnel against the lobe's exact one
               (exact F(58 deg) = 0.083, Schlick 0.063), +-5 % at normal incidence where Schlick is exact; stated, not tuned away
+  reflection, eta < 1 (round 6)  REFLECTION_IOR1_LUT, lut.cu:94-916: 16^3 over (cos theta_o, roughness, eta), declared and never fetched by the reference's live
+              path (lut.cu:1038-1045), is the SAME estimator applied to `MicrofacetReflectionDielectric(ior = eta, roughness)` with its EXACT Fresnel, total internal
+              reflection included (bxdf.cu:274-283: F = 1 where eta^2 + c^2 < 1) -- its eta-cell-0 slice equals REFLECTION_LUT.x to four digits.  The constructor of
+              `BSDF` only ever passes 1.5 or 1 / 1.5 (bsdf.cu:16-18), so the replay goes through `orc_bsdf_ior` / `fh_kat_bsdf_ior`, which set the relative index the
+              lobe classes take as an argument.  All 4096 cells: |replay - table| <= 0.0085 (rms 0.0018) with 48 x 48 draws; on the 3759 cells whose table value is
+              >= 0.05: rms 0.35 %, 15 cells beyond 2 %, worst 4.8 %, all on the edge of total internal reflection where a cell is the mean of a step.  The cells far
+              BELOW 0.05 (eta -> 1, smooth: F0 ~ 2e-4) are dominated by the few microfacets in GGX's tail that reflect totally; the replay converges to the table
+              from below with the number of draws (-43 % at 48^2, -4 % at 384^2 on the cell checked here), so they are held to the absolute bound only.
 and the hemispherical integral proper (directions below the horizon rejected) is what the table holds only for smooth lobes: at roughness 1 and
 normal incidence the table is TWICE the integral (0.626 against 1 - ln 2 = 0.307): the reference's albedo tables overestimate rough lobes, by construction.
 """
@@ -108,6 +116,81 @@ def check_tables(bsdf):
     assert np.abs(e[:, 15]).max() < 0.07  # normal incidence: Schlick's approximation is exact in F0 there, the two Fresnel models agree and so do lobe and table
 
 
+T_IOR1 = GOLD["table_reflection_ior1"].reshape(16, 16, 16)  # [eta k][roughness j][cos i]  (lut.cu:994-1003: idx = i + 16 j + 256 k)
+
+
+def check_ior1_table(bsdf_ior, eta_cells, k=48):
+    """the third table: every (cos, roughness) cell of the given eta slices, replayed through the dielectric reflection lobe at ior = eta (cell centres)"""
+    worst_abs, rel_all, n_over = 0.0, [], 0
+    for kc in eta_cells:
+        eta = float(CENTRES[kc])
+        e = np.array([replay(lambda m, wo, wi, u1, u2: bsdf_ior(m, eta, wo, wi, u1, u2), dielectric(float(CENTRES[j])), CENTRES, k) for j in range(16)])
+        t = T_IOR1[kc].astype(np.float64)
+        worst_abs = max(worst_abs, float(np.abs(e - t).max()))
+        big = t >= 0.05
+        rel = e[big] / t[big] - 1.0
+        rel_all.append(rel)
+        n_over += int((np.abs(rel) > 0.02).sum())
+        # total internal reflection proper: smooth cells (roughness <= 3/32) below the critical angle hold F = 1 and nothing else
+        tir = CENTRES < np.sqrt(max(1.0 - eta * eta, 0.0)) - 0.08
+        if tir.any():
+            assert np.abs(e[:2][:, tir] / T_REFL[:2][:, tir, 0] - 1.0).max() < 0.01  # = REFLECTION_LUT.x, whose Fresnel is 1
+            assert np.abs(t[:2][:, tir] / T_REFL[:2][:, tir, 0] - 1.0).max() < 0.01
+    rel = np.concatenate(rel_all)
+    print(f"REFLECTION_IOR1_LUT, eta cells {list(eta_cells)}: max |replay - table| {worst_abs:.5f}; {rel.size} cells >= 0.05: rms {np.sqrt((rel ** 2).mean()):.5f}, "
+          f"worst {rel.min():+.4f} / {rel.max():+.4f}, {n_over} beyond 2 %")
+    assert worst_abs < 0.012
+    assert np.sqrt((rel ** 2).mean()) < 0.006 and np.abs(rel).max() < 0.06 and n_over <= 0.01 * rel.size + 2
+
+
+def check_ior1_tail_cell(bsdf_ior):
+    """a cell far below 0.05 (eta 0.969, roughness 0.219, cos 0.656: table 0.00149, F at normal incidence 2.5e-4): what is there comes from GGX's tail reflecting totally,
+    and the replay climbs to the table with the number of draws"""
+    eta, r, i = float(CENTRES[15]), float(CENTRES[3]), 10
+    t = float(T_IOR1[15, 3, i])
+    lo = replay(lambda m, wo, wi, u1, u2: bsdf_ior(m, eta, wo, wi, u1, u2), dielectric(r), [CENTRES[i]], 48)[0]
+    hi = replay(lambda m, wo, wi, u1, u2: bsdf_ior(m, eta, wo, wi, u1, u2), dielectric(r), [CENTRES[i]], 384)[0]
+    print(f"tail cell: table {t:.5f}, replay {lo:.5f} at 48^2 draws, {hi:.5f} at 384^2")
+    assert lo < hi and abs(hi / t - 1.0) < 0.10 and abs(lo / t - 1.0) > 0.25
+
+
+def test_ior1_table_layout_is_the_fetchers(oracle):
+    """the axis order read off lut.cu:994-1045 -- x = |w.y|, y = roughness, z = eta, idx = i + 16 j + 256 k, trilinear with clamped neighbours -- restated in numpy
+    float32 reproduces the reference's own fetcher (run by gen_ref_golden.py) bit for bit at 2000 random points, clamps included"""
+    f = np.float32
+    x = GOLD["in_albedo_reflection_ior1"]
+    u, v, z = np.abs(x[:, 0]), np.clip(x[:, 1], f(0), f(1)), np.clip(x[:, 2], f(0), f(1))
+    uvz = [u * f(16), v * f(16), z * f(16)]
+    ijk = [np.clip(a.astype(np.int32), 0, 15) for a in uvz]
+    h = [a - b.astype(f) for a, b in zip(uvz, ijk)]
+    at = lambda di, dj, dk: T_IOR1[np.clip(ijk[2] + dk, 0, 15), np.clip(ijk[1] + dj, 0, 15), np.clip(ijk[0] + di, 0, 15)]
+    t00 = at(0, 0, 0) * (f(1) - h[0]) + at(1, 0, 0) * h[0]
+    t01 = at(0, 0, 1) * (f(1) - h[0]) + at(1, 0, 1) * h[0]
+    t10 = at(0, 1, 0) * (f(1) - h[0]) + at(1, 1, 0) * h[0]
+    t11 = at(0, 1, 1) * (f(1) - h[0]) + at(1, 1, 1) * h[0]
+    t0 = t00 * (f(1) - h[1]) + t10 * h[1]
+    t1 = t01 * (f(1) - h[1]) + t11 * h[1]
+    got = (t0 * (f(1) - h[2]) + t1 * h[2]).astype(f)
+    assert np.array_equal(got.view(np.uint32), GOLD["out_albedo_reflection_ior1"].view(np.uint32))
+
+
+def test_ior1_table_is_the_integral_of_the_checkers_dielectric_lobe(oracle):
+    check_ior1_table(oracle.bsdf_ior, range(16))
+    check_ior1_tail_cell(oracle.bsdf_ior)
+
+
+def test_bsdf_ior_entry_is_the_constructor_at_its_own_index(oracle):
+    """orc_bsdf_ior at eta = 1.5 is orc_bsdf(entering = true), bit for bit: the entry changes the index and nothing else"""
+    rng = np.random.default_rng(11)
+    n = 4096
+    wo = rng.normal(size=(n, 3)).astype(np.float32); wo[:, 1] = np.abs(wo[:, 1]); wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    wi = rng.normal(size=(n, 3)).astype(np.float32); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    u1, u2 = rng.random(n, dtype=np.float32), rng.random((n, 2), dtype=np.float32)
+    m = _material(specular=1.0, specular_roughness=0.3, transmission=0.5, coat=0.4, sheen=0.2)
+    a, b = oracle.bsdf(m, True, wo, wi, u1, u2), oracle.bsdf_ior(m, 1.5, wo, wi, u1, u2)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_reference_albedo_tables_are_integrals_of_the_checkers_lobes(oracle):
     check_tables(lambda m, wo, wi, u1, u2: oracle.bsdf(m, True, wo, wi, u1, u2))
 
@@ -139,3 +222,34 @@ def test_reference_albedo_tables_are_integrals_of_the_hip_lobes(renderer):
         return out
 
     check_tables(bsdf)
+
+
+def _hip_bsdf_ior(renderer):
+    from fredholm_amd import native as N
+
+    def bsdf_ior(m, eta, wo, wi, u1, u2):
+        n = wo.shape[0]
+        out = np.zeros((n, 18), np.float32)
+        rc = N.lib().fh_kat_bsdf_ior(renderer._ctx, N.ptr(np.ascontiguousarray(m)), C.c_float(eta), C.c_uint32(127), n, N.ptr(np.ascontiguousarray(wo)), N.ptr(np.ascontiguousarray(wi)),
+                                     N.ptr(np.ascontiguousarray(u1)), N.ptr(np.ascontiguousarray(u2)), N.ptr(out))
+        assert rc == 0
+        return out
+
+    return bsdf_ior
+
+
+@pytest.mark.gpu
+def test_ior1_table_is_the_integral_of_the_hip_dielectric_lobe(renderer, oracle):
+    """all sixteen eta slices through fh_kat_bsdf_ior (the device code of the shade kernels), and the entry against the checker's bit for bit"""
+    hip = _hip_bsdf_ior(renderer)
+    check_ior1_table(hip, range(16))
+    check_ior1_tail_cell(hip)
+    rng = np.random.default_rng(12)
+    n = 1 << 16
+    wo = rng.normal(size=(n, 3)).astype(np.float32); wo[:, 1] = np.abs(wo[:, 1]); wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    wi = rng.normal(size=(n, 3)).astype(np.float32); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    u1, u2 = rng.random(n, dtype=np.float32), rng.random((n, 2), dtype=np.float32)
+    for eta in (0.03125, 0.40625, 0.96875, 1.5):
+        for m in (dielectric(0.35), _material(specular=1.0, specular_roughness=0.3, transmission=0.5, coat=0.4, sheen=0.2)):
+            a, b = hip(m, eta, wo, wi, u1, u2), oracle.bsdf_ior(m, eta, wo, wi, u1, u2)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), eta
