@@ -8,6 +8,13 @@
 #include <filesystem>
 #include <stdexcept>
 
+// the reference's header includes the application's logging library (renderer.h:12), and app/controller.cpp:311 relies on getting it from here
+#if defined(__has_include)
+#if __has_include("spdlog/spdlog.h")
+#include "spdlog/spdlog.h"
+#endif
+#endif
+
 #include "../cwl/util.h"
 #include "../optwl/optwl.h"
 #include "camera.h"

@@ -291,6 +291,56 @@ struct Layers {
     assert r.returncode == 0, r.stderr
 
 
+REF_APP = "/root/reference/app"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_APP, "rtcamp8.cpp")), reason="the reference checkout exists only in the build container")
+def test_reference_apps_compile_against_the_facade(tmp_path):
+    """north_star's literal drop-in claim: the reference's OWN application sources -- app/rtcamp8.cpp (headless batch driver, :47-303) and app/controller.cpp
+    (the GUI's render-side half, :8-330) -- compile UNEDITED against include/, from where they lie (never copied; outputs go to tmp_path).  Only their
+    third-party leaves are stood in for under tests/shims/app: spdlog (no-op logging) and stb_image_write (declarations), both empty submodules of the checkout.
+    rtcamp8.cpp is also LINKED against libfredholm_hip.so, so every symbol the header-only facade forwards to exists.  `MODULES_SOURCE_DIR` is the CMake
+    definition of fredholm/CMakeLists.txt:44; controller.cpp needs OpenGL types for its CUDAGLBuffer members (cwl/buffer.h:88-143), hence FH_WITH_OPENGL."""
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "shims", "app")]
+    r = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", *inc, os.path.join(REF_APP, "rtcamp8.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-DFH_WITH_OPENGL", '-DMODULES_SOURCE_DIR="/nonexistent"', *inc, "-I" + REF_APP, os.path.join(REF_APP, "controller.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = tmp_path / "ref_rtcamp8"
+    r = subprocess.run(["g++", "-std=c++20", "-O1", *inc, os.path.join(REF_APP, "rtcamp8.cpp"), os.path.join(ROOT, "tests", "shims", "app", "stb_image_write_impl.cpp"), "-o", str(exe),
+                        "-L" + os.path.join(ROOT, "fredholm_amd"), "-lfredholm_hip", "-Wl,-rpath," + os.path.join(ROOT, "fredholm_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-pthread"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    nm = subprocess.run(["nm", "-D", "--undefined-only", str(exe)], capture_output=True, text=True).stdout
+    used = {ln.split()[-1] for ln in nm.splitlines() if " fh_" in ln}
+    assert {"fh_render", "fh_sync", "fh_scene_upload", "fh_bvh_build", "fh_set_transforms", "fh_post_process", "fh_denoise", "fh_load_arhosek_sky"} <= used, sorted(used)
+
+
+def test_cuda_check_names_of_the_facade_behave_like_the_reference_macro(tmp_path):
+    """cwl/util.h: CUDA_CHECK throws std::runtime_error carrying the call text, file and line (reference cwl/util.h:11-21); cudaFree(0) creates the context --
+    on a box without a GPU that is the loud failure path"""
+    src = tmp_path / "cc.cpp"
+    src.write_text("""
+#include "cwl/util.h"
+#include <cstdio>
+#include <cstring>
+int main() {
+  try { CUDA_CHECK(cudaFree(0)); std::puts("context ok"); }
+  catch (const std::runtime_error& e) { std::printf("threw: %s", e.what()); return std::strstr(e.what(), "cudaFree(0)") && std::strstr(e.what(), "cc.cpp:") ? 3 : 4; }
+  try { CUDA_CHECK(FH_E_INVALID); } catch (const std::runtime_error& e) { return std::strstr(e.what(), "FH_E_INVALID") ? 0 : 5; }
+  return 6;
+}
+""")
+    exe = tmp_path / "cc"
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L" + os.path.join(ROOT, "fredholm_amd"), "-lfredholm_hip",
+                        "-Wl,-rpath," + os.path.join(ROOT, "fredholm_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    import torch
+    assert run.returncode == (0 if torch.cuda.is_available() else 3), run.stdout + run.stderr
+
+
 # ---------------------------------------------------------------- image files (include/fredholm/image_io.h, fredholm_amd/image_io.py)
 def _png_bytes(w, h, depth, ctype, rows, extra=b""):
     import struct
