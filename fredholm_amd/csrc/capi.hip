@@ -980,6 +980,14 @@ int fh_kernel_info(fh_ctx* ctx, int which, uint32_t out[6])
   if (!out || which < 0 || which > 1) return fail(ctx, FH_E_INVALID, "fh_kernel_info: which must be 0 (closest hit) or 1 (secondary rays)");
   return kernel_info(ctx, which, out);
 }
+// test hook (fredholm_hip_test.h): where the scene's first-hit rays start, and what the probing passes have counted so far
+int fh_kat_ray_start(fh_ctx* ctx, double out[5])
+{
+  CTX_CHECK(ctx);
+  if (!out) return fail(ctx, FH_E_INVALID, "fh_kat_ray_start: null argument");
+  out[0] = (double)ctx->bu_choice; out[1] = ctx->bu_items[0]; out[2] = ctx->bu_items[1]; out[3] = ctx->bu_cost[0]; out[4] = ctx->bu_cost[1];
+  return FH_OK;
+}
 int fh_reset_stats(fh_ctx* ctx)
 {
   CTX_CHECK(ctx);

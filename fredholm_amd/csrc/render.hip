@@ -659,8 +659,9 @@ FH_D f3 emission_of(const SceneDev& sc, const MaterialDev& m, float tu, float tv
 FH_D void store_secondary(const PoolDev& pool, uint32_t slot, uint32_t p, f3 o, float tmax, f3 d, bool active, f3 c, uint32_t start_bits = 1u)
 {
   const size_t k = pool.sec_at(slot, p);
-  pool.sec[k] = mk4(o, tmax);
   pool.sec[k + 1] = mk4(d, __uint_as_float(active ? start_bits : 0u));
+  if (!active) return;  // (nobody reads origin or contribution of a place without a ray)
+  pool.sec[k] = mk4(o, tmax);
   pool.sec[k + 2] = mk4(c, 0.0f);
 }
 
@@ -693,6 +694,12 @@ struct BounceSlots {
 };
 
 struct SecRay { f3 o; float tmax; f3 d; bool active; f3 c; };
+
+// A shadow ray whose pre-multiplied contribution is exactly (+-0, +-0, +-0) cannot change a bit of the result whatever it hits: the radiance it would be added to starts at
+// +0 and a sum is -0 only when both terms are, so x + (+-0) == x for every radiance x that can occur.  The reference traces it all the same (pt.cu:837-857 sends the sky's
+// shadow ray for a black constant background too: one of three secondary rays per bounce of a Cornell box); here such a ray is stored as "no ray in this
+// place".  NaN compares unequal to 0 and stays: a NaN contribution of an unoccluded ray must still reach the radiance and zero the sample (pt.cu:474-478).
+FH_D bool contributes(f3 c) { return !(c.x == 0.0f && c.y == 0.0f && c.z == 0.0f); }
 
 // What one shaded hit produces (pt.cu:680-944) goes to a SINK as soon as it exists, so that a kernel that only stores the products
 // (k_shade) does not keep them alive in registers next to the BSDF state; k_tail, which traces the rays itself, collects them in
@@ -826,7 +833,8 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows<4>& 
     const f3 f = bsdf.eval(wo, wi);
     const float pdf = 1.0f;
     const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
-    out.secondary(SEC_DIR, so, 1e9f - 0.001f, sd, true, clamp01(T * w * f * abs_cos(wi) / pdf) * fr.dir_le);
+    const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * fr.dir_le;
+    out.secondary(SEC_DIR, so, 1e9f - 0.001f, sd, contributes(c), c);
   }
   // sky / constant background (pt.cu:817-857)
   {
@@ -835,7 +843,8 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows<4>& 
     const f3 f = bsdf.eval(wo, wi);
     const float pdf = abs_cos(wi) / kPi;
     const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
-    out.secondary(SEC_SKY, so, 1e9f - 0.001f, sd, true, clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, sd));
+    const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, sd);
+    out.secondary(SEC_SKY, so, 1e9f - 0.001f, sd, contributes(c), c);
   }
   // area lights (pt.cu:860-889, :282-322)
   if (has_lights) {
@@ -861,7 +870,8 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows<4>& 
     const f3 f = bsdf.eval(wo, wi);
     const float pdf = r * r / fabsf(dot(-sd, ln)) * pdf_area;
     const float w = pdf / (pdf + bsdf.eval_pdf(wo, wi));
-    out.secondary(SEC_AREA, so, r - 0.001f, sd, facing, clamp01(T * w * f * abs_cos(wi) / pdf) * le);
+    const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * le;
+    out.secondary(SEC_AREA, so, r - 0.001f, sd, facing && contributes(c), c);
   }
   // BSDF-sampled light ray (pt.cu:893-925)
   {
@@ -881,7 +891,8 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows<4>& 
       // no emitters: the ray contributes only if it escapes, with the sky's cosine pdf (pt.cu:917-919)
       const float pdf_light = abs_cos(wi) / kPi;
       const float w = pdf / (pdf + pdf_light);
-      out.secondary(SEC_LIGHT, lo, 1e9f, ld, true, clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, ld));
+      const f3 c = clamp01(T * w * f * abs_cos(wi) / pdf) * env_radiance(fr, ld);
+      out.secondary(SEC_LIGHT, lo, 1e9f, ld, contributes(c), c);
     }
   }
   // next direction (pt.cu:928-943) and the next bounce's Russian roulette (pt.cu:457-471)
@@ -2011,8 +2022,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     if (slots > 1u && passes > slots && passes % slots != 0u && (passes / slots + 1u) * slots <= n_samples) passes = (passes / slots + 1u) * slots;
     batch = (n_samples + passes - 1u) / passes;
   }
-  // (the passes of a call overlap, three in flight: a big call that would fit two passes is cut into three of the same size)
-  if ((n_samples + batch - 1u) / batch < (uint32_t)ctx->n_slots && n_samples >= (uint32_t)ctx->n_slots && (unsigned long long)n_samples * n_px >= 3ull << 24) batch = (n_samples + (uint32_t)ctx->n_slots - 1u) / (uint32_t)ctx->n_slots;
+  // (the passes of a call overlap, three in flight: a big call that would fit one or two passes is cut into three of the same size -- unless its passes run one after
+  // the other anyway: the bug-compat mode and the measuring mode, where a split is pure overhead)
+  if (!quirk_call && (ctx->flags & FH_FLAG_SERIAL_PASSES) == 0 && (n_samples + batch - 1u) / batch < (uint32_t)ctx->n_slots && n_samples >= (uint32_t)ctx->n_slots && (unsigned long long)n_samples * n_px >= 3ull << 24) batch = (n_samples + (uint32_t)ctx->n_slots - 1u) / (uint32_t)ctx->n_slots;
 
   const SceneDev sc_all = scene_dev(ctx);
   const SceneDev& sc = sc_all;  // (the passes below shadow this with their own copy: where rays start is a per-pass choice)
@@ -2240,7 +2252,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     if (sc_all.bvh8.parent && stream && (ctx->flags & FH_FLAG_ROOT_START) == 0u) {
       if (tun.bottom_up == 1u) use_bu = true;
       else if (tun.bottom_up == 2u) {
-        if (ctx->bu_choice == 0 && !count) { use_bu = (ctx->bu_toggle++ & 1u) != 0u; pass_bu = use_bu ? 1 : 0; }
+        // (only a pass whose secondary launch can climb is a probe: the merged launch of a one-pass call walks from the root whatever the pass says and counts no test
+        // rounds, so counting it would fill one side of the comparison with cost 0 and fix the choice at "root" -- the reference's 1- and 16-sample calls come first in a GUI)
+        if (ctx->bu_choice == 0 && !count && !merge && !sc_all.has_alpha) { use_bu = (ctx->bu_toggle++ & 1u) != 0u; pass_bu = use_bu ? 1 : 0; }
         else use_bu = ctx->bu_choice == 2;
       }
     }

@@ -107,7 +107,7 @@ EXPORTS = [
     "fh_pack_owned", "fh_unpack_shard", "fh_render", "fh_sync", "fh_get_stats", "fh_reset_stats", "fh_post_process", "fh_denoise", "fh_gl_register_buffer", "fh_gl_unregister_buffer", "fh_malloc",
     "fh_free", "fh_memset", "fh_copy_to_device", "fh_copy_to_host", "fh_copy_on_device", "fh_image_load_rgba8", "fh_image_free", "fh_stream", "fh_trace_rays", "fh_kernel_info", "fh_kat_hash", "fh_kat_cmj",
     "fh_kat_sobol", "fh_kat_elementary", "fh_kat_warp", "fh_kat_bsdf", "fh_kat_bsdf_ior", "fh_kat_sky", "fh_kat_hosek_state", "fh_kat_camera",
-    "fh_kat_offset_origin", "fh_kat_math", "fh_kat_sqrt", "fh_kat_tex2d", "fh_kat_face_classes", "fh_kat_alpha_records", "fh_measure_bandwidth",
+    "fh_kat_offset_origin", "fh_kat_math", "fh_kat_sqrt", "fh_kat_tex2d", "fh_kat_face_classes", "fh_kat_alpha_records", "fh_kat_ray_start", "fh_measure_bandwidth",
 ]
 
 _lib = None

@@ -52,6 +52,9 @@ int fh_kat_face_classes(fh_ctx* ctx, uint8_t* out, uint32_t n);
 /* the any-hit record of every face (n_faces x 32 words: texture coordinates, flags, texture pointers, then 16 words of opacity micromap: two bits per cell, cell = 16 * floor(16 v) + floor(16 u));
    all zero for scenes without cut-outs */
 int fh_kat_alpha_records(fh_ctx* ctx, uint32_t* out, uint32_t n_faces);
+/* where the scene's first-hit rays start their traversal (render.hip, "where this pass's first-hit rays start"): out[0] = 0 still probing, 1 the root, 2 the wide node of
+   the face they leave; out[1..2] = shaded paths the probing passes have counted from the root / from the face, out[3..4] = their test cycles by the issue model's weights */
+int fh_kat_ray_start(fh_ctx* ctx, double out[5]);
 
 #ifdef __cplusplus
 }

@@ -798,6 +798,87 @@ def test_rays_that_start_at_the_node_of_their_face_do_not_change_results(oracle,
             _assert_image_parity(gpu[name], ref[name])
 
 
+def test_one_pass_calls_do_not_decide_where_rays_start(monkeypatch):
+    """The probing that decides where a scene's first-hit rays start counts test rounds of the SECONDARY launch proper.  A call of one pass -- the reference GUI's 1-sample
+    calls, the first thing a scene sees -- traces its secondary rays in the merged launch, which walks from the root and counts nothing: such calls must not be taken for
+    probes (they used to fill both sides of the comparison with cost 0 and fix the choice at the root until the next build).  Then multi-pass calls decide
+    (this 60 k-triangle soup: 728 against 733 test cycles per shaded path, so the root; the 1 M-triangle soup of configs[2]: 378 against 313, the face's node)."""
+    monkeypatch.setenv("FH_STREAM", "1")
+    monkeypatch.setenv("FH_BOTTOM_UP", "2")
+    monkeypatch.delenv("FH_MERGE", raising=False)
+    r = F.Renderer(0)
+    r.load_scene(scenes.triangle_soup(60000, 0.05))
+    r.build_ias()
+    r.load_arhosek_sky(3.0, 0.3)
+    w, h = 192, 108
+    r.set_resolution(w, h)
+    cam = F.Camera(**scenes.SOUP_CAMERA)
+    L = F.RenderLayer(r, w, h)
+
+    def ray_start():
+        out = (C.c_double * 5)()
+        _kat(r, "fh_kat_ray_start", out)
+        return [float(x) for x in out]
+
+    for _ in range(12):  # one-pass calls, with the host behind the GPU every time so that every counter snapshot is read
+        r.render(cam, (0.0, 0.0, 0.0), L, 1, 6)
+        r.wait_for_completion()
+    st = ray_start()
+    assert st[0] == 0.0 and st[1] == 0.0 and st[2] == 0.0, st  # still probing, nothing counted
+    r.set_path_pool(w * h * 2)  # 16 samples = eight passes of two
+    for _ in range(16):
+        r.render(cam, (0.0, 0.0, 0.0), L, 16, 6)
+        r.wait_for_completion()
+        if ray_start()[0] != 0.0:
+            break
+    st = ray_start()
+    assert st[0] in (1.0, 2.0), st  # decided -- by what BOTH kinds of probing passes counted: paths and test cycles on either side, and the rule itself
+    assert st[1] >= 65536.0 and st[2] >= 65536.0 and st[3] > 0.0 and st[4] > 0.0, st
+    assert (st[0] == 2.0) == (st[4] / st[2] < 0.95 * st[3] / st[1]), st
+    r.close()
+
+
+def _secondary_rays_per_shaded_hit(sc, setup, bg, w=96, h=72, spp=4, depth=4):
+    r = F.Renderer(0)
+    r.load_scene(sc)
+    r.build_ias()
+    if setup:
+        setup(r)
+    r.set_resolution(w, h)
+    r.set_tail_depth(depth)  # every bounce through the wavefront kernels, which count
+    r.set_flags(2)           # FH_FLAG_COUNT_TRAVERSAL
+    L = F.RenderLayer(r, w, h)
+    r.render(F.Camera(**scenes.CORNELL_CAMERA), bg, L, spp, depth)
+    r.wait_for_completion()
+    st = r.stats()
+    r.close()
+    return st["rays_shadow"] / max(st["shaded_hits"], 1)
+
+
+def test_secondary_rays_that_cannot_contribute_are_not_traced(oracle):
+    """pt.cu:837-857 sends the sky's shadow ray for a black constant background too; its contribution is exactly (0, 0, 0), so nothing it hits can change a bit of the result
+    and the ray is dropped (render.hip: contributes).  Counted: a Cornell box under a black background traces at most the area-light ray and the light ray per shaded hit,
+    under a grey one the sky ray too; and the images of both -- and of the cases where the dropped ray's contribution is NaN and must NOT be dropped: a Hosek sky seen
+    from below (arhosek.cu:113, radiance NaN below the horizon zeroes the sample, pt.cu:474-478) -- stay bit-identical to the checker, which traces every ray."""
+    black = _secondary_rays_per_shaded_hit(scenes.cornell_box(), None, (0.0, 0.0, 0.0))
+    grey = _secondary_rays_per_shaded_hit(scenes.cornell_box(), None, (0.2, 0.3, 0.5))
+    assert black <= 2.0 + 1e-9 and grey > black + 0.9, (black, grey)
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    for bg in ((0.0, 0.0, 0.0), (0.2, 0.3, 0.5), (0.0, 0.5, 0.0)):
+        gpu, ref = _render_pair(oracle, scenes.cornell_box(), cam, 64, 48, launches=2, spp_per_launch=2, depth=5, bg=bg)
+        for name in ("beauty", "albedo"):
+            _assert_image_parity(gpu[name], ref[name])
+
+    def hosek(x):
+        x.load_arhosek_sky(3.0, 0.3)
+
+    # the soup under a Hosek sky, seen from BELOW: most sky-NEE directions of the first hits point below the horizon, where the model's radiance is NaN
+    below = F.Camera(origin=(0.0, -2.6, 1.5), forward=(0.0, 0.866, -0.5), fov=np.radians(60.0), F=100.0, focus=10000.0)
+    gpu, ref = _render_pair(oracle, scenes.triangle_soup(20000, 0.1), below, 80, 60, launches=2, spp_per_launch=2, depth=5, setup=hosek)
+    _assert_image_parity(gpu["beauty"], ref["beauty"])
+    assert np.isfinite(gpu["beauty"]).all() and gpu["beauty"][..., :3].max() > 0.0
+
+
 @pytest.mark.parametrize("mode", ["0", "1", "2"])
 def test_rays_that_start_at_the_node_of_a_cut_out_face_do_not_change_results(oracle, monkeypatch, mode):
     """The same switch in a scene with cut-outs, where the launch of the first-hit rays carries the any-hit test: the fence of alpha-tested quads in the textured Cornell
