@@ -150,6 +150,69 @@ def traversal_roofline(cnt, timed, key, steps, launches, avg_ms, avg_alone_ms, b
                     "priced against HBM only for reference -- node and triangle arrays are served by L2 / Infinity Cache, see traffic"}
 
 
+def shade_record(r, cfg, spp, timed, alone, cnt, steps):
+    """the shade kernels' own record, whether or not they dominate: time alone, shaded hits per second, registers / waves per SIMD of every
+    class's kernel (fh_kernel_info), and -- from the configuration's counter file when it carries a `shade` block of this pass size (tools/collect_profile6.py) -- VALU busy
+    by the static-mix rule, lane utilisation, SQ_WAIT_ANY share, L2 hit rate, fabric bytes per hit"""
+    rec = {"ms_per_step_alone": round(alone["shade_ms"], 3), "ms_per_step_in_flight": round(timed["shade_ms"] / max(steps, 1), 3), "launches_per_step": round(timed["n_shade_launches"] / max(steps, 1), 1),
+           "shaded_hits_per_step": int(cnt["shaded_hits"]), "shaded_ghits_per_s_alone": round(cnt["shaded_hits"] / (alone["shade_ms"] * 1e-3) / 1e9, 3) if alone["shade_ms"] > 0 else None,
+           "algorithmic_bytes_per_hit": SHADE_BYTES_PER_HIT, "kernels": r.shade_kernel_info()}
+    for tj in counter_files(cfg):
+        sh = tj.get("shade")
+        if not sh:
+            continue
+        if pass_size_differs(tj, spp, timed["n_passes"], steps) is not False:
+            rec["counters_unusable"] = {"file": tj["file"], "why": "samples per pass of the counter run differ from this run's"}
+            break
+        hits = max(sh.get("shaded_hits_in_counter_run") or 0, 1)
+        rec.update({"valu_lane_utilisation": sh.get("valu_lane_utilisation"), "wait_any_frac_of_wave_cycles": sh.get("wait_any_frac_of_wave_cycles"), "l2_hit_rate": sh.get("tcc_hit_rate"),
+                    "valu_insts_per_hit": round(sh["valu_insts_total"] / hits, 1) if sh.get("valu_insts_total") and sh.get("shaded_hits_in_counter_run") else None,
+                    "fabric_bytes_per_hit": round(sh["traffic_bytes_total"] / hits, 1) if sh.get("traffic_bytes_total") and sh.get("shaded_hits_in_counter_run") else None,
+                    "lds_bank_conflict_frac": sh.get("lds_bank_conflict_frac"), "counters_from": tj["file"], "counters_stale": tj.get("source_fingerprint") != source_fingerprint()})
+        shares = [fma_share_of(f"k_shade<{k['compiled_for_lobes']}u, 3>") for k in rec["kernels"]]
+        shares = [x["share"] for x in shares if x]
+        fs = {"share": sum(shares) / len(shares)} if shares else None  # (the scene's shade kernels weigh alike here: their static mixes differ by a few per cent)
+        if fs and rec.get("valu_insts_per_hit") and alone["shade_ms"] > 0:
+            rec["fma_class_share_static"] = round(fs["share"], 4)
+            cyc_mix = max(fs["share"] / VALU_FMA_PEAK_PER_CYCLE, (1.0 - fs["share"]) / VALU_OTHER_PEAK_PER_CYCLE)
+            rec["valu_busy"] = round(rec["valu_insts_per_hit"] * cnt["shaded_hits"] * cyc_mix / (alone["shade_ms"] * 1e-3 * N_SIMDS * NOMINAL_CLOCK_GHZ * 1e9), 4)
+        break
+    return rec
+
+
+def freeze_roofline_fields(roof):
+    """Fixed-name fields next to `frac` (one definition that does not move again).  What each means:
+      frac_valu_issue_model          counted wave-level node / triangle tests x their microbenchmarked issue cycles / launch time / (1024 SIMDs x 2.4 GHz): the model `frac` has carried since round 3
+      frac_hbm_counters              (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the kernel's own counter passes / launch time alone / 8 TB/s: what the fabric saw, against the HBM peak; null without a usable counter file
+      frac_survey_8d_over_hbm_peak   SURVEY 8(d) bytes per ray x rays / launch time / 8 TB/s.  NOT a fraction of a roof that can bind: the node and triangle arrays are served by L2 and
+                                     Infinity Cache, so this ratio may exceed 1 on small trees (it is exempt from the [0, 1] rule and says so in bound_verdict)
+      ta_busy, valu_busy             TA_TA_BUSY / (256 CUs x cycles) and executed VALU instructions x the issue cycles of the static mix / SIMD cycles, from the counter file; null without one
+      bound_verdict                  one line: which of these is the roof"""
+    if roof.get("bound") == "valu_issue":
+        roof["frac_valu_issue_model"] = roof.get("frac")
+    roof["frac_hbm_counters"] = roof.get("frac_hbm_measured")
+    roof["frac_survey_8d_over_hbm_peak"] = roof.get("algorithmic_gbs_over_hbm_peak") if roof.get("bound") != "hbm" else roof.get("frac")  # (bound "hbm": `frac` IS the algorithmic bytes over the HBM peak)
+    roof["ta_busy"] = (roof.get("vl1d") or {}).get("ta_busy_frac")
+    roof["valu_busy"] = roof.get("valu_busy_measured")
+    s8, hc, ta, vb = roof["frac_survey_8d_over_hbm_peak"], roof["frac_hbm_counters"], roof["ta_busy"], roof["valu_busy"]
+    parts = []
+    if vb is not None and ta is not None:
+        parts.append(f"bound by VALU issue ({vb:.2f} busy) and the vector L1's look-up rate (TA {ta:.2f} busy) together")
+    elif roof.get("bound") == "valu_issue":
+        parts.append(f"bound by VALU issue (model fraction {roof.get('frac')}; no counter file of this launch size for the measured busy shares)")
+    elif roof.get("bound") == "hbm":
+        parts.append("priced against HBM with its algorithmic bytes (DESIGN.md 4), a lower bound of what moves: the kernel waits on scattered 16-byte accesses and on VALU")
+    if hc is not None:
+        parts.append(f"HBM is not the roof: the counters see {hc:.2f} of the 8 TB/s peak")
+    if s8 is not None:
+        parts.append(f"the SURVEY 8(d) bytes per ray flow at {s8:.2f} x the HBM peak" + (", i.e. out of L2 / Infinity Cache" if (hc is not None and s8 > 2 * hc) or s8 > 0.66 else ""))
+    roof["bound_verdict"] = "; ".join(parts) if parts else None
+    return roof
+
+
+FRAC_EXEMPT = ("frac_survey_8d_over_hbm_peak",)  # a cache-served byte rate over the HBM peak: see freeze_roofline_fields
+
+
 def workload(cfg, tmpdir):
     """scene + environment + camera + frame parameters of BASELINE.json configs[cfg]"""
     import numpy as np
@@ -346,15 +409,16 @@ def usable_counters(cfg, kernel, spp, n_passes, steps):
 
 
 def refuse_bad_fracs(obj, path=""):
-    """A fraction of a roof is in [0, 1].  Any `frac*` field outside (a model priced against the wrong launch, a counter file of another launch size) is NOT printed: it is taken
-    out of the line and listed under `fractions_refused` at the top level, and the run says so on stderr.  Returns the list of (path, value) removed."""
+    """A fraction of a roof is in [0, 1].  Any `frac*` field outside (a model priced against the wrong launch, a counter file of another launch size) is taken out of its place in
+    the line and listed under `fractions_refused` at the top level with its value -- and the run FAILS: main() prints the line (so the record exists) and exits with code 3
+    (round 6; before, the run went on).  Returns the list of (path, value) removed."""
     bad = []
     if isinstance(obj, dict):
         for k in list(obj.keys()):
             v = obj[k]
             if isinstance(v, (dict, list)):
                 bad += refuse_bad_fracs(v, f"{path}.{k}" if path else k)
-            elif k.startswith("frac") and isinstance(v, (int, float)) and not isinstance(v, bool) and not (0.0 <= v <= 1.0):
+            elif k.startswith("frac") and k not in FRAC_EXEMPT and isinstance(v, (int, float)) and not isinstance(v, bool) and not (0.0 <= v <= 1.0):
                 bad.append((f"{path}.{k}" if path else k, v))
                 del obj[k]
     elif isinstance(obj, list):
@@ -459,12 +523,14 @@ def general_scene_block(local_rank, tmpdir, bw, spp=540, steps=2, warmup=1, pool
             cyc_mix = max(fs["share"] / VALU_FMA_PEAK_PER_CYCLE, (1.0 - fs["share"]) / VALU_OTHER_PEAK_PER_CYCLE)
             roof["valu_busy_measured"] = round(per_cycle * cyc_mix, 4)
             roof["valu_busy_formula"] = {"insts_per_cycle_per_simd": round(per_cycle, 4), "fma_class_share_static": fs["share"], "share_from": fs["source"], "share_stale": fs["stale"]}
+    freeze_roofline_fields(roof)
+    shade = shade_record(r, 3, spp, timed, alone, cnt, steps)
     paths = max(cnt["paths"], 1)
     out = {"workload": w["name"], "msamples_per_s": round(W * H * spp * steps / dt / 1e6, 2), "ms_per_step": round(dt / steps * 1e3, 3), "spp_per_step": spp, "spp_per_pass": round(pool_spp, 3) if isinstance(pool_spp, float) else pool_spp,
            "passes_per_step": round(timed["n_passes"] / max(steps, 1), 2), "path_pools": {"gb": round(pool_bytes_timed / 1e9, 1), "paths": int(pool_paths_timed)},
            "steps": steps, "warmup": warmup, "triangles": int(w["scene"]["indices"].shape[0]),
            "note": "BASELINE.json configs[3] at a shorter frame than its 4096 spp (throughput does not depend on the frame length beyond three passes: 512 / 4096 spp measure within 1 %); 540 = twelve passes of 45 samples, the pass the 4096-spp run submits and its counter file was collected with",
-           "roofline": roof,
+           "roofline": roof, "shade": shade,
            "kernel_ms_per_step_alone": {"trace_closest": round(alone["trace_closest_ms"], 3), "trace_secondary": round(alone["trace_shadow_ms"], 3), "shade": round(alone["shade_ms"], 3),
                                         "generate": round(alone["generate_ms"], 3), "route_and_sort": round(alone["queue_ms"], 3), "accumulate": round(alone["accumulate_ms"], 3),
                                         "tail": round(alone["tail_ms"], 3), "render_total": round(alone["render_ms"], 3)},
@@ -477,6 +543,20 @@ def general_scene_block(local_rank, tmpdir, bw, spp=540, steps=2, warmup=1, pool
     out["latency"] = latency_block(r, w, cam, layers, frames=(100, 40))
     r.close()
     return out
+
+
+def self_launch(n_gpus, argv=None):
+    """start `n_gpus` ranks of this script on this node (one process per GPU, rendezvous on 127.0.0.1, a free port) and wait: returns the launcher's exit code, which is
+    non-zero when any rank failed"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    print("bench.py: no WORLD_SIZE in the environment, starting the ranks myself: " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
 
 
 def main():
@@ -494,6 +574,11 @@ def main():
     ap.add_argument("--check-frame", action="store_true", help="N > 1: rank 0 re-renders the whole frame unsharded and compares it bit for bit with the gathered one")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process starts the N ranks through torch.distributed.run as CHILD processes -- it has made no GPU call (torch is
+        # not even imported yet) and never replaces itself -- relays their output (rank 0 prints the JSON line) and exits with the launcher's code
+        sys.exit(self_launch(args.gpus))
+
     import numpy as np
     import torch
 
@@ -505,9 +590,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py` (WORLD_SIZE={world})")
+    if args.gpus != world and args.gpus > 1:
+        raise SystemExit(f"--gpus {args.gpus} under a launcher that started {world} rank(s): start it with --nproc-per-node {args.gpus}, or without a launcher (bench.py then starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     backend = os.environ.get("FH_BENCH_BACKEND", "nccl")  # "gloo": functional test of the N > 1 path on a box with fewer GPUs
@@ -523,6 +607,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    failed_rc = 0
     tmp = tempfile.TemporaryDirectory(prefix="fh_bench_")
     w = workload(args.config, tmp.name)
     WIDTH, HEIGHT, MAX_DEPTH = w["width"], w["height"], w["depth"]
@@ -589,9 +674,8 @@ def main():
                         gathered[k].copy_(host[k], non_blocking=False)
             ev_gathered.record(torch.cuda.current_stream())
             lib_stream.wait_event(ev_gathered)
-            if rank == 0:
-                for k in range(world):       # present the assembled frame (fh_unpack_shard: the inverse of every rank's pack)
-                    r.unpack_shard(k, world, gathered[k].data_ptr(), 4, frame.data_ptr())
+            if rank == 0:                    # present the assembled frame: every rank's shard back into place in ONE launch (fh_unpack_shards, the inverse of the packs)
+                r.unpack_shards([g.data_ptr() for g in gathered], 4, frame.data_ptr())
                 presented = frame
         if post and rank == 0:               # the post chain runs on the assembled frame (bloom has a 16-pixel halo), on the library's stream
             r.post_process(presented.data_ptr(), pp_bufs[0].data_ptr(), pp_bufs[1].data_ptr(), WIDTH, HEIGHT, post, pp_bufs[2].data_ptr())
@@ -748,7 +832,7 @@ def main():
             roof["from_root"] = {"nodes_per_ray": round(cnt_root[f"nodes_{ck_}"] / max(cnt_root[f"rays_{ck_}"], 1), 2), "triangles_per_ray": round(cnt_root[f"tris_{ck_}"] / max(cnt_root[f"rays_{ck_}"], 1), 2),
                                  "wave_node_tests_per_launch": int(wn0 * steps / launches), "wave_tri_tests_per_launch": int(wt0 * steps / launches),
                                  "share_of_those_tests_done": round((cnt[f"wave_node_steps_{key_}"] * im_["node"] + cnt[f"wave_tri_steps_{key_}"] * im_["tri"]) / max(wn0 * im_["node"] + wt0 * im_["tri"], 1.0), 4),
-                                 "frac_priced_with_these_tests": round(min(cyc0 / (avg_ms * 1e-3) / 1e9 / (N_SIMDS * NOMINAL_CLOCK_GHZ), 1.0), 5) if avg_ms > 0 else None,
+                                 "frac_priced_with_these_tests": round(cyc0 / (avg_ms * 1e-3) / 1e9 / (N_SIMDS * NOMINAL_CLOCK_GHZ), 5) if avg_ms > 0 else None,
                                  "note": "the counting replay with every ray started at the root (FH_FLAG_ROOT_START): the tests a walk from the root needs for the same hits; frac counts the tests done, "
                                          "so it falls when tests are avoided -- frac_priced_with_these_tests is this run's launch time priced with the root-start test counts"}
         if pmc_k and avg_alone_ms > 0:  # the counters are collected with the kernels serialised, so they are priced against the kernel's time alone
@@ -782,6 +866,8 @@ def main():
             roof["counters_built_from"] = {"git_head": pmc_k.get("git_head"), "source_fingerprint": then["source_fingerprint"], "this_run": now["source_fingerprint"]}
         if unusable:
             roof["counters_unusable"] = unusable
+        freeze_roofline_fields(roof)
+        shade = shade_record(r, args.config, spp, timed, alone, cnt, steps) if world == 1 else None
         sec = lambda k: fam[k]["alone"] * 1e-3  # seconds per step with the kernel alone on the GPU
         rates = {"closest_hit_grays_per_s": round(cnt["rays_closest"] / sec("k_trace_closest_stream") / 1e9, 3) if sec("k_trace_closest_stream") > 0 else None,
                  "secondary_grays_per_s": round(cnt["rays_shadow"] / sec("k_trace_secondary_stream") / 1e9, 3) if sec("k_trace_secondary_stream") > 0 else None,
@@ -811,7 +897,7 @@ def main():
                        "post": "bloom + chromatic aberration + tone map on the whole frame, inside the timed region" if post else "none"},
             "step_ms": {"min": round(sm[0], 3), "median": round(sm[len(sm) // 2], 3), "max": round(sm[-1], 3)},
             "source_fingerprint": source_fingerprint(),  # of the device sources this library was built from (what profiles/*_traffic_config*.json are checked against)
-            "roofline": roof, "rates": rates, "whole_frame": whole,
+            "roofline": roof, **({"shade": shade} if shade else {}), "rates": rates, "whole_frame": whole,
             "kernel_ms_per_step": {"trace_closest": round(timed["trace_closest_ms"] / steps, 3), "trace_secondary": round(timed["trace_shadow_ms"] / steps, 3), "shade": round(timed["shade_ms"] / steps, 3),
                                    "tail": round(timed["tail_ms"] / steps, 3), "generate": round(timed["generate_ms"] / steps, 3), "accumulate": round(timed["accumulate_ms"] / steps, 3),
                                    "route_and_sort": round(timed["queue_ms"] / steps, 3), "render_total": round(timed["render_ms"] / steps, 3),
@@ -845,16 +931,18 @@ def main():
         if refused:
             out["fractions_refused"] = [{"field": k, "value": v} for k, v in refused]
             print("bench.py: refused to print fractions outside [0, 1]: " + ", ".join(f"{k} = {v}" for k, v in refused), file=sys.stderr, flush=True)
-            if "frac" not in out["roofline"]:  # the contract's field: the SURVEY 8(d) view of the same kernel stands in, named as such
-                out["roofline"]["frac"] = min(out["roofline"].get("algorithmic_gbs_over_hbm_peak") or 0.0, 1.0)
-                out["roofline"]["frac_is"] = "algorithmic_gbs_over_hbm_peak (the modelled fraction was refused)"
+            out["failed"] = "a fraction of a roof outside [0, 1]: the line is printed for the record, the run exits with code 3"
         print(json.dumps(out), flush=True)
+        if refused:
+            failed_rc = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if r is not None:
         r.close()
     tmp.cleanup()
+    if failed_rc:
+        sys.exit(failed_rc)
 
 
 if __name__ == "__main__":

@@ -53,7 +53,7 @@ __global__ void k_face_bounds(const float4* face_rec, uint32_t n, float4* lo, fl
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   float l[3] = {3e38f, 3e38f, 3e38f}, h[3] = {-3e38f, -3e38f, -3e38f};
   if (f < n) {
-    const float4 a = face_rec[7 * f], b = face_rec[7 * f + 1], c = face_rec[7 * f + 2];
+    const float4 a = face_rec[kFaceRec * (size_t)f], b = face_rec[kFaceRec * (size_t)f + 1], c = face_rec[kFaceRec * (size_t)f + 2];
     l[0] = fminf(a.x, fminf(b.x, c.x)); l[1] = fminf(a.y, fminf(b.y, c.y)); l[2] = fminf(a.z, fminf(b.z, c.z));
     h[0] = fmaxf(a.x, fmaxf(b.x, c.x)); h[1] = fmaxf(a.y, fmaxf(b.y, c.y)); h[2] = fmaxf(a.z, fmaxf(b.z, c.z));
     lo[f] = make_float4(l[0], l[1], l[2], 0.0f);
@@ -159,7 +159,7 @@ __global__ void k_split_count(const float4* face_rec, const float4* face_lo, con
   const SplitGrid g = split_grid(lo, hi, thr);
   uint32_t c = 1;
   if (g.ka * g.kb > 1) {
-    const float4 v0 = face_rec[7 * (size_t)f], v1 = face_rec[7 * (size_t)f + 1], v2 = face_rec[7 * (size_t)f + 2];
+    const float4 v0 = face_rec[kFaceRec * (size_t)f], v1 = face_rec[kFaceRec * (size_t)f + 1], v2 = face_rec[kFaceRec * (size_t)f + 2];
     c = 0;
     float4 a, b;
     for (int i = 0; i < g.ka; ++i)
@@ -180,7 +180,7 @@ __global__ void k_split_emit(const float4* face_rec, const float4* face_lo, cons
   uint32_t o = offset[f];
   const SplitGrid g = split_grid(lo, hi, thr);
   if (g.ka * g.kb > 1 && count[f] > 0) {
-    const float4 v0 = face_rec[7 * (size_t)f], v1 = face_rec[7 * (size_t)f + 1], v2 = face_rec[7 * (size_t)f + 2];
+    const float4 v0 = face_rec[kFaceRec * (size_t)f], v1 = face_rec[kFaceRec * (size_t)f + 1], v2 = face_rec[kFaceRec * (size_t)f + 2];
     uint32_t written = 0;
     float4 a, b;
     for (int i = 0; i < g.ka; ++i)
@@ -345,7 +345,7 @@ __global__ void k_emit_tris(const float4* face_rec, const uint8_t* face_cls, con
     tris[3 * i + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     return;
   }
-  const float4 a = face_rec[7 * f], b = face_rec[7 * f + 1], c = face_rec[7 * f + 2];
+  const float4 a = face_rec[kFaceRec * (size_t)f], b = face_rec[kFaceRec * (size_t)f + 1], c = face_rec[kFaceRec * (size_t)f + 2];
   tris[3 * i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
   tris[3 * i + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);  // .w != 0: candidate hits need the alpha test
   tris[3 * i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
@@ -652,7 +652,7 @@ __global__ void k_emit_tris8(const float4* face_rec, const uint8_t* face_cls, co
   if (face_node) face_node[f] = (split_count && split_count[f] > 1u) ? 0u : tri_slot[i] >> 3;  // the wide node that holds the face; a face that entered the build as several references: the root
   const size_t t = 3 * (size_t)tri_slot[i];
   if (face_cls[f] & 0x20u) return;  // never hit (above): the slot keeps the degenerate triangle k_clear_tris8 put there
-  const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
+  const float4 a = face_rec[kFaceRec * (size_t)f], b = face_rec[kFaceRec * (size_t)f + 1], c = face_rec[kFaceRec * (size_t)f + 2];
   tris[t] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
   tris[t + 1] = make_float4(b.x, b.y, b.z, (face_cls[f] & 0x40u) ? 1.0f : 0.0f);
   tris[t + 2] = make_float4(c.x, c.y, c.z, 0.0f);
@@ -749,7 +749,7 @@ __global__ void k_face_node_to_rec(const uint32_t* face_node, uint32_t n, float4
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n) return;
   const uint32_t node = face_node[f];
-  face_rec[7 * (size_t)f + 6].z = __uint_as_float(node == 0xffffffffu ? 0u : node + 1u);
+  face_rec[kFaceRec * (size_t)f + 6].z = __uint_as_float(node == 0xffffffffu ? 0u : node + 1u);
 }
 
 // surface-area-heuristic cost of a binary tree: sum over inner nodes of area(node) (the leaves are the same triangles in both builders)
@@ -967,7 +967,7 @@ __global__ void k_refresh_tris8(const float4* face_rec, uint32_t n_slots, float4
   if (i >= n_slots) return;
   const uint32_t f = __float_as_uint(tris[3 * (size_t)i].w);
   if (f == 0xffffffffu) return;  // a slot without a triangle
-  const float4 a = face_rec[7 * (size_t)f], b = face_rec[7 * (size_t)f + 1], c = face_rec[7 * (size_t)f + 2];
+  const float4 a = face_rec[kFaceRec * (size_t)f], b = face_rec[kFaceRec * (size_t)f + 1], c = face_rec[kFaceRec * (size_t)f + 2];
   tris[3 * (size_t)i] = make_float4(a.x, a.y, a.z, __uint_as_float(f));
   tris[3 * (size_t)i + 1].x = b.x; tris[3 * (size_t)i + 1].y = b.y; tris[3 * (size_t)i + 1].z = b.z;  // .w keeps the alpha flag
   tris[3 * (size_t)i + 2] = make_float4(c.x, c.y, c.z, 0.0f);

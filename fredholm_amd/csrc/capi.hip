@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_face_records(uint32_t nf, const float* 
     uv[k][0] = texcoords[2 * v];
     uv[k][1] = texcoords[2 * v + 1];
   }
-  float4* r = rec + 7 * (size_t)f;
+  float4* r = rec + kFaceRec * (size_t)f;
   r[0] = mk4(p[0], uv[0][0]); r[1] = mk4(p[1], uv[0][1]); r[2] = mk4(p[2], uv[1][0]);
   r[3] = mk4(n[0], uv[1][1]); r[4] = mk4(n[1], uv[2][0]); r[5] = mk4(n[2], uv[2][1]);
   r[6] = make_float4(__uint_as_float(mi.x), __uint_as_float(mi.y), 0.0f, 0.0f);
@@ -250,7 +250,7 @@ int rebuild_device_scene(fh_ctx* ctx)
     if (ptr) { (void)hipFree(ptr); ptr = nullptr; }
     return hipMalloc((void**)&ptr, bytes ? bytes : 16);
   };
-  FH_HIP(re_alloc(ctx->d_face_rec, 7ull * nf * sizeof(float4)));
+  FH_HIP(re_alloc(ctx->d_face_rec, (unsigned long long)kFaceRec * nf * sizeof(float4)));
   FH_HIP(re_alloc(ctx->d_face_cls, cls.size()));
   FH_HIP(re_alloc(ctx->d_materials, mats.size() * sizeof(MaterialDev)));
   FH_HIP(re_alloc(ctx->d_lights, lights.size() * sizeof(AreaLightDev)));
@@ -393,6 +393,24 @@ int upload_textures(fh_ctx* ctx, uint32_t n, const fh_texture_desc* descs)
   return FH_OK;
 }
 
+// the pixels of rank `rank` of `world` in the order the library packs them: tiles t with t % world == rank, row-major tile order; inside a tile 8 x 8 blocks, row-major,
+// and row-major inside a block -- so the 64 lanes of a wave of k_generate (64 consecutive list entries) hold a compact 8 x 8 patch of the image instead of two rows of 32:
+// their camera rays share more nodes and their first hits more faces (r6-4: closest-hit -2 %, configs[2] / [3] +0.9 %; 4 x 4 blocks measure the same).  FH_PIXEL_BLOCK=0:
+// rows of the whole tile, as before round 6.  fredholm_amd/distributed.py: tile_ownership is the same list; tests/test_gpu_parity.py compares the two.
+constexpr uint32_t kPixelBlock = 8;
+static void owned_list(uint32_t width, uint32_t height, uint32_t tw, uint32_t th, uint32_t rank, uint32_t world, std::vector<uint32_t>& owned, std::vector<uint32_t>* owned_xy)
+{
+  static const uint32_t blk = [] { const char* e = getenv("FH_PIXEL_BLOCK"); const int v = e ? atoi(e) : (int)kPixelBlock; return (uint32_t)(v > 0 && v <= 64 ? v : 65536); }();
+  const uint32_t tx = (width + tw - 1) / tw, ty = (height + th - 1) / th;
+  for (uint32_t t = rank; t < tx * ty; t += world) {
+    const uint32_t x0 = (t % tx) * tw, y0 = (t / tx) * th;
+    for (uint32_t by = y0; by < y0 + th && by < height; by += (blk < th ? blk : th))
+      for (uint32_t bx = x0; bx < x0 + tw && bx < width; bx += (blk < tw ? blk : tw))
+        for (uint32_t y = by; y < by + blk && y < y0 + th && y < height; ++y)
+          for (uint32_t x = bx; x < bx + blk && x < x0 + tw && x < width; ++x) { owned.push_back(x + width * y); if (owned_xy) owned_xy->push_back(x | (y << 16)); }
+  }
+}
+
 int rebuild_ownership(fh_ctx* ctx)
 {
   if (ctx->d_owned) { (void)hipFree(ctx->d_owned); ctx->d_owned = nullptr; }
@@ -401,14 +419,7 @@ int rebuild_ownership(fh_ctx* ctx)
   if (ctx->width == 0 || ctx->height == 0) return FH_OK;
   if (ctx->width > 65535u || ctx->height > 65535u) return fail(ctx, FH_E_UNSUPPORTED, "frames wider or higher than 65535 pixels are not supported");
   std::vector<uint32_t> owned, owned_xy;
-  const uint32_t tw = ctx->tile_w, th = ctx->tile_h;
-  const uint32_t tx = (ctx->width + tw - 1) / tw, ty = (ctx->height + th - 1) / th;
-  for (uint32_t t = 0; t < tx * ty; ++t) {
-    if (t % ctx->shard_world != ctx->shard_rank) continue;
-    const uint32_t x0 = (t % tx) * tw, y0 = (t / tx) * th;
-    for (uint32_t y = y0; y < y0 + th && y < ctx->height; ++y)
-      for (uint32_t x = x0; x < x0 + tw && x < ctx->width; ++x) { owned.push_back(x + ctx->width * y); owned_xy.push_back(x | (y << 16)); }
-  }
+  owned_list(ctx->width, ctx->height, ctx->tile_w, ctx->tile_h, ctx->shard_rank, ctx->shard_world, owned, &owned_xy);
   ctx->n_owned = (uint32_t)owned.size();
   FH_HIP(hipMalloc((void**)&ctx->d_owned, owned.empty() ? 16 : owned.size() * 4));
   FH_HIP(hipMalloc((void**)&ctx->d_owned_xy, owned.empty() ? 16 : owned.size() * 4));
@@ -424,6 +435,18 @@ __global__ void k_pack(const float* layer, const uint32_t* owned, uint32_t n, ui
 __global__ void k_unpack(const float* packed, const uint32_t* owned, uint32_t n, uint32_t fpp, float* layer)
 {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n * fpp; i += gridDim.x * blockDim.x) layer[(size_t)owned[i / fpp] * fpp + i % fpp] = packed[i];
+}
+// every rank's shard in ONE launch (fh_unpack_shards): `all_owned` is the ownership lists of ranks 0 .. world - 1 one after the other (a permutation of the frame's pixels),
+// start[r] where rank r's list begins in it, packed[r] that rank's packed shard
+struct ShardSources { const float* packed[kMaxShardsPerLaunch]; uint32_t start[kMaxShardsPerLaunch + 1]; uint32_t world; };
+__global__ void k_unpack_all(ShardSources src, const uint32_t* all_owned, uint32_t n, uint32_t fpp, float* layer)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n * fpp; i += gridDim.x * blockDim.x) {
+    const uint32_t j = i / fpp, c = i % fpp;
+    uint32_t r = 0;
+    while (r + 1u < src.world && j >= src.start[r + 1u]) ++r;
+    layer[(size_t)all_owned[j] * fpp + c] = src.packed[r][(size_t)(j - src.start[r]) * fpp + c];
+  }
 }
 
 }  // namespace
@@ -582,6 +605,7 @@ int fh_ctx_destroy(fh_ctx* ctx)
     if (p) (void)hipFree(p);
   for (fh_ctx::ShardList& c : ctx->shard_lists)
     if (c.d_owned) (void)hipFree(c.d_owned);
+  if (ctx->frame_map.d_all) (void)hipFree(ctx->frame_map.d_all);
   for (int k = 0; k < 4; ++k) if (ctx->d_split[k]) (void)hipFree(ctx->d_split[k]);
   if (ctx->d_split_counters) (void)hipFree(ctx->d_split_counters);
   if (ctx->sky_stream) { (void)hipStreamSynchronize(ctx->sky_stream); (void)hipStreamDestroy(ctx->sky_stream); }
@@ -908,6 +932,40 @@ int fh_unpack_shard(fh_ctx* ctx, uint32_t rank, uint32_t world, const float* pac
   return FH_OK;
 }
 
+int fh_unpack_shards(fh_ctx* ctx, uint32_t world, const float* const* packed, uint32_t fpp, float* layer)
+{
+  CTX_CHECK(ctx);
+  if (!layer || !packed || fpp == 0 || world == 0) return FH_E_INVALID;
+  for (uint32_t r = 0; r < world; ++r)
+    if (!packed[r]) return fail(ctx, FH_E_INVALID, "fh_unpack_shards: null shard pointer");
+  if (world > kMaxShardsPerLaunch) {  // (more ranks than one launch's argument block holds: one launch per rank)
+    for (uint32_t r = 0; r < world; ++r) { const int rc = fh_unpack_shard(ctx, r, world, packed[r], fpp, layer); if (rc) return rc; }
+    return FH_OK;
+  }
+  if (ctx->width > 65535u || ctx->height > 65535u) return fail(ctx, FH_E_UNSUPPORTED, "frames wider or higher than 65535 pixels are not supported");
+  // the ownership lists of all `world` ranks, one after the other: built once per (world, resolution, tile size) and kept, so a presented frame is ONE asynchronous launch
+  fh_ctx::FrameMap& fm = ctx->frame_map;
+  if (!(fm.d_all && fm.world == world && fm.width == ctx->width && fm.height == ctx->height && fm.tile_w == ctx->tile_w && fm.tile_h == ctx->tile_h)) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (fm.d_all) (void)hipFree(fm.d_all);
+    fm = fh_ctx::FrameMap{};
+    std::vector<uint32_t> all;
+    fm.start.assign(world + 1u, 0u);
+    for (uint32_t r = 0; r < world; ++r) { owned_list(ctx->width, ctx->height, ctx->tile_w, ctx->tile_h, r, world, all, nullptr); fm.start[r + 1u] = (uint32_t)all.size(); }
+    FH_HIP(hipMalloc((void**)&fm.d_all, all.empty() ? 16 : all.size() * 4));
+    if (!all.empty()) FH_HIP(hipMemcpy(fm.d_all, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    fm.world = world; fm.width = ctx->width; fm.height = ctx->height; fm.tile_w = ctx->tile_w; fm.tile_h = ctx->tile_h;
+  }
+  ShardSources src{};
+  src.world = world;
+  for (uint32_t r = 0; r < world; ++r) { src.packed[r] = packed[r]; src.start[r] = fm.start[r]; }
+  src.start[world] = fm.start[world];
+  const uint32_t n = fm.start[world];
+  if (n) hipLaunchKernelGGL(k_unpack_all, dim3((uint32_t)(((size_t)n * fpp + 255) / 256)), dim3(256), 0, ctx->stream, src, fm.d_all, n, fpp, layer);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
 int fh_render(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_render_layers* layers, uint32_t n_samples, uint32_t max_depth, uint32_t seed)
 {
   CTX_CHECK(ctx);
@@ -977,7 +1035,7 @@ int fh_get_stats(fh_ctx* ctx, fh_stats* out)
 int fh_kernel_info(fh_ctx* ctx, int which, uint32_t out[6])
 {
   CTX_CHECK(ctx);
-  if (!out || which < 0 || which > 1) return fail(ctx, FH_E_INVALID, "fh_kernel_info: which must be 0 (closest hit) or 1 (secondary rays)");
+  if (!out || which < 0 || which > 1 + (int)kMaxClasses) return fail(ctx, FH_E_INVALID, "fh_kernel_info: which must be 0 (closest hit), 1 (secondary rays) or 2 + a shading class of the scene");
   return kernel_info(ctx, which, out);
 }
 // test hook (fredholm_hip_test.h): where the scene's first-hit rays start, and what the probing passes have counted so far

@@ -113,6 +113,9 @@ struct fh_ctx {
   hipStream_t sky_stream = nullptr;
   hipEvent_t ev_sky = nullptr;
   struct ShardList { uint32_t rank, world, width, height, tile_w, tile_h; uint32_t* d_owned; uint32_t n_owned; };
+  // fh_unpack_shards: the ownership lists of all ranks of a split one after the other (a permutation of the frame) and where each rank's begins
+  struct FrameMap { uint32_t world = 0, width = 0, height = 0, tile_w = 0, tile_h = 0; uint32_t* d_all = nullptr; std::vector<uint32_t> start; };
+  FrameMap frame_map;
   std::vector<ShardList> shard_lists;  // ownership lists of other ranks' shards, built on first use by fh_unpack_shard and kept (freed with the context)
 
   // environment (renderer.h:819-827)

@@ -15,6 +15,10 @@
 
 namespace fh {
 
+// float4s per face record: positions, normals, texture coordinates in the .w lanes, material, start node.  (Padding a record to one 128-byte line -- 8 -- and handing k_shade
+// the face id with its queue entry, so that it need not wait for the hit record, were both measured in round 6 and buy nothing: tools/patches/r6_face_rec_128_and_cls_prim.patch)
+constexpr uint32_t kFaceRec = 7;
+constexpr uint32_t kMaxShardsPerLaunch = 16;  // fh_unpack_shards: ranks whose packed shards one launch un-permutes (a node has 8)
 constexpr uint32_t kMaxClasses = 8;       // shading classes (distinct lobe masks) per scene
 constexpr uint32_t kNumQueues = kMaxClasses;
 
@@ -51,7 +55,7 @@ struct Bvh8Dev {
 };
 
 struct SceneDev {
-  const float4* face_rec;       // 7 per face
+  const float4* face_rec;       // kFaceRec per face
   const uint8_t* face_cls;      // shading class of the face's material | 0x80 if emissive
   const MaterialDev* materials;
   const AreaLightDev* lights;

@@ -773,9 +773,9 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows<4>& 
   const uint32_t sidx = image_idx + n_spp * fr.width * fr.height;
 
   // surface (pt.cu:141-179) from the pre-transformed face record
-  const float4 r0 = sc.face_rec[7 * (size_t)prim], r1 = sc.face_rec[7 * (size_t)prim + 1], r2 = sc.face_rec[7 * (size_t)prim + 2];
-  const float4 r3 = sc.face_rec[7 * (size_t)prim + 3], r4 = sc.face_rec[7 * (size_t)prim + 4], r5 = sc.face_rec[7 * (size_t)prim + 5];
-  const float4 r6 = sc.face_rec[7 * (size_t)prim + 6];
+  const float4 r0 = sc.face_rec[kFaceRec * (size_t)prim], r1 = sc.face_rec[kFaceRec * (size_t)prim + 1], r2 = sc.face_rec[kFaceRec * (size_t)prim + 2];
+  const float4 r3 = sc.face_rec[kFaceRec * (size_t)prim + 3], r4 = sc.face_rec[kFaceRec * (size_t)prim + 4], r5 = sc.face_rec[kFaceRec * (size_t)prim + 5];
+  const float4 r6 = sc.face_rec[kFaceRec * (size_t)prim + 6];
   // (.z of the record's last vector: 1 + the wide node that holds the face, written by the BVH build -- where this bounce's first-hit rays start their traversal, fh_trace.h)
   out.start_node(sc.face_node ? __float_as_uint(r6.z) : 0u);
   const f3 p0 = mk3(r0), p1 = mk3(r1), p2 = mk3(r2);
@@ -854,8 +854,8 @@ FH_D void shade_hit(const SceneDev& sc, const FrameDev& fr, const SobolRows<4>& 
     li = li < sc.n_lights - 1u ? li : sc.n_lights - 1u;
     const AreaLightDev lt = sc.lights[li];
     const f2 bc = triangle_barycentric(u2);
-    const float4 l0 = sc.face_rec[7 * (size_t)lt.face], l1 = sc.face_rec[7 * (size_t)lt.face + 1], l2 = sc.face_rec[7 * (size_t)lt.face + 2];
-    const float4 l3 = sc.face_rec[7 * (size_t)lt.face + 3], l4 = sc.face_rec[7 * (size_t)lt.face + 4], l5 = sc.face_rec[7 * (size_t)lt.face + 5];
+    const float4 l0 = sc.face_rec[kFaceRec * (size_t)lt.face], l1 = sc.face_rec[kFaceRec * (size_t)lt.face + 1], l2 = sc.face_rec[kFaceRec * (size_t)lt.face + 2];
+    const float4 l3 = sc.face_rec[kFaceRec * (size_t)lt.face + 3], l4 = sc.face_rec[kFaceRec * (size_t)lt.face + 4], l5 = sc.face_rec[kFaceRec * (size_t)lt.face + 5];
     const float lw = 1.0f - bc.x - bc.y;
     const f3 lp = lw * mk3(l0) + bc.x * mk3(l1) + bc.y * mk3(l2);
     const f3 ln = lw * mk3(l3) + bc.x * mk3(l4) + bc.y * mk3(l5);
@@ -1073,7 +1073,7 @@ FH_D f3 resolve_light_ray(const SceneDev& sc, const FrameDev& fr, f3 T, float co
   bool add = false;
   if (hit) {
     if (sc.face_cls[h.prim] & 0x80u) {
-      const size_t fb = 7 * (size_t)h.prim;
+      const size_t fb = kFaceRec * (size_t)h.prim;
       const float4 l0 = sc.face_rec[fb], l1 = sc.face_rec[fb + 1], l2 = sc.face_rec[fb + 2], l3 = sc.face_rec[fb + 3], l4 = sc.face_rec[fb + 4], l5 = sc.face_rec[fb + 5];
       const float lw = 1.0f - h.u - h.v;
       const f3 lp = lw * mk3(l0) + h.u * mk3(l1) + h.v * mk3(l2);
@@ -1652,6 +1652,27 @@ void dispatch_shade(hipStream_t st, uint32_t grid, uint32_t lobes, const SceneDe
   return launch_shade<L_ALL>(st, grid, sc, fr, pool, cls, depth, three);
 }
 
+// registers / LDS / scratch / resident workgroups per CU of the shade kernel a class of `lobes` is shaded by (fh_kernel_info, which >= 2): the same choice as dispatch_shade
+template <uint32_t LOBES>
+hipError_t shade_attributes_of(bool three, hipFuncAttributes& at, int& blocks)
+{
+  const void* fn = (three && LOBES != L_ALL) ? (const void*)k_shade<LOBES, (LOBES == L_ALL ? FH_SHADE_BLOCKS : 3)> : (const void*)k_shade<LOBES>;
+  const hipError_t e = hipFuncGetAttributes(&at, fn);
+  if (e != hipSuccess) return e;
+  if (three && LOBES != L_ALL) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_shade<LOBES, (LOBES == L_ALL ? FH_SHADE_BLOCKS : 3)>, kBlock, 0);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_shade<LOBES>, kBlock, 0);
+}
+hipError_t shade_attributes(uint32_t lobes, bool three, hipFuncAttributes& at, int& blocks, uint32_t& compiled_lobes)
+{
+  if ((lobes & ~(uint32_t)L_DIFF) == 0) { compiled_lobes = L_DIFF; return shade_attributes_of<L_DIFF>(three, at, blocks); }
+  if ((lobes & ~(uint32_t)L_METAL) == 0) { compiled_lobes = L_METAL; return shade_attributes_of<L_METAL>(three, at, blocks); }
+  if ((lobes & ~(uint32_t)(L_SPEC | L_DIFF)) == 0) { compiled_lobes = L_SPEC | L_DIFF; return shade_attributes_of<L_SPEC | L_DIFF>(three, at, blocks); }
+  if ((lobes & ~(uint32_t)(L_METAL | L_SPEC | L_DIFF)) == 0) { compiled_lobes = L_METAL | L_SPEC | L_DIFF; return shade_attributes_of<L_METAL | L_SPEC | L_DIFF>(three, at, blocks); }
+  if ((lobes & ~(uint32_t)(L_COAT | L_METAL | L_SPEC | L_DIFF)) == 0) { compiled_lobes = L_COAT | L_METAL | L_SPEC | L_DIFF; return shade_attributes_of<L_COAT | L_METAL | L_SPEC | L_DIFF>(three, at, blocks); }
+  compiled_lobes = L_ALL;
+  return shade_attributes_of<L_ALL>(three, at, blocks);
+}
+
 hipEvent_t take_event(fh_ctx* ctx)
 {
   if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
@@ -1712,6 +1733,18 @@ SceneDev scene_dev(const fh_ctx* ctx)
 int kernel_info(fh_ctx* ctx, int which, uint32_t out[6])
 {
   for (int k = 0; k < 6; ++k) out[k] = 0u;
+  if (which >= 2) {  // the shade kernel of shading class which - 2 of the scene: out[3] = resident workgroups per CU (x 4 waves / 4 SIMDs = waves per SIMD), out[4] = its lobe mask as compiled
+    const uint32_t c = (uint32_t)(which - 2);
+    if (c >= ctx->n_classes) return fail(ctx, FH_E_INVALID, "fh_kernel_info: the scene has no such shading class");
+    hipFuncAttributes sa{};
+    int blocks = 0;
+    uint32_t compiled = 0;
+    const bool three = ctx->tun.shade_wgs ? ctx->tun.shade_wgs == 3u : true;
+    const hipError_t se = shade_attributes(ctx->class_lobes[c], three, sa, blocks, compiled);
+    if (se != hipSuccess) return fail(ctx, FH_E_HIP, std::string("hipFuncGetAttributes: ") + hipGetErrorString(se));
+    out[0] = (uint32_t)sa.numRegs; out[1] = (uint32_t)sa.sharedSizeBytes; out[2] = (uint32_t)sa.localSizeBytes; out[3] = (uint32_t)(blocks > 0 ? blocks : 0); out[4] = compiled; out[5] = ctx->class_lobes[c];
+    return FH_OK;
+  }
   const bool alpha = (ctx->has_alpha && !ctx->tun.ignore_alpha) || ctx->tun.force_alpha;
   hipFuncAttributes at{};
   hipError_t e = hipSuccess;

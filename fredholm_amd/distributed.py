@@ -10,19 +10,26 @@ frame (RCCL all_gather over xGMI; `gloo` in the CPU tests).
 import numpy as np
 
 
-def tile_ownership(width, height, rank, world, tile_w=32, tile_h=32):
-    """Image indices (x + width*y) owned by `rank`, in the order the library packs them.
+PIXEL_BLOCK = 8  # capi.hip: kPixelBlock
 
-    Must stay identical to rebuild_ownership() in fredholm_amd/csrc/capi.hip (checked on the GPU
-    by tests/test_gpu_parity.py::test_tile_ownership_matches_library)."""
+
+def tile_ownership(width, height, rank, world, tile_w=32, tile_h=32, block=PIXEL_BLOCK):
+    """Image indices (x + width*y) owned by `rank`, in the order the library packs them: tiles t % world == rank in row-major tile order; inside a tile
+    `block` x `block` pixel blocks, row-major, and row-major inside a block (a wave of the camera-ray kernel then holds a compact patch of the image).
+
+    Must stay identical to owned_list() in fredholm_amd/csrc/capi.hip (checked on the GPU
+    by tests/test_gpu_parity.py::test_tile_ownership_matches_library_and_shards_reassemble)."""
     tx = (width + tile_w - 1) // tile_w
     ty = (height + tile_h - 1) // tile_h
     out = []
     for t in range(rank, tx * ty, world):
         x0, y0 = (t % tx) * tile_w, (t // tx) * tile_h
-        xs = np.arange(x0, min(x0 + tile_w, width), dtype=np.uint32)
-        ys = np.arange(y0, min(y0 + tile_h, height), dtype=np.uint32)
-        out.append((xs[None, :] + np.uint32(width) * ys[:, None]).reshape(-1))
+        x1, y1 = min(x0 + tile_w, width), min(y0 + tile_h, height)
+        for by in range(y0, y1, min(block, tile_h)):
+            for bx in range(x0, x1, min(block, tile_w)):
+                xs = np.arange(bx, min(bx + block, x1), dtype=np.uint32)
+                ys = np.arange(by, min(by + block, y1), dtype=np.uint32)
+                out.append((xs[None, :] + np.uint32(width) * ys[:, None]).reshape(-1))
     return np.concatenate(out) if out else np.zeros(0, dtype=np.uint32)
 
 

@@ -104,7 +104,7 @@ EXPORTS = [
     "fh_ctx_create", "fh_ctx_destroy", "fh_last_error", "fh_set_flags", "fh_get_flags", "fh_set_path_pool", "fh_path_pool_bytes", "fh_path_pool_allocated", "fh_alpha_face_counts", "fh_alpha_cell_counts", "fh_set_tail_depth", "fh_scene_upload", "fh_bvh_build", "fh_set_transforms",
     "fh_scene_n_lights", "fh_set_directional_light", "fh_clear_directional_light", "fh_set_sky_intensity", "fh_load_arhosek_sky",
     "fh_clear_arhosek_sky", "fh_load_ibl", "fh_clear_ibl", "fh_set_resolution", "fh_init_render_states", "fh_set_tile_shard", "fh_owned_pixel_count",
-    "fh_pack_owned", "fh_unpack_shard", "fh_render", "fh_sync", "fh_get_stats", "fh_reset_stats", "fh_post_process", "fh_denoise", "fh_gl_register_buffer", "fh_gl_unregister_buffer", "fh_malloc",
+    "fh_pack_owned", "fh_unpack_shard", "fh_unpack_shards", "fh_render", "fh_sync", "fh_get_stats", "fh_reset_stats", "fh_post_process", "fh_denoise", "fh_gl_register_buffer", "fh_gl_unregister_buffer", "fh_malloc",
     "fh_free", "fh_memset", "fh_copy_to_device", "fh_copy_to_host", "fh_copy_on_device", "fh_image_load_rgba8", "fh_image_free", "fh_stream", "fh_trace_rays", "fh_kernel_info", "fh_kat_hash", "fh_kat_cmj",
     "fh_kat_sobol", "fh_kat_elementary", "fh_kat_warp", "fh_kat_bsdf", "fh_kat_bsdf_ior", "fh_kat_sky", "fh_kat_hosek_state", "fh_kat_camera",
     "fh_kat_offset_origin", "fh_kat_math", "fh_kat_sqrt", "fh_kat_tex2d", "fh_kat_face_classes", "fh_kat_alpha_records", "fh_kat_ray_start", "fh_measure_bandwidth",

@@ -342,6 +342,11 @@ class Renderer:
     def unpack_shard(self, rank, world, packed_ptr, floats_per_pixel, layer_ptr):
         self._ck(N.lib().fh_unpack_shard(self._ctx, C.c_uint32(rank), C.c_uint32(world), C.c_void_p(packed_ptr), C.c_uint32(floats_per_pixel), C.c_void_p(layer_ptr)), "fh_unpack_shard")
 
+    def unpack_shards(self, packed_ptrs, floats_per_pixel, layer_ptr):
+        """fh_unpack_shards: every rank's packed shard (device pointers, rank order) into the frame in ONE launch"""
+        arr = (C.c_void_p * len(packed_ptrs))(*[C.c_void_p(int(p)) for p in packed_ptrs])
+        self._ck(N.lib().fh_unpack_shards(self._ctx, C.c_uint32(len(packed_ptrs)), arr, C.c_uint32(floats_per_pixel), C.c_void_p(layer_ptr)), "fh_unpack_shards")
+
     # -- the hot path (renderer.h:657-736)
     def set_time(self, time):
         """renderer.h:614-640: advance the animation, re-upload the instance transforms, rebuild the acceleration structure"""
@@ -376,6 +381,16 @@ class Renderer:
         self._ck(N.lib().fh_kernel_info(self._ctx, int(which), out), "fh_kernel_info")
         return {"vgprs": int(out[0]), "static_lds_bytes": int(out[1]), "scratch_bytes": int(out[2]), "workgroups_per_cu": int(out[3]), "stack_levels_in_lds": int(out[4]),
                 "stack_levels": int(out[5])}
+
+    def shade_kernel_info(self):
+        """fh_kernel_info(2 + c) for every shading class c of the scene: registers, LDS, scratch, waves per SIMD of the shade kernel each class runs"""
+        out = []
+        for c in range(8):
+            o = (C.c_uint32 * 6)()
+            if N.lib().fh_kernel_info(self._ctx, 2 + c, o) != 0:
+                break
+            out.append({"class": c, "lobes": int(o[5]), "compiled_for_lobes": int(o[4]), "vgprs": int(o[0]), "static_lds_bytes": int(o[1]), "scratch_bytes": int(o[2]), "waves_per_simd": int(o[3])})
+        return out
 
     def reset_stats(self):
         self._ck(N.lib().fh_reset_stats(self._ctx), "fh_reset_stats")

@@ -195,6 +195,9 @@ int fh_set_tile_shard(fh_ctx* ctx, uint32_t rank, uint32_t world, uint32_t tile_
 int fh_owned_pixel_count(fh_ctx* ctx, uint32_t* out);
 int fh_pack_owned(fh_ctx* ctx, const float* layer, uint32_t floats_per_pixel, float* packed);
 int fh_unpack_shard(fh_ctx* ctx, uint32_t rank, uint32_t world, const float* packed, uint32_t floats_per_pixel, float* layer);
+/* the same for ALL ranks of a split in one asynchronous launch: packed[r] = rank r's packed shard (device pointers in a host array of `world` entries, read during the call).
+ * What rank 0 calls once per presented frame after the gather (bench.py); world > 16 falls back to one launch per rank. */
+int fh_unpack_shards(fh_ctx* ctx, uint32_t world, const float* const* packed, uint32_t floats_per_pixel, float* layer);
 
 /* -- THE hot path: Renderer::render (renderer.h:657-734) -> __raygen__rg & friends (fredholm/modules/pt.cu:418-999).
  * Adds n_samples samples per owned pixel to the running means in `layers`; equivalent to n_samples consecutive
@@ -240,6 +243,8 @@ int fh_trace_rays(fh_ctx* ctx, uint32_t n, const float* rays7, int any_hit, floa
  * out[0] = vector registers per lane, out[1] = static LDS bytes per workgroup, out[2] = scratch bytes per lane, out[3] = workgroups per CU the kernel is
  * launched with, out[4] = stack levels it keeps in LDS (the deeper ones spill to global memory), out[5] = stack levels the BVH needs.  Valid after a
  * BVH build; out[3..4] after the first fh_render of the scene (0 before).  Lets a profile be tied to the code object that produced it (bench.py). */
+/* which = 2 + c: the shade kernel of shading class c of the uploaded scene (FH_E_INVALID beyond the scene's classes): out[0..2] as above, out[3] = resident workgroups per
+ * CU (of 4 waves: = waves per SIMD), out[4] = the lobe mask the kernel is compiled for, out[5] = the lobe mask of the class. */
 int fh_kernel_info(fh_ctx* ctx, int which, uint32_t out[6]);
 /* measured HBM bandwidth of this GPU (GB/s): a streaming float4 read and a float4 copy (read + written bytes) over `bytes`-sized buffers,
    `iters` launches each.  The "measured HBM roofline" SURVEY.md 8(d) asks for; use buffers well beyond the 256 MiB Infinity Cache. */

@@ -895,7 +895,7 @@ def test_counters_of_another_pass_size_are_refused():
     assert all(bench.pass_size_differs(tj, 1024, 3, 1) is None for tj in old)
 
 
-def test_fractions_outside_0_1_are_never_printed():
+def test_fractions_outside_0_1_are_taken_out_of_the_line():
     sys.path.insert(0, ROOT)
     import bench
     out = {"roofline": {"frac": 2.86412, "frac_alone": 0.4, "valu": {"frac_x": -0.1}, "algorithmic_gbs_over_hbm_peak": 1.03, "frac_none": None}, "general_scene": {"roofline": {"frac_hbm_measured": 1.2, "frac": 0.34}},
@@ -904,6 +904,46 @@ def test_fractions_outside_0_1_are_never_printed():
     assert sorted(k for k, _ in bad) == ["general_scene.roofline.frac_hbm_measured", "list[0].frac_a", "roofline.frac", "roofline.valu.frac_x"]
     assert out == {"roofline": {"frac_alone": 0.4, "valu": {}, "algorithmic_gbs_over_hbm_peak": 1.03, "frac_none": None}, "general_scene": {"roofline": {"frac": 0.34}}, "list": [{}], "fraction_of_nothing": 0.5}
     assert bench.refuse_bad_fracs(out) == []
+
+
+def test_roofline_fields_with_fixed_names_and_their_verdict():
+    """round 6: the names that do not move again.  frac_survey_8d_over_hbm_peak is a cache-served byte rate over the HBM peak -- the one `frac*` that may exceed 1 -- and the
+    verdict line says which roof binds"""
+    sys.path.insert(0, ROOT)
+    import bench
+    roof = {"bound": "valu_issue", "frac": 0.34, "frac_hbm_measured": 0.19, "algorithmic_gbs_over_hbm_peak": 0.75, "vl1d": {"ta_busy_frac": 0.83}, "valu_busy_measured": 0.78}
+    bench.freeze_roofline_fields(roof)
+    assert (roof["frac_valu_issue_model"], roof["frac_hbm_counters"], roof["frac_survey_8d_over_hbm_peak"], roof["ta_busy"], roof["valu_busy"]) == (0.34, 0.19, 0.75, 0.83, 0.78)
+    assert "VALU issue (0.78 busy)" in roof["bound_verdict"] and "TA 0.83" in roof["bound_verdict"] and "HBM is not the roof" in roof["bound_verdict"] and "L2 / Infinity Cache" in roof["bound_verdict"]
+    bare = bench.freeze_roofline_fields({"bound": "valu_issue", "frac": 0.4, "algorithmic_gbs_over_hbm_peak": 1.7})
+    assert bare["frac_hbm_counters"] is None and bare["ta_busy"] is None and "no counter file" in bare["bound_verdict"]
+    assert bench.refuse_bad_fracs({"roofline": bare}) == []          # the exempt ratio may exceed 1 ...
+    assert bench.refuse_bad_fracs({"roofline": {"frac_hbm_counters": 1.2}}) == [("roofline.frac_hbm_counters", 1.2)]  # ... a fraction of a roof may not (main() then exits with code 3)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE: the parent makes no GPU call (it returns before torch is imported), starts N ranks through torch.distributed.run as a
+    CHILD process on 127.0.0.1 and relays its exit code"""
+    sys.path.insert(0, ROOT)
+    import subprocess as sp
+
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(sp, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and os.path.samefile(cmd[-5], os.path.join(ROOT, "bench.py")) and seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    assert "torch" not in bench.main.__code__.co_names[: list(bench.main.__code__.co_names).index("self_launch")]  # nothing of torch is touched before the hand-over
 
 
 def test_scaling_model_and_static_instruction_mix_come_from_committed_files():

@@ -1419,6 +1419,34 @@ def test_tile_ownership_matches_library_and_shards_reassemble():
     pad = max(s.shape[0] for s in shards)
     padded = [np.concatenate([s, np.zeros((pad - s.shape[0], 4), np.float32)]) for s in shards]
     assert np.array_equal(_bits(D.assemble(w, h, padded, tw, th)), _bits(want))
+    # every shard back into the frame in ONE launch (fh_unpack_shards: what rank 0 calls per presented frame), from equally padded shards as the gather delivers them,
+    # for several channel counts, and again after a change of resolution (the frame map is rebuilt)
+    full.set_tile_shard(0, 1, tw, th)
+    for fpp in (4, 1):
+        bufs = []
+        for s_ in padded:
+            b = F.renderer.DeviceBuffer(full, pad * 4 * fpp)
+            b.upload(np.ascontiguousarray(s_[:, :fpp]))
+            bufs.append(b)
+        dst = F.renderer.DeviceBuffer(full, w * h * 4 * fpp)
+        dst.clear()
+        full.unpack_shards([b.ptr for b in bufs], fpp, dst.ptr)
+        full.wait_for_completion()
+        assert np.array_equal(_bits(dst.download(np.float32, (h, w, fpp))), _bits(want[..., :fpp]))
+    full.set_resolution(w - 16, h)
+    own = [D.tile_ownership(w - 16, h, k, world, tw, th) for k in range(world)]
+    pad2 = max(o.size for o in own)
+    ramp = np.arange((w - 16) * h, dtype=np.float32)
+    bufs = []
+    for o in own:
+        b = F.renderer.DeviceBuffer(full, pad2 * 4)
+        b.upload(np.concatenate([ramp[o], np.zeros(pad2 - o.size, np.float32)]))
+        bufs.append(b)
+    dst = F.renderer.DeviceBuffer(full, (w - 16) * h * 4)
+    dst.clear()
+    full.unpack_shards([b.ptr for b in bufs], 1, dst.ptr)
+    full.wait_for_completion()
+    assert np.array_equal(dst.download(np.float32, ((w - 16) * h,)), ramp)
     full.close()
 
 

@@ -8,9 +8,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_bench_step_gathers_the_unsharded_frame(tmp_path):
-    """bench.py's N > 1 step end to end -- tile-sharded render, pack, gather to rank 0, fh_unpack_shard -- as two fresh processes (one per
-    rank, started by torch.distributed.run exactly as the driver starts them) sharing this one GPU, with gloo in place of RCCL.  --check-frame
+@pytest.mark.parametrize("launcher", ["driver", "self"])
+def test_two_rank_bench_step_gathers_the_unsharded_frame(tmp_path, launcher):
+    """bench.py's N > 1 step end to end -- tile-sharded render, pack, gather to rank 0, fh_unpack_shards -- as two fresh processes (one per
+    rank) sharing this one GPU, with gloo in place of RCCL: started by torch.distributed.run exactly as the driver starts them ("driver"), and by bench.py itself from
+    `python bench.py --gpus 2` with no launcher and no WORLD_SIZE ("self": the parent never touches the GPU, the ranks are its children).  --check-frame
     makes rank 0 compare the gathered frame bit for bit with an unsharded render of as many samples."""
     import json
     import os
@@ -22,8 +24,12 @@ def test_two_rank_bench_step_gathers_the_unsharded_frame(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, FH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "4", "--check-frame", "--no-cpu-baseline"]
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "4", "--check-frame", "--no-cpu-baseline"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert run.returncode == 0, run.stderr[-3000:]
     assert "frame gathered from 2 ranks bit-identical to the unsharded render: True" in run.stderr
@@ -70,6 +76,13 @@ def test_bench_line_contract(tmp_path, cfg, spp):
     if cfg == 2:
         assert r["bound"] == "valu_issue" and r["kernel"].startswith("k_trace") and 1.0 < r["clock_ghz_in_kernel"] < 2.6
         assert 0.0 < r["lane_utilisation"]["node_tests"] <= 1.0 and 0.0 < r["lane_utilisation"]["triangle_tests"] <= 1.0
+    # round 6: the fixed-name fields and the shade kernels' own record, whichever kernel dominates
+    for k in ("frac_hbm_counters", "frac_survey_8d_over_hbm_peak", "ta_busy", "valu_busy", "bound_verdict"):
+        assert k in r, k
+    assert r["frac_hbm_counters"] is None and r["frac_survey_8d_over_hbm_peak"] == (r["frac"] if r["bound"] == "hbm" else r["algorithmic_gbs_over_hbm_peak"]) and isinstance(r["bound_verdict"], str)
+    sh = out["shade"]
+    assert sh["ms_per_step_alone"] > 0 and sh["shaded_ghits_per_s_alone"] > 0 and sh["kernels"] and all(k["vgprs"] > 0 and 1 <= k["waves_per_simd"] <= 8 for k in sh["kernels"])
+    assert (sh.get("counters_from") and "valu_lane_utilisation" in sh) or "valu_busy" not in sh
     p = out["parity"]
     assert p["rmse"] == 0.0 and p["bit_identical_pixels"] == 1.0 and p["pixels"] == 8 * 1920
     lat = out["latency"]

@@ -56,6 +56,24 @@ d = {"kernel": k["name"], "config": cfg, "spp_per_pass": pmc_pass_spp, "submitte
      "frame_traffic_bytes_per_spp": frame / (renders * pspp),
      "frame_note": f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every kernel of the run / ({renders} renders x {pspp} spp): fabric-side bytes one sample per pixel of the whole frame costs",
      "note": "fabric-side bytes (L2 misses; Infinity-Cache hits are counted)."}
+# ---- round 6: the cooperative triangle test's LDS bank conflicts of the dominant kernel, and the shade kernels' own block (bench.py: `shade` record) -- every un-instrumented k_shade
+# instantiation of the run summed; the counter run renders `renders` times and the shade kernels are the same in all of them
+if "SQ_LDS_BANK_CONFLICT" in k and "SQ_LDS_IDX_ACTIVE" in k:
+    d["lds_bank_conflict_frac"] = round(g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_LDS_IDX_ACTIVE"), 1.0), 4)
+sh = [x for x in ks if x["name"].startswith("k_shade<")]
+if sh:
+    tot = lambda n: sum(x.get(n, (0, 0))[1] for x in sh)
+    pmc_full = json.loads(pmc_line)
+    per_sample = (pmc_full.get("rates") or {}).get("per_sample", {}).get("shaded_hits")
+    res = (1920 * 1080) if cfg != 4 else (3840 * 2160)
+    d["shade"] = {"kernels": sorted(x["name"] for x in sh), "dispatches": int(sum(x["dispatches"] for x in sh)),
+                  "valu_insts_total": int(tot("SQ_INSTS_VALU")), "valu_lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / max(64 * tot("SQ_INSTS_VALU"), 1), 4),
+                  "wait_any_frac_of_wave_cycles": round(tot("SQ_WAIT_ANY") / max(tot("SQ_WAVE_CYCLES"), 1), 4),
+                  "tcc_hit_rate": round(tot("TCC_HIT_sum") / max(tot("TCC_HIT_sum") + tot("TCC_MISS_sum"), 1), 4),
+                  "traffic_bytes_total": int((2 * tot("FETCH_SIZE") + tot("WRITE_SIZE")) * 1024),
+                  "lds_bank_conflict_frac": round(tot("SQ_LDS_BANK_CONFLICT") / max(tot("SQ_LDS_IDX_ACTIVE"), 1), 4) if tot("SQ_LDS_IDX_ACTIVE") else None,
+                  "shaded_hits_in_counter_run": int(per_sample * res * pspp * renders) if per_sample else None,
+                  "note": f"summed over the {renders} renders of the counter run (timed step, warm-up, serial step, two counting replays: the shade kernels are the same in all of them)"}
 # what the counters belong to (bench.py: roofline.counters_stale): the device sources and the kernel's registers / LDS / scratch of the run that was profiled, and the commit it was collected at
 import subprocess
 d["source_fingerprint"] = b.get("source_fingerprint")
