@@ -817,7 +817,7 @@ def main():
             roof = {"bound": "hbm", "kernel": kernel_name, "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(f["launches"]), "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms_alone": round(avg_alone_ms, 4),
                     "frac_alone": round(bytes_per_launch / (avg_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if avg_alone_ms > 0 else None,
-                    "measured_hbm_gbs": {"read": round(bw_read, 1), "copy": round(bw_copy, 1)}, "frac_of_measured_copy": round(alg_gbs / bw_copy, 5) if bw_copy > 0 else None,
+                    "measured_hbm_gbs": {"read": round(bw_read, 1), "copy": round(bw_copy, 1)}, "algorithmic_gbs_over_measured_copy": round(alg_gbs / bw_copy, 5) if bw_copy > 0 else None,  # (a ratio, not a fraction of a roof: cache-served bytes can exceed the copy rate)
                     "note": where + "; achieved = algorithmic bytes (DESIGN.md 4) / kernel time inside the timed region; the kernel waits on scattered 16-byte accesses to path and face records and on VALU "
                             "(BSDF, software transcendentals), so the algorithmic figure is a lower bound of what moves"}
         if dom.startswith("k_trace"):
@@ -878,7 +878,7 @@ def main():
                          "puts the lens a focal length behind the camera origin) and end in k_generate, so Msamples/s of this workload is not a general-scene number: configs[3] (an interior, every ray hits) is"}
         # ---- the whole frame: algorithmic bytes of every counted kernel family over the step, and the fabric-side bytes the counters saw over a step
         alg_step = sum(v["bytes"] for v in fam.values() if v["bytes"] is not None)
-        whole = {"algorithmic_bytes_per_step": int(alg_step), "algorithmic_gbs": round(alg_step / (dt / steps) / 1e9, 1), "frac_of_hbm_peak": round(alg_step / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5),
+        whole = {"algorithmic_bytes_per_step": int(alg_step), "algorithmic_gbs": round(alg_step / (dt / steps) / 1e9, 1), "algorithmic_gbs_over_hbm_peak": round(alg_step / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5),
                  "note": "traversal + shade + generate + accumulate bytes (DESIGN.md 4) over the wall time of a step; the fused tail, route and sort kernels are not counted"}
         if pmc and pmc.get("frame_traffic_bytes_per_spp"):
             fb = pmc["frame_traffic_bytes_per_spp"] * spp

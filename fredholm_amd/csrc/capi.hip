@@ -567,6 +567,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_uint("FH_TAIL_DEPTH", 0, 64, t.tail_depth);
     env_uint("FH_TAIL_PATHS", 64, 1 << 30, t.tail_paths);
     env_off("FH_SORT", t.sort_queues);
+    env_uint("FH_SORT_ONEPASS", 0, 2, t.sort_onepass);
     env_uint("FH_BOTTOM_UP", 0, 2, t.bottom_up);
     env_uint("FH_SUBPASS", 1, 3, t.sub_passes);
     env_uint("FH_SUBPASS_MIN", 1, 1 << 30, t.sub_pass_min_paths);

@@ -193,6 +193,7 @@ struct fh_ctx {
     uint32_t bottom_up = 2;         // FH_BOTTOM_UP=0: every ray starts its traversal at the root; =1: first-hit rays of scenes without cut-outs start at the wide node that holds the face
                                     // they leave and climb; default (2): the first passes after a build try both and the counted test rounds per shaded path decide (render.hip)
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
+    uint32_t sort_onepass = 2;      // FH_SORT_ONEPASS: cell sorts in calls of ONE pass -- 0 none, 1 all (as in multi-pass calls), 2 only the queue the fused tail takes over
     bool debug_tail = false;        // FH_DEBUG_TAIL
     bool force_alpha = false;       // FH_FORCE_ALPHA=1 (timing experiments): the kernels with the any-hit path compiled in, whatever the scene
     bool ignore_alpha = false;      // FH_NO_ALPHA=1 (timing experiments only: wrong images): cut-out textures are not tested during traversal

@@ -1202,6 +1202,8 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? 5 : 6)) k_trace_
 
 // secondary rays, streaming: a lane's item is one shaded path; its secondary-ray slots are traced one after the other by the
 // same lane, so the additions into the path's radiance keep the reference's order (directional, sky, area, BSDF-sampled)
+// (Items that are single RAYS instead of paths -- so that a small launch would end in its longest ray, not in its longest path -- were built and measured in round 6, bit-identical
+// and SLOWER: the rays of a path share their first nodes, and the launches of one-pass calls are not bound by a lane's chain.  tools/patches/r6_ray_items.patch, profiles/README.md r6-8.)
 template <bool COUNT, bool LIGHTS>
 struct SecondaryStream {
   static constexpr bool all_any = !LIGHTS;  // without emitters every secondary ray stops at its first hit
@@ -2385,18 +2387,23 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       }
       {
         Span sp(ctx, sh, 6);
-        if (sort_queues) {
-          // secondary rays of this bounce and the radiance rays of the next one, each into cell order
+        // secondary rays of this bounce and the radiance rays of the next one, each into cell order.  ONE-PASS calls (r6-7): the order buys their launches nothing -- every
+        // line they touch is touched for the first time whatever the order -- and the six sort launches per bounce are pure chain: 4- and 16-sample calls of configs[3] are
+        // 3 % / 2 % faster without them; only the queue the fused tail takes over keeps its order (FH_SORT_ONEPASS=1: all, =0: none)
+        const bool tail_next = depth + 1u == wave_depth && wave_depth < max_depth;
+        const bool sort_sec = sort_queues && (!single_pass || tun.sort_onepass == 1u);
+        const bool sort_rad = sort_queues && (!single_pass || tun.sort_onepass == 1u || (tun.sort_onepass == 2u && tail_next));
+        ps = pd;
+        if (sort_sec) {
           sort_queue_by_cell(sh, sort_blocks, pool.counters + depth * kCounterStride + CNT_SEC, pool.q_sec, pool.key_sec, pool.bins, pool.q_sec_sorted);
-          ps = pd;
           ps.q_sec = pool.q_sec_sorted;
+        }
+        if (sort_rad) {
           const uint32_t nxt = (depth + 1u) & 1u;
           sort_queue_by_cell(sh, sort_blocks, pool.counters + (depth + 1u) * kCounterStride + CNT_RAD, pd.q_rad[nxt], pool.key_rad, pool.bins, q_spare);
           uint32_t* const unsorted = pd.q_rad[nxt];
           pd.q_rad[nxt] = q_spare;  // the next bounce reads the sorted queue ...
           q_spare = unsorted;       // ... and the buffer it came from is the next scratch target
-        } else {
-          ps = pd;
         }
       }
       if (shade_sep) { FH_HIP(hipEventRecord(ctx->ev_shade[slot][2u * depth + 1u], sh)); FH_HIP(hipStreamWaitEvent(st, ctx->ev_shade[slot][2u * depth + 1u], 0)); }
