@@ -9,7 +9,7 @@
 //   5. bottom-up box refit with arrival counters               (k_refit)
 //   6. emit the traversal layout: 64-byte two-child nodes whose children are inner nodes or leaves of
 //      <= 4 Morton-contiguous triangles, and the triangle array in leaf order (k_emit2 / k_emit_tris)
-//   6a. optionally PLOC instead of the radix tree (chosen per scene by summed inner-node area) and SAH refinement by parallel reinsertion (FH_SAH_ITERS; off: it lowers
+//   6a. optionally PLOC instead of the radix tree (chosen per scene by summed inner-node area) and (round 5, measured and taken out: tools/patches) SAH refinement by parallel reinsertion (FH_SAH_ITERS; off: it lowers
 //      the area and not the visits, profiles/README.md r5-1)
 //   7. collapse to the 8-wide quantised layout the traversal kernels prefer (bvh8 section), with the way up -- per wide node parent << 3 | child slot, per face the node
 //      that holds it (also written into the face record) -- for rays that start at their face (fh_trace.h)
@@ -763,199 +763,6 @@ __global__ void k_sah_sum(int n_inner, const float4* node_lo, const float4* node
 }
 
 // ------------------------------------------------------------------------------------------------
-// SAH refinement of the binary tree by parallel reinsertion (Meister & Bittner, "Parallel Reinsertion for Bounding Volume
-// Hierarchy Optimization", Eurographics 2018).  The radix tree splits by Morton prefix, PLOC merges greedily; neither looks at
-// the surface-area heuristic the traversal cost follows.  optixAccelBuild, which the reference calls (renderer.h:484-494), is a
-// SAH-class builder; this pass is what brings the tree under the collapse to that class.  Per round:
-//   1. search   every node x (thread per node) looks for the position y where removing x (its parent p disappears, its sibling
-//               takes p's place, the ancestors shrink) and re-attaching it next to y (p becomes the parent of x and y, the
-//               ancestors of y grow) lowers the summed area of the inner nodes the most: a branch-and-bound walk that climbs
-//               from p to the root and, at every ancestor (the pivot), descends into the sibling subtree while
-//               gain so far - growth along the descent - area(x) can still beat the best gain found (parent pointers, no stack);
-//   2. lock     every x with a positive gain writes (gain, x) with atomicMax into every node its move touches: the nodes on the
-//               tree path from x to y below their common ancestor, and p, the grandparent, the sibling and y's parent;
-//   3. apply    an x that still holds all of its locks re-links p between y and y's parent.  Moves with disjoint lock sets touch
-//               disjoint pointers and cannot put a node under itself (a node that became an ancestor of y would lie on the
-//               locked path), so any subset of them leaves a tree; nothing depends on the order they run in;
-//   4. refit    boxes (and leaf counts) bottom up with arrival counters; the sum of the inner-node areas is the objective.
-// Rounds stop when a round gains less than 1 % (FH_SAH_MIN_GAIN) or after FH_SAH_ITERS rounds (default 0 = off until measured).
-// Everything is deterministic (atomicMax of unique keys; unions are order independent).  Hits do not depend on the shape of the
-// tree (fh_trace.h: ties break by face id), so images are bit-identical with and without this pass.
-// Unified node index u: inner nodes 0 .. n_inner-1, leaf i at n_inner + i.  box lo.w / hi.w of an inner node = left / right child.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float area_of(const float4& lo, const float4& hi) { return box_area(lo, hi); }
-__device__ __forceinline__ float union_area(const float4& alo, const float4& ahi, const float4& blo, const float4& bhi)
-{
-  const float ex = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), ey = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y), ez = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
-  return ex * ey + ey * ez + ez * ex;
-}
-
-__global__ void k_ri_init(int n_inner, int n_leaves, int root, const int2* children, const float4* node_lo, const float4* node_hi, const float4* leaf_lo, const float4* leaf_hi,
-                          float4* ulo, float4* uhi, int* upar)
-{
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n_inner + n_leaves) return;
-  if (u < n_inner) {
-    const int2 ch = children[u];
-    const int l = ch.x >= 0 ? ch.x : n_inner + ~ch.x, r = ch.y >= 0 ? ch.y : n_inner + ~ch.y;
-    float4 lo = node_lo[u], hi = node_hi[u];
-    lo.w = __int_as_float(l); hi.w = __int_as_float(r);
-    ulo[u] = lo; uhi[u] = hi;
-    upar[l] = u; upar[r] = u;
-    if (u == root) upar[u] = -1;
-  } else {
-    float4 lo = leaf_lo[u - n_inner], hi = leaf_hi[u - n_inner];
-    lo.w = __int_as_float(-1); hi.w = __int_as_float(-1);
-    ulo[u] = lo; uhi[u] = hi;
-  }
-}
-
-// best re-insertion position of every node: out_gain[u] > 0, out_y[u] = the node x is to become the sibling of, out_c[u] = the pivot (common ancestor) it was found under
-__global__ void k_ri_search(int n_total, int n_inner, int root, const float4* __restrict__ ulo, const float4* __restrict__ uhi, const int* __restrict__ upar, float* out_gain, int* out_y,
-                            int* out_c, int max_visits, float min_gain)
-{
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n_total) return;
-  float best = min_gain;
-  int best_y = -1, best_c = -1;
-  const int p = x == root ? -1 : upar[x];
-  if (p >= 0 && p != root) {
-    const float4 xlo = ulo[x], xhi = uhi[x];
-    const float ax = area_of(xlo, xhi);
-    float d_up = area_of(ulo[p], uhi[p]);  // what the removal has gained below the current pivot: area(p) + the shrinkage of the ancestors passed
-    float4 rlo = make_float4(3e38f, 3e38f, 3e38f, 0.0f), rhi = make_float4(-3e38f, -3e38f, -3e38f, 0.0f);  // box of the current ancestor without x
-    int cur = x, pivot = p, visits = 0;
-    while (pivot >= 0) {
-      const int left = __float_as_int(ulo[pivot].w), right = __float_as_int(uhi[pivot].w);
-      const int sib = left == cur ? right : left;
-      // ---- candidates in the subtree of sib; c = growth of the nodes between sib and the candidate's parent (inclusive) if x goes below them
-      int z = sib;
-      float c = 0.0f;
-      bool down = true;
-      for (;;) {
-        if (down) {
-          const float4 zlo = ulo[z], zhi = uhi[z];
-          ++visits;
-          const float m = union_area(zlo, zhi, xlo, xhi);
-          if (!(pivot == p && z == sib)) {  // (next to its own sibling is where x is)
-            const float g = d_up - c - m;
-            if (g > best) { best = g; best_y = z; best_c = pivot; }
-          }
-          const float inc = m - area_of(zlo, zhi);
-          if (z < n_inner && d_up - (c + inc) - ax > best && visits < max_visits) { c += inc; z = __float_as_int(zlo.w); continue; }
-          down = false;
-        }
-        if (z == sib) break;
-        const int pz = upar[z];
-        const float4 plo = ulo[pz], phi = uhi[pz];
-        if (__float_as_int(plo.w) == z) { z = __float_as_int(phi.w); down = true; }
-        else { z = pz; c -= union_area(plo, phi, xlo, xhi) - area_of(plo, phi); }
-      }
-      // ---- one level up: the pivot shrinks to the union of the siblings passed so far
-      const float4 slo = ulo[sib], shi = uhi[sib];
-      rlo = make_float4(fminf(rlo.x, slo.x), fminf(rlo.y, slo.y), fminf(rlo.z, slo.z), 0.0f);
-      rhi = make_float4(fmaxf(rhi.x, shi.x), fmaxf(rhi.y, shi.y), fmaxf(rhi.z, shi.z), 0.0f);
-      if (pivot != p) {
-        d_up += area_of(ulo[pivot], uhi[pivot]) - area_of(rlo, rhi);
-        if (pivot != root) {  // next to the shrunken ancestor itself (the root stays the root)
-          const float g = d_up - union_area(rlo, rhi, xlo, xhi);
-          if (g > best) { best = g; best_y = pivot; best_c = upar[pivot]; }
-        }
-      }
-      if (visits >= max_visits) break;
-      cur = pivot;
-      pivot = upar[pivot];
-    }
-  }
-  out_gain[x] = best_y >= 0 ? best : 0.0f;
-  out_y[x] = best_y;
-  out_c[x] = best_c;
-}
-
-// the nodes a move of x next to y touches; F(node) returns false to stop
-template <class F>
-__device__ __forceinline__ bool ri_for_lock_set(int x, int y, int c, const float4* ulo, const float4* uhi, const int* upar, F f)
-{
-  const int p = upar[x], g = upar[p];
-  const int s = __float_as_int(ulo[p].w) == x ? __float_as_int(uhi[p].w) : __float_as_int(ulo[p].w);
-  if (!f(p) || !f(g) || !f(s) || !f(upar[y])) return false;
-  for (int z = x, guard = 0; z != c && z >= 0 && guard < 4096; z = upar[z], ++guard) if (!f(z)) return false;
-  for (int z = y, guard = 0; z != c && z >= 0 && guard < 4096; z = upar[z], ++guard) if (!f(z)) return false;
-  return true;
-}
-
-__global__ void k_ri_lock(int n_total, const float4* ulo, const float4* uhi, const int* upar, const float* gain, const int* ys, const int* cs, unsigned long long* lock)
-{
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n_total) return;
-  const int y = ys[x];
-  if (y < 0) return;
-  const unsigned long long key = ((unsigned long long)__float_as_uint(gain[x]) << 32) | (uint32_t)x;  // (gains are positive floats: their bits order like their values)
-  ri_for_lock_set(x, y, cs[x], ulo, uhi, upar, [&](int n) { atomicMax(&lock[n], key); return true; });
-}
-
-__device__ __forceinline__ void ri_replace_child(float4* ulo, float4* uhi, int node, int from, int to)
-{
-  if (__float_as_int(ulo[node].w) == from) ulo[node].w = __int_as_float(to);
-  else uhi[node].w = __int_as_float(to);
-}
-
-__global__ void k_ri_apply(int n_total, float4* ulo, float4* uhi, int* upar, const float* gain, const int* ys, const int* cs, const unsigned long long* lock, uint32_t* n_applied)
-{
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n_total) return;
-  const int y = ys[x];
-  if (y < 0) return;
-  const unsigned long long key = ((unsigned long long)__float_as_uint(gain[x]) << 32) | (uint32_t)x;
-  // (a node that is not ours is never followed: ri_for_lock_set stops at the first one, and the nodes we did follow are modified by nobody else)
-  if (!ri_for_lock_set(x, y, cs[x], ulo, uhi, upar, [&](int n) { return lock[n] == key; })) return;
-  const int p = upar[x], g = upar[p];
-  const int s = __float_as_int(ulo[p].w) == x ? __float_as_int(uhi[p].w) : __float_as_int(ulo[p].w);
-  ri_replace_child(ulo, uhi, g, p, s);  // p leaves: the sibling takes its place
-  upar[s] = g;
-  const int q = upar[y];                // p goes between y and y's parent
-  ri_replace_child(ulo, uhi, q, y, p);
-  upar[p] = q;
-  ulo[p].w = __int_as_float(x);
-  uhi[p].w = __int_as_float(y);
-  upar[y] = p;
-  atomicAdd(n_applied, 1u);
-}
-
-// boxes and leaf counts of the inner nodes, bottom up (child links in .w are kept)
-__global__ void k_ri_refit(int n_inner, int n_leaves, float4* ulo, float4* uhi, const int* upar, unsigned int* arrive, int* count)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_leaves) return;
-  int cur = upar[n_inner + i];
-  while (cur >= 0) {
-    __threadfence();
-    const unsigned int prev = atomicAdd(&arrive[cur], 1u);
-    if (prev == 0u) return;
-    __threadfence();
-    const float4 mylo = ulo[cur], myhi = uhi[cur];
-    const int l = __float_as_int(mylo.w), r = __float_as_int(myhi.w);
-    const float4 al = ulo[l], ah = uhi[l], bl = ulo[r], bh = uhi[r];
-    ulo[cur] = make_float4(fminf(al.x, bl.x), fminf(al.y, bl.y), fminf(al.z, bl.z), mylo.w);
-    uhi[cur] = make_float4(fmaxf(ah.x, bh.x), fmaxf(ah.y, bh.y), fmaxf(ah.z, bh.z), myhi.w);
-    count[cur] = (l < n_inner ? count[l] : 1) + (r < n_inner ? count[r] : 1);
-    cur = upar[cur];
-  }
-}
-
-__global__ void k_ri_export(int n_inner, const float4* ulo, const float4* uhi, const int* count, int2* children, int2* ranges, float4* node_lo, float4* node_hi)
-{
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n_inner) return;
-  const float4 lo = ulo[u], hi = uhi[u];
-  const int l = __float_as_int(lo.w), r = __float_as_int(hi.w);
-  children[u] = make_int2(l < n_inner ? l : ~(l - n_inner), r < n_inner ? r : ~(r - n_inner));
-  ranges[u] = make_int2(0, count[u] - 1);
-  node_lo[u] = make_float4(lo.x, lo.y, lo.z, 0.0f);
-  node_hi[u] = make_float4(hi.x, hi.y, hi.z, 0.0f);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Refit of the wide tree.  When only the instance transforms change (Renderer::set_time: the reference rebuilds its IAS and leaves
 // the GAS alone, renderer.h:614-640) the topology of the flattened tree is kept: the triangle copies are refreshed from the moved
 // face records and the boxes are recomputed bottom up, level by level (levels are contiguous node ranges because the collapse is
@@ -1165,8 +972,7 @@ int bvh_build_device(fh_ctx* ctx)
     if (const char* e = getenv("FH_SPLIT")) splitting = splitting && e[0] != '0';
     if (splitting) {
       const float extent = fmaxf(fmaxf(ctx->scene_hi[0] - ctx->scene_lo[0], ctx->scene_hi[1] - ctx->scene_lo[1]), ctx->scene_hi[2] - ctx->scene_lo[2]);
-      float thr = extent / 32.0f;  // FH_SPLIT_DIV: the divisor
-      if (const char* e = getenv("FH_SPLIT_DIV")) { const float v = (float)atof(e); if (v >= 2.0f && v <= 4096.0f) thr = extent / v; }
+      float thr = extent / 32.0f;
       const float eps = extent * 1e-6f;
       FH_HIP(split_count.alloc(n)); FH_HIP(split_offset.alloc(n));
       size_t scan_bytes = 0;
@@ -1174,8 +980,7 @@ int bvh_build_device(fh_ctx* ctx)
       DevBuf<char> scan_tmp;
       FH_HIP(scan_tmp.alloc(scan_bytes));
       uint32_t total = n;
-      double split_budget = 1.5;  // references per face the split may produce at most (FH_SPLIT_BUDGET)
-      if (const char* e = getenv("FH_SPLIT_BUDGET")) { const double v = atof(e); if (v >= 1.0 && v <= 8.0) split_budget = v; }
+      const double split_budget = 1.5;  // references per face the split may produce at most
       for (int attempt = 0; attempt < 6; ++attempt, thr *= 2.0f) {  // a scene made of large triangles only: coarser cells until the references fit
         hipLaunchKernelGGL(k_split_count, dim3(blocks), dim3(256), 0, st, ctx->d_face_rec, face_lo.p, face_hi.p, n, thr, eps, split_count.p);
         FH_HIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, split_count.p, split_offset.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
@@ -1248,8 +1053,7 @@ int bvh_build_device(fh_ctx* ctx)
       FH_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, valid.p, offset.p, 0u, (size_t)nr, rocprim::plus<uint32_t>(), st));
       DevBuf<char> scan_tmp;
       FH_HIP(scan_tmp.alloc(scan_bytes));
-      int ploc_radius = kPlocRadius;  // FH_PLOC_RADIUS: neighbours searched to either side
-      if (const char* e = getenv("FH_PLOC_RADIUS")) { const int v = atoi(e); if (v >= 1 && v <= 256) ploc_radius = v; }
+      const int ploc_radius = kPlocRadius;  // neighbours searched to either side
       int* cid = cid_a.p; int* cid_o = cid_b.p;
       float4 *clo = clo_a.p, *chi = chi_a.p, *clo_o = clo_b.p, *chi_o = chi_b.p;
       uint32_t count = nr;
@@ -1305,92 +1109,8 @@ int bvh_build_device(fh_ctx* ctx)
     const float4* c_node_lo = ploc ? p_node_lo.p : node_lo.p;
     const float4* c_node_hi = ploc ? p_node_hi.p : node_hi.p;
 
-    // ---- SAH refinement of the chosen binary tree by parallel reinsertion (kernels above), in place
-    {
-      int sah_iters = 0;          // FH_SAH_ITERS: rounds at most (0: off, the default: profiles/README.md r5-1)
-      double sah_min_gain = 0.01; // FH_SAH_MIN_GAIN: stop when a round lowers the summed inner-node area by less than this share
-      int sah_visits = 1024;      // FH_SAH_VISITS: nodes one search may look at
-      if (const char* e = getenv("FH_SAH_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) sah_iters = v; }
-      if (const char* e = getenv("FH_SAH_MIN_GAIN")) { const double v = atof(e); if (v >= 0.0 && v < 1.0) sah_min_gain = v; }
-      if (const char* e = getenv("FH_SAH_VISITS")) { const int v = atoi(e); if (v >= 8 && v <= (1 << 20)) sah_visits = v; }
-      ctx->stats_sah_before = ctx->stats_sah_after = 0.0;
-      ctx->stats_sah_rounds = 0;
-      if (sah_iters > 0 && n_inner >= 3) {
-        const auto t_sah = std::chrono::steady_clock::now();
-        const uint32_t n_total = n_inner + nr;
-        const uint32_t tblocks = (n_total + 255) / 256;
-        DevBuf<float4> ulo, uhi;
-        DevBuf<int> upar, ri_y, ri_c, ri_count;
-        DevBuf<float> ri_gain;
-        DevBuf<unsigned long long> ri_lock;
-        DevBuf<double> ri_sum;
-        DevBuf<uint32_t> ri_applied;
-        FH_HIP(ulo.alloc(n_total)); FH_HIP(uhi.alloc(n_total)); FH_HIP(upar.alloc(n_total)); FH_HIP(ri_y.alloc(n_total)); FH_HIP(ri_c.alloc(n_total)); FH_HIP(ri_count.alloc(n_inner));
-        FH_HIP(ri_gain.alloc(n_total)); FH_HIP(ri_lock.alloc(n_total)); FH_HIP(ri_sum.alloc(1)); FH_HIP(ri_applied.alloc(1));
-        int2* m_children = ploc ? p_children.p : children.p;
-        int2* m_ranges = ploc ? p_ranges.p : ranges.p;
-        float4* m_node_lo = ploc ? p_node_lo.p : node_lo.p;
-        float4* m_node_hi = ploc ? p_node_hi.p : node_hi.p;
-        hipLaunchKernelGGL(k_ri_init, dim3(tblocks), dim3(256), 0, st, (int)n_inner, (int)nr, root_node, m_children, m_node_lo, m_node_hi, leaf_lo.p, leaf_hi.p, ulo.p, uhi.p, upar.p);
-        auto sah_of = [&](double* out) -> int {
-          FH_HIP(hipMemsetAsync(ri_sum.p, 0, 8, st));
-          hipLaunchKernelGGL(k_sah_sum, dim3(iblocks), dim3(256), 0, st, (int)n_inner, ulo.p, uhi.p, ri_sum.p);
-          FH_HIP(hipMemcpyAsync(out, ri_sum.p, 8, hipMemcpyDeviceToHost, st));
-          FH_HIP(hipStreamSynchronize(st));
-          return FH_OK;
-        };
-        double sah_prev = 0.0;
-        { const int rc = sah_of(&sah_prev); if (rc) return rc; }
-        ctx->stats_sah_before = sah_prev;
-        double root_area_eps = 0.0;
-        {
-          float4 rl, rh;
-          FH_HIP(hipMemcpyAsync(&rl, ulo.p + root_node, 16, hipMemcpyDeviceToHost, st));
-          FH_HIP(hipMemcpyAsync(&rh, uhi.p + root_node, 16, hipMemcpyDeviceToHost, st));
-          FH_HIP(hipStreamSynchronize(st));
-          const double ex = rh.x - rl.x, ey = rh.y - rl.y, ez = rh.z - rl.z;
-          root_area_eps = (ex * ey + ey * ez + ez * ex) * 1e-9;  // gains below a billionth of the root's area are rounding noise, not moves worth a lock
-        }
-        int rounds = 0;
-        for (int it = 0; it < sah_iters; ++it) {
-          hipLaunchKernelGGL(k_ri_search, dim3(tblocks), dim3(256), 0, st, (int)n_total, (int)n_inner, root_node, ulo.p, uhi.p, upar.p, ri_gain.p, ri_y.p, ri_c.p, sah_visits,
-                             (float)root_area_eps);
-          FH_HIP(hipMemsetAsync(ri_lock.p, 0, 8ull * n_total, st));
-          FH_HIP(hipMemsetAsync(ri_applied.p, 0, 4, st));
-          hipLaunchKernelGGL(k_ri_lock, dim3(tblocks), dim3(256), 0, st, (int)n_total, ulo.p, uhi.p, upar.p, ri_gain.p, ri_y.p, ri_c.p, ri_lock.p);
-          hipLaunchKernelGGL(k_ri_apply, dim3(tblocks), dim3(256), 0, st, (int)n_total, ulo.p, uhi.p, upar.p, ri_gain.p, ri_y.p, ri_c.p, ri_lock.p, ri_applied.p);
-          FH_HIP(hipMemsetAsync(arrive.p, 0, 4ull * n_inner, st));
-          hipLaunchKernelGGL(k_ri_refit, dim3(rblocks), dim3(256), 0, st, (int)n_inner, (int)nr, ulo.p, uhi.p, upar.p, arrive.p, ri_count.p);
-          double sah_now = 0.0;
-          { const int rc = sah_of(&sah_now); if (rc) return rc; }
-          ++rounds;
-          if (getenv("FH_DEBUG_BVH")) {
-            uint32_t applied = 0;
-            FH_HIP(hipMemcpy(&applied, ri_applied.p, 4, hipMemcpyDeviceToHost));
-            std::vector<int> hy(n_total);
-            FH_HIP(hipMemcpy(hy.data(), ri_y.p, 4ull * n_total, hipMemcpyDeviceToHost));
-            size_t wanted = 0;
-            for (int v : hy) wanted += v >= 0;
-            fprintf(stderr, "[bvh] reinsertion round %d: %zu nodes with a better place, ", it + 1, wanted);
-            fprintf(stderr, "%u moves, inner-node area %.4f -> %.4f (%.2f %%)\n", applied, sah_prev, sah_now, 100.0 * (sah_prev - sah_now) / sah_prev);
-          }
-          const bool done = !(sah_prev - sah_now > sah_min_gain * sah_prev);
-          sah_prev = sah_now;
-          if (done) break;
-        }
-        if (rounds == 0) {  // (counts for the export)
-          FH_HIP(hipMemsetAsync(arrive.p, 0, 4ull * n_inner, st));
-          hipLaunchKernelGGL(k_ri_refit, dim3(rblocks), dim3(256), 0, st, (int)n_inner, (int)nr, ulo.p, uhi.p, upar.p, arrive.p, ri_count.p);
-        }
-        hipLaunchKernelGGL(k_ri_export, dim3(iblocks), dim3(256), 0, st, (int)n_inner, ulo.p, uhi.p, ri_count.p, m_children, m_ranges, m_node_lo, m_node_hi);
-        FH_HIP(hipGetLastError());
-        FH_HIP(hipStreamSynchronize(st));
-        ctx->stats_sah_after = sah_prev;
-        ctx->stats_sah_rounds = rounds;
-        ctx->stats_sah_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sah).count();
-        if (getenv("FH_DEBUG_BVH")) fprintf(stderr, "[bvh] reinsertion: %d rounds, %.2f ms, inner-node area %.4f -> %.4f\n", rounds, ctx->stats_sah_ms, ctx->stats_sah_before, ctx->stats_sah_after);
-      }
-    }
+    // (SAH refinement of the chosen binary tree by parallel reinsertion, Meister & Bittner 2018, was built in round 5: the summed inner-node area falls by 2-7 %, the node visits per
+    // ray do not -- 15.28 -> 15.12 on configs[2], 11.73 -> 11.81 on configs[3].  profiles/README.md r5-1, tools/patches/r6_pruned_switches.patch)
 
     // ---- collapse to BVH8, breadth first
     DevBuf<Work8> work_a, work_b;

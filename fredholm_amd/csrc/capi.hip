@@ -482,13 +482,7 @@ int fh_ctx_create(int device, fh_ctx** out)
   fh_ctx* ctx = new fh_ctx;
   ctx->device = device;
   auto bail = [&](const char* what) { g_create_error = what; delete ctx; return FH_E_HIP; };
-  // FH_TRACE_CUS=k (experiment, with FH_SHADE_STREAM): the pass streams -- traversal, generate, accumulate -- may use only k of every 32 compute units, so that the shade
-  // side of the other passes always finds room; the streaming launches size their grids for 8 k CUs
-  uint32_t cu_words[8];
-  int trace_cus = 0;
-  if (const char* e = getenv("FH_TRACE_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 31) trace_cus = v; }
-  for (int k = 0; k < 8; ++k) cu_words[k] = trace_cus ? ((1u << trace_cus) - 1u) : 0xffffffffu;
-  auto make_stream = [&](hipStream_t* s) { return trace_cus ? hipExtStreamCreateWithCUMask(s, 8, cu_words) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); };
+  auto make_stream = [&](hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); };
   if (make_stream(&ctx->stream) != hipSuccess) return bail("hipStreamCreate failed");
   if (hipMalloc((void**)&ctx->d_sobol, kSobolMatricesBytes) != hipSuccess) return bail("hipMalloc failed");
   if (hipMalloc((void**)&ctx->d_lut_refl, kLutReflectionBytes) != hipSuccess) return bail("hipMalloc failed");
@@ -527,7 +521,6 @@ int fh_ctx_create(int device, fh_ctx** out)
     fh_ctx::Tunables& t = ctx->tun;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) t.n_cus = (uint32_t)prop.multiProcessorCount;
-    if (trace_cus) t.n_cus = t.n_cus * (uint32_t)trace_cus / 32u;
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && v >= 64 * 1024) t.lds_per_cu = (uint32_t)v;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && v >= 64 * 1024) t.lds_per_block = (uint32_t)v;
@@ -539,9 +532,6 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_off("FH_COOP", t.coop);
     env_off("FH_STREAM", t.stream);
     t.stream_forced = t.stream && getenv("FH_STREAM") != nullptr;
-    env_uint("FH_STREAM_WGS", 1, 8, t.stream_wgs_per_cu);
-    env_uint("FH_STREAM_GRID", 8, 8192, t.stream_grid);
-    t.stream_grid &= ~7u;
     env_uint("FH_STREAM_REFILL", 1, 64, t.stream_refill);
     env_uint("FH_STREAM_MIN_RAYS", 0, 65535, t.stream_min_rays);
     env_off("FH_SORT_SMALL", t.sort_small);
@@ -551,13 +541,6 @@ int fh_ctx_create(int device, fh_ctx** out)
     if (const char* e = getenv("FH_POISON")) t.poison_pools = e[0] == '1';
     env_off("FH_SKY_SPLIT", t.sky_split);
     env_uint("FH_SKY_SPLIT_MIN_LOG2", 0, 40, t.sky_split_min_log2);
-    env_uint("FH_SHADE_STREAM", 0, 2, t.shade_stream);
-    if (t.shade_stream) {
-      int least = 0, greatest = 0;
-      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      for (int k = 0; k < 3; ++k)
-        if (hipStreamCreateWithPriority(&ctx->shade_stream[k], hipStreamNonBlocking, t.shade_stream == 2 ? greatest : least) != hipSuccess) return bail("hipStreamCreateWithPriority failed");
-    }
     env_uint("FH_STACK_LDS", 1, 99, t.stack_lds_entries);
     env_uint("FH_SHADE_WGS", 2, 3, t.shade_wgs);
     env_uint("FH_STREAM_CHUNK", 16, 65535, t.stream_chunk);
@@ -569,10 +552,7 @@ int fh_ctx_create(int device, fh_ctx** out)
     env_off("FH_SORT", t.sort_queues);
     env_uint("FH_SORT_ONEPASS", 0, 2, t.sort_onepass);
     env_uint("FH_BOTTOM_UP", 0, 2, t.bottom_up);
-    env_uint("FH_SUBPASS", 1, 3, t.sub_passes);
-    env_uint("FH_SUBPASS_MIN", 1, 1 << 30, t.sub_pass_min_paths);
     t.debug_tail = getenv("FH_DEBUG_TAIL") != nullptr;
-    if (const char* e = getenv("FH_NO_ALPHA")) t.ignore_alpha = e[0] == '1';
     if (const char* e = getenv("FH_FORCE_ALPHA")) t.force_alpha = e[0] == '1';
   }
   {  // the sky-pixel kernel's stream has the lowest priority: its workgroups -- pure arithmetic, 110 registers -- take what the passes leave instead of the wave slots the
@@ -615,8 +595,6 @@ int fh_ctx_destroy(fh_ctx* ctx)
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto e : ctx->ev_bounce) (void)hipEventDestroy(e);
   for (int k = 0; k < 3; ++k) {
-    for (auto e : ctx->ev_shade[k]) (void)hipEventDestroy(e);
-    if (ctx->shade_stream[k]) (void)hipStreamDestroy(ctx->shade_stream[k]);
   }
   for (int k = 0; k < 3; ++k) {
     if (ctx->h_counters[k]) (void)hipHostFree(ctx->h_counters[k]);

@@ -14,8 +14,6 @@ struct fh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;   // main stream: everything the caller can observe is ordered on it
   hipStream_t aux_stream[2] = {nullptr, nullptr};  // passes j % n_slots != 0 of fh_render run here, overlapping the latency-bound ends of the passes before
-  hipStream_t shade_stream[3] = {nullptr, nullptr, nullptr};  // FH_SHADE_STREAM (experiment): route / shade / sort launches of pass slot k on a stream of their own (=2: of high priority)
-  std::vector<hipEvent_t> ev_shade[3];                          // (traced, shaded) per bounce of the pass in slot k
   std::string err;
   uint32_t flags = 0;
 
@@ -92,8 +90,6 @@ struct fh_ctx {
   bool use_bvh8 = false;
   int builder_choice = 0;  // 0 = not decided for this scene, 1 = radix tree (LBVH), 2 = PLOC; decided at the first build after an upload
   double bvh_build_ms = 0.0;
-  double stats_sah_before = 0.0, stats_sah_after = 0.0, stats_sah_ms = 0.0;  // summed inner-node area of the binary tree before / after the reinsertion rounds of the last full build
-  int stats_sah_rounds = 0;
   float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};  // padded world bounds of the geometry
 
   // frame state
@@ -167,8 +163,6 @@ struct fh_ctx {
     bool coop = true;               // FH_COOP=0: per-lane triangle loop
     bool stream = true;             // FH_STREAM=0: one fixed batch per wave; FH_STREAM=1: streaming whatever the size of the tree
     bool stream_forced = false;
-    uint32_t stream_wgs_per_cu = 0; // FH_STREAM_WGS: workgroups per CU of the streaming kernels (0 = the kernels' LDS budget decides)
-    uint32_t stream_grid = 0;       // FH_STREAM_GRID: blocks (0 = n_cus * workgroups per CU)
     uint32_t stream_refill = 24;    // FH_STREAM_REFILL: idle lanes that trigger a refill
     uint32_t stream_min_rays = 64;  // FH_STREAM_MIN_RAYS: queue entries per wave below which workgroups of a streaming launch stay out (render.hip: stream_block_idle); 0 = all take part
     bool overlap_secondary = true;  // FH_OVERLAP=0: single-pass calls keep every launch on one stream
@@ -177,7 +171,6 @@ struct fh_ctx {
     uint32_t sky_blocks_per_cu = 0; // FH_SKY_BLOCKS: workgroups per CU k_sky_pixels is launched with (grid-stride over the sky pixels); 0 = one thread per pixel
     bool poison_pools = false;      // FH_POISON=1: new path pools are filled with 0xa5 before their first use (tests: nothing may read what nobody wrote)
     bool merge_trace = true;        // FH_MERGE=0: single-pass calls trace secondary rays and the next bounce's closest-hit rays in two launches (two streams) instead of one
-    uint32_t shade_stream = 0;      // FH_SHADE_STREAM=1|2 (experiment, profiles/README.md r4): the shade-side launches of a pass on their own stream, 2: of high priority
     uint32_t shade_wgs = 0;         // FH_SHADE_WGS=2|3: workgroups per CU the shade kernels are compiled for (0: three; until r5-12 for textured scenes that stream only)
     uint32_t stack_lds_entries = 0; // FH_STACK_LDS=n: stack levels the streaming kernels keep in LDS (0: as many as cost no workgroup; 99: all)
     bool sort_small = false;        // FH_SORT_SMALL=1: cell-order the bounce queues of trees the fixed-batch kernels trace as well
@@ -188,15 +181,12 @@ struct fh_ctx {
                                          // whose items are whole paths with two to four rays each, loses with more than 64: 113.9 -> 115.7 ms at 128)
     uint32_t tail_depth = 0;        // FH_TAIL_DEPTH: fixed number of wavefront bounces before k_tail
     uint32_t tail_paths = 0;        // FH_TAIL_PATHS: survivors at which the adaptive mode switches to k_tail; 0 = 65536, 262144 for passes of at most 4 Mi paths
-    uint32_t sub_passes = 1;        // FH_SUBPASS=n (measured, profiles/README.md r5-4; off): a call that fits one pass is cut into n pixel sub-passes on the pass streams
-    uint32_t sub_pass_min_paths = 1u << 19;  // FH_SUBPASS_MIN: ... from this many camera paths on
     uint32_t bottom_up = 2;         // FH_BOTTOM_UP=0: every ray starts its traversal at the root; =1: first-hit rays of scenes without cut-outs start at the wide node that holds the face
                                     // they leave and climb; default (2): the first passes after a build try both and the counted test rounds per shaded path decide (render.hip)
     bool sort_queues = true;        // FH_SORT=0: trace the bounce queues in emission order
     uint32_t sort_onepass = 2;      // FH_SORT_ONEPASS: cell sorts in calls of ONE pass -- 0 none, 1 all (as in multi-pass calls), 2 only the queue the fused tail takes over
     bool debug_tail = false;        // FH_DEBUG_TAIL
     bool force_alpha = false;       // FH_FORCE_ALPHA=1 (timing experiments): the kernels with the any-hit path compiled in, whatever the scene
-    bool ignore_alpha = false;      // FH_NO_ALPHA=1 (timing experiments only: wrong images): cut-out textures are not tested during traversal
   } tun;
 
   // bloom weights of the last sigma used (post.hip): no allocation, upload or host synchronisation per frame

@@ -112,18 +112,11 @@ FH_D float4 tex_rgba(const SceneDev& sc, int id, float u, float v)
   fht_tex2d(&sc.textures[id], sc.srgb_lut, u, v, o);
   return make_float4(o[0], o[1], o[2], o[3]);
 }
-#ifndef FH_OPACITY_MICROMAP
-#define FH_OPACITY_MICROMAP 1
-#endif
 __device__ __attribute__((noinline)) bool alpha_pass(const SceneDev& sc, uint32_t prim, float bu, float bv)
 {
   // one 64-byte record per face (capi.hip: rebuild_device_scene): texture coordinates of the three vertices + the textures that can actually cut
   // (a texture whose every texel is opaque is not listed: a filtered fetch of it cannot come out below 0.5)
-#if defined(FH_ALPHA_STUB) && FH_ALPHA_STUB == 1
-  return true;  // (measurement only: the kernels with the any-hit test compiled in, every candidate accepted without a look at its texture)
-#endif
   const uint4* r = sc.alpha_rec + 8 * (size_t)prim;
-#if FH_OPACITY_MICROMAP
   {  // the face's opacity micromap (capi.hip: rebuild_device_scene): 16 x 16 cells of the hit's barycentrics, two bits each -- decided at upload for every point of the cell
     const uint32_t ci = (uint32_t)fminf(fmaxf(bu, 0.0f) * 16.0f, 15.0f), cj = (uint32_t)fminf(fmaxf(bv, 0.0f) * 16.0f, 15.0f);
     const uint32_t cell = cj * 16u + ci;
@@ -131,7 +124,6 @@ __device__ __attribute__((noinline)) bool alpha_pass(const SceneDev& sc, uint32_
     if (st == 1u) return true;
     if (st == 2u) return false;
   }
-#endif
   const uint4 q0 = r[0], q1 = r[1], q2 = r[2];  // (the alpha texture's entry, r[3], is read where a face has one: most cut-outs sit in the base colour's alpha)
   const float bw = 1.0f - bu - bv;
   const float tu = bw * __uint_as_float(q0.x) + bu * __uint_as_float(q0.z) + bv * __uint_as_float(q1.x);
@@ -139,9 +131,6 @@ __device__ __attribute__((noinline)) bool alpha_pass(const SceneDev& sc, uint32_
   const uint32_t flags = q1.z;
   if (flags & 1u) {  // alpha of the base-colour texture
     const uint8_t* tex = (const uint8_t*)(const __attribute__((address_space(1))) uint8_t*)(uintptr_t)(((unsigned long long)q2.y << 32) | q2.x);  // (a pointer into global memory: four global loads instead of flat ones)
-#if defined(FH_ALPHA_STUB) && FH_ALPHA_STUB == 2
-    { const float a = fht_tex2d_channel8(tex, q2.z, q2.w, nullptr, 3u, tu, tv); asm volatile("" ::"v"(a)); return true; }  // (measurement only: the whole fetch, every candidate accepted)
-#endif
     if (fht_tex2d_channel8(tex, q2.z, q2.w, nullptr, 3u, tu, tv) < 0.5f) return false;
   }
   if (flags & 2u) {  // red of the alpha texture
@@ -257,9 +246,6 @@ FH_D uint32_t octant_permute(uint32_t m, uint32_t oct)
 // down by two units (v_rcp_f32 is good to one), so a box that starts just before tmax is never cut off.  tmax < 0: every scaled interval is reversed, so no child with a proper box is hit, as with the unscaled
 // comparison (an empty slot's inverted box can be flagged then: its triangle slot holds the degenerate triangle no ray hits); tmax = 0: the scale is infinite and children may be flagged, but no triangle is accepted (the ray's hit record starts at its tmax); a NaN tmax
 // counts as no limit in v_min_f32, as it did in the minimum of the unscaled form.  (tmax = +0 no longer reaches the division: see the floor in node8_test.)
-#ifndef FH_NODE_SLACK
-#define FH_NODE_SLACK 1
-#endif
 FH_D float fma_clamp01(float a, float b, float c)
 {
   float r;
@@ -302,7 +288,7 @@ FH_D uint32_t node8_test(const Ray8& r, const uint4 n0, const uint4 n1, const ui
   // triangle test itself makes of a ray from far away; so the near planes of every axis are moved in and the far planes out by 2^-21 of that axis' own offset:
   // nothing next to the padding for a ray that starts in or near the scene, and what keeps a thin box from being skipped by a camera far outside it.
   // Six FMA-class instructions per node, which issue beside the others.
-  const float kSlack = FH_NODE_SLACK ? 4.76837158203125e-7f : 0.0f;  // (FH_NODE_SLACK=0: timing experiments only)
+  const float kSlack = 4.76837158203125e-7f;
   const float fx = fmaf(fabsf(ox), kSlack, ox), fy = fmaf(fabsf(oy), kSlack, oy), fz = fmaf(fabsf(oz), kSlack, oz);
   const float nx = fmaf(fabsf(ox), -kSlack, ox), ny = fmaf(fabsf(oy), -kSlack, oy), nz = fmaf(fabsf(oz), -kSlack, oz);
   uint32_t hits = 0;
@@ -334,49 +320,8 @@ FH_D Ray8 ray8_prepare(const RayPre& rp, f3 d)
   return r;
 }
 
-#ifndef FH_NODE_FETCH_PAIR
-#define FH_NODE_FETCH_PAIR 0
-#endif
-// Node fetch by PAIRS of lanes (streaming kernels, FH_NODE_FETCH_PAIR=1; measured, see tools/micro/node_visit.hip and profiles/README.md).  Every lane of a node load asks the
-// vector L1 for its own line, four times per node; here the two lanes of a pair read BOTH their nodes together, 32 contiguous bytes each, so a load instruction touches one line
-// per pair and a node visit 128 lines per wave instead of 256, and one butterfly of v_cndmask_b32 with a DPP operand (16 instructions) hands every lane the halves its partner
-// read for it.  Called by all 64 lanes together (a DPP operand of a lane that is switched off is not read): a lane without a visit lends its loads to its partner's node.
-FH_D void node8_fetch_pair(const Bvh8Dev& bvh, bool visit, uint32_t ni, uint4& n0, uint4& n1, uint4& n2, uint4& n3)
-{
-  const uint32_t lane = __lane_id();
-  const bool odd = (lane & 1u) != 0u;
-  const uint32_t mine = visit ? ni : 0xffffffffu;
-  const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xb1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]: the partner's node
-  uint32_t i_even = odd ? other : mine, i_odd = odd ? mine : other;
-  i_even = i_even == 0xffffffffu ? i_odd : i_even;
-  i_odd = i_odd == 0xffffffffu ? i_even : i_odd;
-  if (i_even == 0xffffffffu) i_even = i_odd = 0u;  // neither lane visits a node: any line will do
-  const uint32_t half = odd ? 32u : 0u;
-  const uint4* pe = (const uint4*)((const char*)bvh.nodes + ((i_even << 6) + half));
-  const uint4* po = (const uint4*)((const char*)bvh.nodes + ((i_odd << 6) + half));
-  const uint4 e0 = pe[0], e1 = pe[1], o0 = po[0], o1 = po[1];  // my half of the even lane's node, my half of the odd lane's node
-  // even lane: pieces 0, 1 are its own e0, e1 and pieces 2, 3 the partner's e0, e1; odd lane: pieces 2, 3 are its own o0, o1 and pieces 0, 1 the partner's o0, o1
-  const unsigned long long even_mask = 0x5555555555555555ull, odd_mask = 0xaaaaaaaaaaaaaaaaull;
-#define FH_PAIR_BUTTERFLY(A, B, OA, OB)                                                                                                                 \
-  asm volatile("s_mov_b64 vcc, %16\n\t"                                                                                                                 \
-               "v_cndmask_b32_dpp %0, %12, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                  \
-               "v_cndmask_b32_dpp %1, %13, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                  \
-               "v_cndmask_b32_dpp %2, %14, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                 \
-               "v_cndmask_b32_dpp %3, %15, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                 \
-               "s_mov_b64 vcc, %17\n\t"                                                                                                                 \
-               "v_cndmask_b32_dpp %4, %8, %12, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                  \
-               "v_cndmask_b32_dpp %5, %9, %13, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                  \
-               "v_cndmask_b32_dpp %6, %10, %14, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                                                 \
-               "v_cndmask_b32_dpp %7, %11, %15, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"                                                       \
-               : "=&v"(OA.x), "=&v"(OA.y), "=&v"(OA.z), "=&v"(OA.w), "=&v"(OB.x), "=&v"(OB.y), "=&v"(OB.z), "=&v"(OB.w)                                 \
-               : "v"(A.x), "v"(A.y), "v"(A.z), "v"(A.w), "v"(B.x), "v"(B.y), "v"(B.z), "v"(B.w), "s"(even_mask), "s"(odd_mask)                          \
-               : "vcc")
-  // OA = even ? A : partner's B,  OB = odd ? B : partner's A   (v_cndmask_b32_dpp D, S0, S1, vcc: D = vcc ? S1 : dpp(S0))
-  FH_PAIR_BUTTERFLY(e0, o0, n0, n2);
-  FH_PAIR_BUTTERFLY(e1, o1, n1, n3);
-#undef FH_PAIR_BUTTERFLY
-}
-
+// (A node fetch by PAIRS of lanes -- the two lanes of a pair read both their nodes together, 32 contiguous bytes each, one butterfly of DPP selects hands every lane its halves:
+// half the L1 look-ups per visit -- was built and measured in round 4 and is slower: the transposition costs more than the look-ups.  tools/patches/r6_pruned_switches.patch)
 // one visited node: the group of its inner children the ray enters (first-child node index, octant-ordered hit bits << 24 | imask)
 // and the group of its candidate triangles (first triangle slot, one bit per slot)
 FH_D void node8_eval(const Ray8& r, uint32_t ni, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, float tmax, uint2& group, uint2& tg)
@@ -386,19 +331,13 @@ FH_D void node8_eval(const Ray8& r, uint32_t ni, const uint4 n0, const uint4 n1,
   group = make_uint2(n0.w >> 8, (octant_permute(hm & imask, r.oct) << 24) | imask);
   tg = make_uint2(8u * ni, hm & ~imask);
 }
-#ifndef FH_ANYHIT_UNORDERED
-#define FH_ANYHIT_UNORDERED 0  // (experiment: a streaming launch whose rays ALL stop at their first hit visits the children in slot order and saves the octant permutation)
-#endif
-// The top of the tree in LDS (streaming kernels, FH_TOP_LDS).  Every ray visits the root and one or two of its children: 2.5 of a secondary ray's 15 node visits on the
+// The top of the tree in LDS (streaming kernels).  Every ray visits the root and one or two of its children: 2.5 of a secondary ray's 15 node visits on the
 // soup, 17 % of the node fetches -- each of them four vector-L1 look-ups per lane, and the look-up rate of the L1 (one line per cycle and CU) is one of the two limits
 // the kernels sit on.  A workgroup stages nodes 0 .. 8 (the root and its inner children, which the breadth-first collapse numbers 1 ..) once, 576 bytes,
 // and a visit of one of them reads LDS (8 cycles per 64-lane ds_read_b128) instead.  Secondary and merged launches only; alone on the GPU the secondary launch takes
 // 103.3 -> 100.7 ms per configs[2] frame and 783 -> 743 ms per 512 spp of configs[3] (profiles/README.md r5-7).
-#ifndef FH_TOP_LDS
-#define FH_TOP_LDS 1
-#endif
 constexpr uint32_t kTopNodes = 9;
-constexpr uint32_t kTopLdsBytes = FH_TOP_LDS ? kTopNodes * 64u : 0u;
+constexpr uint32_t kTopLdsBytes = kTopNodes * 64u;
 FH_D void stage_top_nodes(const Bvh8Dev& bvh, uint4* lds_top)  // every thread of the workgroup; ends with its barrier
 {
   if (threadIdx.x < kTopNodes * 4u) lds_top[threadIdx.x] = (threadIdx.x >> 2) < bvh.n_nodes ? bvh.nodes[threadIdx.x] : make_uint4(0u, 0u, 0u, 0u);
@@ -408,7 +347,7 @@ template <bool ORDERED = true>
 FH_D void node8_visit(const Bvh8Dev& bvh, const Ray8& r, uint32_t ni, float tmax, uint2& group, uint2& tg, const uint4* top = nullptr)
 {
   uint4 n0, n1, n2, n3;
-  if (FH_TOP_LDS && top && ni < kTopNodes) {
+  if (top && ni < kTopNodes) {
     const uint4* nd = top + 4u * ni;
     n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3];
   } else {
@@ -596,31 +535,21 @@ struct CoopLds {            // per-wave slices of the block's LDS
 // ring is worked off by as many lanes as it holds entries -- when it fills up, once it holds kAlphaFlush of them, and always before a finished ray is committed.  What a ray
 // ends up with is the minimum over the same accepted candidates as before (a parked candidate only keeps the ray's limit and its first-hit stop from taking effect a few visits
 // earlier): the bits do not change.
-#ifndef FH_ALPHA_FLUSH
-#define FH_ALPHA_FLUSH 16
-#endif
-#ifndef FH_ALPHA_DEFER_MIXED
-#define FH_ALPHA_DEFER_MIXED 0  // 1 (measured twice, r4-19 and r5-3): park candidates in the kernels whose rays stop at their first hit as well
-#endif
-#ifndef FH_ALPHA_SUSPEND
-#define FH_ALPHA_SUSPEND 1      // a ray that stops at its first hit WAITS while a candidate of its is parked (0: it goes on walking the tree, round 4's r4-19 loss)
-#endif
-constexpr uint32_t kAlphaRing = 32, kAlphaFlush = FH_ALPHA_FLUSH;
+constexpr uint32_t kAlphaRing = 32, kAlphaFlush = 16;
 // which streaming kernels park: the closest-hit launch.  A ray that stops at its first hit (every secondary ray of a scene without emitters) is finished by the first candidate
 // that passes, and parked it goes on walking the tree until the ring is worked off: secondary 760 -> 835 ms per 512 spp of configs[3] with parking, closest 357 -> 329 (r4-19).
-// Round 5 built what that suggests -- the owner of a parked candidate SUSPENDED (FH_ALPHA_SUSPEND: a bit per lane next to the ring's counter, set by whoever parks, cleared
+// Round 5 built what that suggests -- the owner of a parked candidate SUSPENDED (a bit per lane next to the ring's counter, set by whoever parks, cleared
 // by alpha_flush, takes the lane out of the node visits and counts it as idle for the refill trigger) -- and measured it on the same box: secondary 752 ms testing in place,
-// 831 parked and walking on, 876 parked and suspended (profiles/README.md r5-3).  The loss is not the walking: it is the ring's LDS (seven stack levels in LDS become five),
+// 831 parked and walking on, 876 parked and suspended (profiles/README.md r5-3; tools/patches/r6_pruned_switches.patch).  The loss is not the walking: it is the ring's LDS (seven stack levels in LDS become five),
 // 32 bytes of scratch instead of 16, and lanes that wait for a round of sixteen.  In place it stays.
 template <bool MIXED, bool ALPHA>
-struct AlphaDefer { static constexpr bool value = ALPHA && (!MIXED || FH_ALPHA_DEFER_MIXED != 0); };
+struct AlphaDefer { static constexpr bool value = ALPHA && !MIXED; };
 constexpr uint32_t kAlphaLdsBytesPerWave = kAlphaRing * 16 + 16;
 constexpr uint32_t kAlphaLdsBytesPerBlock = 4u * kAlphaLdsBytesPerWave;
-FH_D unsigned long long* alpha_suspended(const CoopLds& cl) { return (unsigned long long*)(cl.aring + kAlphaRing) + 1; }  // lanes whose first-hit ray waits for a parked candidate
 FH_D void alpha_ring(CoopLds& cl, unsigned char* block_lds, uint32_t wave_in_block)
 {
   cl.aring = (uint4*)(block_lds + (size_t)wave_in_block * kAlphaLdsBytesPerWave);
-  if (__lane_id() == 0u) { *(uint32_t*)(cl.aring + kAlphaRing) = 0u; *alpha_suspended(cl) = 0ull; }
+  if (__lane_id() == 0u) *(uint32_t*)(cl.aring + kAlphaRing) = 0u;
 }
 constexpr uint32_t kCoopLdsBytesPerWave = 64 * 32 + 64 * 8 + 64 * 8 + kCoopQueue * 4;
 // static LDS of one 256-thread workgroup of a cooperative / streaming traversal kernel (the stack comes on top, dynamically)
@@ -661,7 +590,6 @@ FH_D void coop_test(const Bvh8Dev& bvh, const CoopLds& cl, uint32_t e, uint32_t&
       const uint32_t pos = atomicAdd((uint32_t*)(cl.aring + kAlphaRing), 1u);
       if (pos < kAlphaRing) {
         cl.aring[pos] = make_uint4((owner << 26) | prim, __float_as_uint(t), __float_as_uint(bu), __float_as_uint(bv));
-        if (ANY_HIT && FH_ALPHA_SUSPEND && r1.w != 0.0f) atomicOr(alpha_suspended(cl), 1ull << owner);  // the owner's ray stops at its first hit: it waits for this one (traverse_stream)
         return;
       }
     }
@@ -689,7 +617,7 @@ FH_D void alpha_flush(const CoopLds& cl, const SceneDev* sc, uint32_t at_least)
       if (cl.key[owner] == mine) cl.uv[owner] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
     }
   }
-  if (__lane_id() == 0u) { *counter = 0u; if (ANY_HIT && FH_ALPHA_SUSPEND) *alpha_suspended(cl) = 0ull; }
+  if (__lane_id() == 0u) *counter = 0u;
 }
 
 // MODE 0: every ray wants its closest hit; 1: every ray stops at its first hit; 2: per lane (`any_lane`), as in the streaming kernels
@@ -780,15 +708,6 @@ FH_D bool traverse_bvh8_coop(const Bvh8Dev& bvh, bool valid, f3 o, f3 d, float t
   return traverse_bvh8_coop_mode<ANY_HIT ? 1 : 0, COUNT, LDS, ALPHA>(bvh, valid, ANY_HIT, o, d, tmax, best, n_nodes, n_tris, ws, cl, flush, lds_column, lds_stride, sc);
 }
 
-#ifndef FH_HANDOVER_SCAN
-#define FH_HANDOVER_SCAN 1
-#endif
-#ifndef FH_BOTTOM_UP_BUILD
-#define FH_BOTTOM_UP_BUILD 1  // (the launches of first-hit rays in scenes without cut-outs can start rays below the root, traverse_stream; FH_BOTTOM_UP=1 switches it on)
-#endif
-#ifndef FH_HANDOVER_SCAN_ALPHA
-#define FH_HANDOVER_SCAN_ALPHA 1  // (0: the kernels with the any-hit test keep the ballot rounds -- the scan's registers can push them into scratch)
-#endif
 // inclusive prefix sum over the 64 lanes of a wave (all lanes active): four row_shr steps inside the rows of 16, then the row totals across the rows (row_bcast:15 / :31).
 // Written as v_add_u32 with a DPP operand -- six instructions; from __builtin_amdgcn_update_dpp the compiler makes a v_mov_b32_dpp AND an add per step.  A DPP operand
 // written by the VALU instruction before needs two wait states on gfx9 (the assembler does not add them inside an asm block): s_nop 1.
@@ -868,9 +787,9 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   // microsecond gained.)  Rays that want their closest hit start at the root: they climb every level anyway.
   // Compiled into the secondary launch of scenes without cut-outs only (kUp): the kernels with the any-hit test have no register for it, and neither has the merged launch of
   // one-pass calls, which carries two policies' state (with the climb and the round counters compiled in it went to 12-32 bytes of scratch and a 16-spp call of configs[3]
-  // from 51.6 to 56.2 ms); not with the pair fetch (FH_NODE_FETCH_PAIR), whose visit does not fetch links.  Whether a scene starts its rays this way is decided per scene by
+  // from 51.6 to 56.2 ms).  Whether a scene starts its rays this way is decided per scene by
   // the host from the round counters below (render.hip; FH_BOTTOM_UP=0 / 1 forces either): dense scenes gain 2-5 % of a frame, interiors of long rays lose 2 %.
-  constexpr bool kUp = FH_BOTTOM_UP_BUILD != 0 && FH_NODE_FETCH_PAIR == 0 && MIXED && !ALPHA && LDS && Policy::can_climb;
+  constexpr bool kUp = MIXED && !ALPHA && LDS && Policy::can_climb;
   bool up = false, fresh = false;
   Ray8 r;
   r.o = mk3(0.0f); r.inv = mk3(1.0f); r.oct = 0u; r.nx = r.ny = r.nz = false;
@@ -882,11 +801,8 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
   bool dry = false;                  // wave-uniform: a refill found no work at all
   uint32_t ray_n0 = 0;               // instrumented build: node counter when the lane's ray started
   cl.key[lane] = 0ull;
-  constexpr bool kSuspend = AlphaDefer<MIXED, ALPHA>::value && MIXED && FH_ALPHA_SUSPEND != 0;
   for (;;) {
-    // (lanes whose first-hit ray has a candidate parked for its any-hit test wait: they take no node visit and count as idle, coop_test / alpha_flush)
-    const bool waiting = kSuspend && ((*alpha_suspended(cl) >> lane) & 1ull) != 0ull;
-    const unsigned long long idle = __ballot(!busy || waiting);
+    const unsigned long long idle = __ballot(!busy);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
     if (n_idle == 64u || (!dry && n_idle >= refill)) {
       // every candidate of a finished ray must be tested before the ray is committed: drain the queue
@@ -943,7 +859,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
     }
     uint2 tg = make_uint2(0u, 0u);
     float best_t = 0.0f;
-    bool walk = busy && !(kSuspend && ((*alpha_suspended(cl) >> lane) & 1ull) != 0ull);  // (read again: a refill above has worked the ring off)
+    bool walk = busy;
     if (walk) {
       const unsigned long long k = cl.key[lane];
       best_t = __uint_as_float((uint32_t)(k >> 32));
@@ -965,29 +881,12 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       } else group = stack.pop();
     }
     if (kUp && __ballot(walk) != 0ull) ++cost_node;
-#if FH_NODE_FETCH_PAIR
-    uint32_t ni = 0u;
     if (walk) {
       const uint32_t hits_imask = group.y;
       const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
       group.y &= ~(1u << bit);
       if (group.y & 0xff000000u) stack.push(group);
-      const uint32_t slot = (bit - 24u) ^ r.oct;
-      ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
-      if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
-    }
-    {
-      uint4 n0, n1, n2, n3;
-      node8_fetch_pair(bvh, walk, ni, n0, n1, n2, n3);  // (all 64 lanes)
-      if (walk) node8_eval(r, ni, n0, n1, n2, n3, best_t, group, tg);
-    }
-#else
-    if (walk) {
-      const uint32_t hits_imask = group.y;
-      const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
-      group.y &= ~(1u << bit);
-      if (group.y & 0xff000000u) stack.push(group);
-      constexpr bool ordered = !(FH_ANYHIT_UNORDERED && Policy::all_any);
+      constexpr bool ordered = true;  // (slot order for launches whose rays ALL stop at their first hit -- no octant permutation -- was measured and is not faster: tools/patches/r6_pruned_switches.patch)
       const uint32_t slot = ordered ? (bit - 24u) ^ r.oct : bit - 24u;
       const uint32_t ni = group.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
       if (COUNT) { n_nodes++; if (ws && first_active_lane()) ws->node++; }
@@ -997,8 +896,7 @@ FH_D void traverse_stream(const Bvh8Dev& bvh, Policy& pol, uint32_t& n_nodes, ui
       if (kUp && climbing) group.y &= ~(1u << (24u + (ordered ? (stack.anchor_skip() ^ r.oct) : stack.anchor_skip())));  // the child the ray came up through has been walked
       if (kUp && (climbing || fresh)) { stack.set_anchor_word(next_link); fresh = false; }
     }
-#endif
-    if (FH_HANDOVER_SCAN && (!ALPHA || FH_HANDOVER_SCAN_ALPHA)) {
+    {
     // one wave prefix sum of the lanes' candidate counts (six DPP adds) and a single scatter, instead of one ballot round per candidate of the fullest lane (~15 instructions
     // per round, 2-3 rounds per visit): secondary 842 -> 825 ms per 512 spp of configs[3], 112.6 -> 110.3 ms per configs[2] frame (profiles/README.md r4-1).  The ring holds 128
     // entries, so a visit that would overfill it -- more than 64 candidates on top of a queue below 64 -- falls back to the rounds

@@ -58,9 +58,6 @@ constexpr uint32_t kMatLds = 32;  // material records staged in LDS by the shade
 #ifndef FH_STREAM_BLOCKS_CLOSEST
 #define FH_STREAM_BLOCKS_CLOSEST FH_STREAM_BLOCKS  // the same for the closest-hit kernel, which needs fewer registers than the secondary-ray kernel
 #endif
-#ifndef FH_BLOCK_PUSH
-#define FH_BLOCK_PUSH 1  // (0, A/B only: k_generate and k_shade append to their queues with one returning atomic per wave instead of one per workgroup)
-#endif
 #ifndef FH_SHADE_BLOCKS
 #define FH_SHADE_BLOCKS 2  // resident workgroups per CU the specialised shade kernels are compiled for (register budget = 512 / that per lane): they take 159-182 registers
 #endif                     // since their products go to memory as they are made (PoolSink); the generic seven-lobe kernel keeps one wave per SIMD (350 registers).
@@ -194,17 +191,10 @@ __global__ void __launch_bounds__(kBlock) k_generate(FrameDev fr, PoolDev pool, 
         pool.flags[p] = 2u;  // finished here and in no queue: only k_accumulate reads the slot again (radiance and flags)
       }
     }
-#if !FH_BLOCK_PUSH
-    queue_push(&pool.counters[CNT_RAD], pool.q_rad[0], enter, p);  // (A/B: one atomic per wave, as before round 4)
-#else
     const unsigned long long m = __ballot(enter);
     if ((threadIdx.x & 63u) == 0u) scratch[4 * c + (threadIdx.x >> 6)] = (uint32_t)__popcll(m);
     packed |= ((enter ? 0x80u : 0u) | (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull))) << (8 * c);
-#endif
    }
-#if !FH_BLOCK_PUSH
-   continue;
-#endif
    __syncthreads();
    if (threadIdx.x == 0u) {
      uint32_t total = 0;
@@ -533,7 +523,7 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : FH_STREAM_BLOCKS_CLOSEST) 
   WaveSteps ws;
   ClosestStream<COUNT> pol(pool, pool.q_rad[depth & 1u], ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_CLOSEST, count, stream_chunk_for(count, chunk)), tc.hist);
   extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];  // the traversal stack of every lane: [entry][thread], as many entries as the BVH has levels
-  // (no LDS copy of the top nodes here, fh_trace.h FH_TOP_LDS: the closest-hit launch gained 0.9 % alone on configs[2] and LOST 1.7 % on configs[3], where the ring of parked any-hit tests already takes its LDS)
+  // (no LDS copy of the top nodes here, fh_trace.h stage_top_nodes: the closest-hit launch gained 0.9 % alone on configs[2] and LOST 1.7 % on configs[3], where the ring of parked any-hit tests already takes its LDS)
   traverse_stream<false, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill);
   stamp.commit(tc.clk);
   if (COUNT) {
@@ -1047,11 +1037,6 @@ __global__ void __launch_bounds__(kBlock, (LOBES == L_ALL ? 1 : BLOCKS)) k_shade
       cont = o.cont;
       if (shaded || cont) cell = cell_of(fr, o.origin);
     }
-#if !FH_BLOCK_PUSH
-    queue_push_keyed(&cnt[CNT_SEC], pool.q_sec, pool.key_sec, shaded, p, cell);
-    queue_push_keyed(&cnt_next[CNT_RAD], pool.q_rad[qnext], pool.key_rad, cont, p, cell);
-    continue;
-#endif
     // queue positions of both appends: one returning atomic per workgroup and queue (fh_device.h: block_queue_reserve)
     uint32_t* const counters2[2] = {&cnt[CNT_SEC], &cnt_next[CNT_RAD]};
     const bool act[2] = {shaded, cont};
@@ -1293,9 +1278,9 @@ __global__ void __launch_bounds__(kBlock, COUNT ? 1 : (LIGHTS ? FH_SECONDARY_BLO
   uint32_t nn = 0, nt = 0;
   WaveSteps ws;
   SecondaryStream<COUNT, LIGHTS> pol(sc, fr, pool, ChunkFeed(pool.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)), tc.hist);
-  __shared__ uint4 lds_top[FH_TOP_LDS ? kTopNodes * 4 : 1];
-  if (FH_TOP_LDS) stage_top_nodes(sc.bvh8, lds_top);
-  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr,
+  __shared__ uint4 lds_top[kTopNodes * 4];
+  stage_top_nodes(sc.bvh8, lds_top);
+  traverse_stream<true, COUNT, true, ALPHA>(sc.bvh8, pol, nn, nt, &ws, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, lds_top,
                                             spill.probe ? pool.counters + depth * kCounterStride + CNT_COST_NODE : nullptr);
   pol.finish();
   stamp.commit(tc.clk);
@@ -1366,9 +1351,9 @@ __global__ void __launch_bounds__(kBlock, LIGHTS ? FH_SECONDARY_BLOCKS_HEAVY : (
   AlphaLds<AlphaDefer<true, ALPHA>::value>::attach(cl);  // candidates waiting for their any-hit test (fh_trace.h: alpha_ring): LDS of the kernels with the test compiled in only
   uint32_t nn = 0, nt = 0;
   MergedStream<LIGHTS> pol(sc, fr, ps, pn, pn.q_rad[(depth + 1u) & 1u], n_sec, ChunkFeed(ps.counters + depth * kCounterStride + CNT_CUR_SEC, count, stream_chunk_for(count, chunk)));
-  __shared__ uint4 lds_top[FH_TOP_LDS ? kTopNodes * 4 : 1];
-  if (FH_TOP_LDS) stage_top_nodes(sc.bvh8, lds_top);
-  traverse_stream<true, false, true, ALPHA>(sc.bvh8, pol, nn, nt, nullptr, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, FH_TOP_LDS ? lds_top : nullptr,
+  __shared__ uint4 lds_top[kTopNodes * 4];
+  stage_top_nodes(sc.bvh8, lds_top);
+  traverse_stream<true, false, true, ALPHA>(sc.bvh8, pol, nn, nt, nullptr, cl, flush, refill, lds_stack, (int)sc.bvh8.depth, &sc, spill, lds_top,
                                             spill.probe ? ps.counters + depth * kCounterStride + CNT_COST_NODE : nullptr);
   pol.sec.finish();
   stamp.commit(tc.clk);
@@ -1711,7 +1696,7 @@ SceneDev scene_dev(const fh_ctx* ctx)
   s.srgb_lut = ctx->d_srgb_lut;
   s.n_textures = ctx->n_textures;
   s.alpha_rec = ctx->d_alpha_rec;
-  s.has_alpha = ((ctx->has_alpha && !ctx->tun.ignore_alpha) || ctx->tun.force_alpha) ? 1u : 0u;
+  s.has_alpha = (ctx->has_alpha || ctx->tun.force_alpha) ? 1u : 0u;
   s.bvh2.nodes = ctx->d_bvh2_nodes;
   s.bvh2.tris = ctx->d_bvh2_tris;
   s.bvh2.n_nodes = ctx->bvh2_n_nodes;
@@ -1725,7 +1710,7 @@ SceneDev scene_dev(const fh_ctx* ctx)
   // bottom-up start (fh_trace.h): rays that leave a surface begin at the wide node that holds the face.  Only the streaming kernels climb; they trace trees of 4096 nodes and more
   // (what the scene CAN do; render_submit switches it per pass: forced by FH_BOTTOM_UP, else by what the first passes of the scene measure)
   const bool bottom_up = ctx->tun.bottom_up != 0 && ctx->use_bvh8 && ctx->d_bvh8_parent && ctx->d_face_node && ctx->tun.coop && ctx->tun.stream && (ctx->tun.stream_forced || ctx->bvh8_n_nodes >= 4096u) &&
-                         ctx->bvh8_n_tris < kCoopMaxTris && !(((ctx->has_alpha && !ctx->tun.ignore_alpha) || ctx->tun.force_alpha));
+                         ctx->bvh8_n_tris < kCoopMaxTris && !((ctx->has_alpha || ctx->tun.force_alpha));
   s.bvh8.parent = bottom_up ? ctx->d_bvh8_parent : nullptr;
   s.face_node = bottom_up ? ctx->d_face_node : nullptr;
   return s;
@@ -1747,7 +1732,7 @@ int kernel_info(fh_ctx* ctx, int which, uint32_t out[6])
     out[0] = (uint32_t)sa.numRegs; out[1] = (uint32_t)sa.sharedSizeBytes; out[2] = (uint32_t)sa.localSizeBytes; out[3] = (uint32_t)(blocks > 0 ? blocks : 0); out[4] = compiled; out[5] = ctx->class_lobes[c];
     return FH_OK;
   }
-  const bool alpha = (ctx->has_alpha && !ctx->tun.ignore_alpha) || ctx->tun.force_alpha;
+  const bool alpha = ctx->has_alpha || ctx->tun.force_alpha;
   hipFuncAttributes at{};
   hipError_t e = hipSuccess;
   with_bool(alpha, [&](auto A) {
@@ -1768,7 +1753,6 @@ void pool_release(fh_ctx* ctx)
 {
   (void)hipStreamSynchronize(ctx->stream);  // nothing may still be running out of the buffers (the counter snapshots trail the accumulate)
   for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(ctx->aux_stream[k]);
-  for (int k = 0; k < 3; ++k) if (ctx->shade_stream[k]) (void)hipStreamSynchronize(ctx->shade_stream[k]);
   if (ctx->sky_stream) (void)hipStreamSynchronize(ctx->sky_stream);
   for (int k = 0; k < 3; ++k) {
     for (void* p : ctx->pool_allocs[k]) (void)hipFree(p);
@@ -2180,13 +2164,12 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     uint32_t w = tun.lds_per_cu / (bytes + static_lds);
     w = w > compiled_for ? compiled_for : (w < 1u ? 1u : w);
     if (stream && reported && reported < w) w = reported;
-    if (tun.stream_wgs_per_cu && tun.stream_wgs_per_cu < w) w = tun.stream_wgs_per_cu;
     return w;
   };
   const uint32_t wgs_closest = wgs_for(stream_stack_bytes, static_lds_closest, FH_STREAM_BLOCKS_CLOSEST, ctx->occupancy_blocks);
   const uint32_t wgs_secondary = wgs_for(stream_stack_bytes_secondary, static_lds_secondary, FH_STREAM_BLOCKS > FH_SECONDARY_BLOCKS_HEAVY ? FH_STREAM_BLOCKS : FH_SECONDARY_BLOCKS_HEAVY, ctx->occupancy_blocks_secondary);
-  const uint32_t stream_grid = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_closest;
-  const uint32_t stream_grid_secondary = tun.stream_grid ? tun.stream_grid : tun.n_cus * wgs_secondary;
+  const uint32_t stream_grid = tun.n_cus * wgs_closest;
+  const uint32_t stream_grid_secondary = tun.n_cus * wgs_secondary;
   // spill area of the streaming launches: [launch in flight: pass slot x (closest, secondary)][entry beyond the LDS part][thread of the launch]
   const uint32_t spill_entries = stream_entries < stream_need ? stream_need - stream_entries : 0u;
   const uint32_t spill_entries_secondary = stream_entries_secondary < stream_need ? stream_need - stream_entries_secondary : 0u;
@@ -2212,27 +2195,8 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
   const bool sort_queues = tun.sort_queues && (stream || tun.sort_small);
   const bool shade_three = tun.shade_wgs ? tun.shade_wgs == 3u : true;  // (above, FH_SHADE_BLOCKS)
 
-  // ---- Small calls (the reference's callers: 1 sample per call in the GUI, controller.cpp:224, 16 in rtcamp8, rtcamp8.cpp:183-189).  A call that fits ONE pass is a chain of
-  // ~50 launches, each of which ends in its few longest rays with the chip nearly idle, and the chain is as long as those ends added up.  Such a call is cut into PIXEL
-  // sub-passes instead: the owned pixels in three contiguous ranges, each range a pass of its own in its own pool on its own stream.  Nothing orders them but what orders any
-  // two passes (below) -- they share no pixel -- so one range's ends run under another's bulk.  Sampler keys are per pixel: same bits.  MEASURED (r5-4) and OFF (FH_SUBPASS=3
-  // switches it on): 1-spp frames get SLOWER, configs[3] 6.45 -> 8.24 ms with three ranges and 7.56 with two, configs[2] 1.95 -> 2.59 / 1.95; 16-spp frames are unchanged
-  // (configs[1]: 13.6 -> 12.8 ms).  Three times the launches cost the host three times the submission, and the chains do not leave the chip as idle as their length suggests.
-  uint32_t n_sub = 1;
-  {
-    const bool one_pass = batch >= n_samples;
-    const bool serial_call = quirk || (ctx->flags & FH_FLAG_SERIAL_PASSES) != 0;
-    if (one_pass && !serial_call && !count && ctx->n_slots >= 2 && tun.sub_passes > 1u && (unsigned long long)n_px * n_samples >= (unsigned long long)tun.sub_pass_min_paths) n_sub = tun.sub_passes < (uint32_t)ctx->n_slots ? tun.sub_passes : (uint32_t)ctx->n_slots;
-  }
-  const uint32_t* const px_list_all = px_list;
-  const uint32_t* const xy_list_all = xy_list;
-  const uint32_t n_px_all = n_px;
-  for (uint32_t sub = 0; sub < n_sub; ++sub) {
-  if (n_sub > 1) {  // pixels [lo, hi) of the list (whole 64-pixel runs, so that a wave of k_generate does not straddle two sub-passes)
-    const uint32_t per = ((n_px_all + n_sub - 1u) / n_sub + 63u) & ~63u;
-    const uint32_t lo = sub * per < n_px_all ? sub * per : n_px_all, hi = lo + per < n_px_all ? lo + per : n_px_all;
-    px_list = px_list_all + lo; xy_list = xy_list_all + lo; n_px = hi - lo;
-  }
+  // (Small calls -- the reference's callers: 1 sample per call in the GUI, controller.cpp:224, 16 in rtcamp8, rtcamp8.cpp:183-189 -- cut into PIXEL sub-passes, each a pass of
+  // its own in its own pool on its own stream, were built and measured in round 5: slower, configs[3] 1 spp 6.45 -> 8.24 ms.  tools/patches/r6_pruned_switches.patch, r5-4.)
   for (uint32_t done = 0; done < n_samples && n_px; done += batch) {
     const uint32_t nb = (n_samples - done) < batch ? (n_samples - done) : batch;
     const uint32_t n_paths = n_px * nb;
@@ -2257,7 +2221,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
     const bool single_pass = !serial && batch >= n_samples && n_samples == nb;
     // ... or, where the streaming kernels trace the scene, both in ONE launch (k_trace_merged_stream): one end instead of two, no second stream (FH_MERGE=0: the two-stream form)
     const bool merge = single_pass && stream && !count && tun.merge_trace;
-    const bool overlap = single_pass && tun.overlap_secondary && !merge && n_sub == 1;  // (pixel sub-passes: the other streams carry the other pixel ranges)
+    const bool overlap = single_pass && tun.overlap_secondary && !merge;
     hipStream_t sb = st;
     if (overlap) {
       sb = (st == ctx->aux_stream[0]) ? ctx->aux_stream[1] : ctx->aux_stream[0];
@@ -2267,16 +2231,9 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         ctx->ev_bounce.push_back(e);
       }
     }
-    // FH_SHADE_STREAM (experiment): the shade side of every bounce -- routing, shade kernels, queue sorts -- on a stream of its own (optionally of high priority), ordered
-    // against the pass's traversal launches by events
-    const bool shade_sep = !serial && !overlap && tun.shade_stream != 0 && ctx->shade_stream[slot] != nullptr;
-    hipStream_t sh = shade_sep ? ctx->shade_stream[slot] : st;
-    if (shade_sep)
-      while (ctx->ev_shade[slot].size() < 2u * (max_depth + 1u)) {
-        hipEvent_t e = nullptr;
-        FH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->ev_shade[slot].push_back(e);
-      }
+    // (The shade side of every bounce -- routing, shade kernels, queue sorts -- on a stream of its own, optionally of high priority, with the pass streams kept off some CUs,
+    // was measured in round 4 and is slower: r4-6, tools/patches/r6_pruned_switches.patch.)
+    hipStream_t sh = st;
     { const int rc = pool_ensure(ctx, slot, n_px * batch); if (rc) return rc; }
     const PoolDev& pool = ctx->pool[slot];
     FH_HIP(hipMemsetAsync(pool.counters, 0, sizeof(uint32_t) * kCounterStride * (max_depth + 1), st));
@@ -2373,7 +2330,6 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         ctx->stats.n_closest_launches++;
       }
       if (quirk && depth == 0) hipLaunchKernelGGL(k_firsthit_scan, dim3(grid_for(n_px)), dim3(kBlock), 0, st, pd, px_list, n_px, nb, ctx->d_quirk_seen);
-      if (shade_sep) { FH_HIP(hipEventRecord(ctx->ev_shade[slot][2u * depth], st)); FH_HIP(hipStreamWaitEvent(sh, ctx->ev_shade[slot][2u * depth], 0)); }
       {
         Span sp(ctx, sh, 6);
         hipLaunchKernelGGL(k_route, dim3(grid), dim3(kBlock), 0, sh, sc, pd, depth, ctx->n_classes, count ? ctx->d_trace_counters + 26 : nullptr);
@@ -2406,7 +2362,6 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
           q_spare = unsorted;       // ... and the buffer it came from is the next scratch target
         }
       }
-      if (shade_sep) { FH_HIP(hipEventRecord(ctx->ev_shade[slot][2u * depth + 1u], sh)); FH_HIP(hipStreamWaitEvent(st, ctx->ev_shade[slot][2u * depth + 1u], 0)); }
       if (merge && depth + 1u < wave_depth) {
         Span sp(ctx, st, 1);
         with_bool(sc.n_lights > 0, [&](auto Li) { with_bool(sc.has_alpha != 0, [&](auto A) {
@@ -2470,7 +2425,6 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       ctx->counters_bu[slot] = pass_bu;
     }
   }
-  }  // (pixel sub-passes)
   // join: later work on the main stream (pack, post-process, copies, the caller's clears) sees every pass of this call
   // (the accumulates form a chain across the streams, so the last one implies all the others)
   if (last_slot != 0 && n_px) FH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_acc[last_slot], 0));

@@ -1,8 +1,8 @@
 """The gate of a round's end (CPU; sorts last so that a red gate hides nothing else).
 
 tools/round_end.sh runs, on a CLEAN tree and in one gpurun call, `pytest -m gpu -x -q`, `__graft_entry__.smoke()` and the default `python bench.py`, and commits the log as
-profiles/rNN_final_gpu_tests.log.  The log begins with HEAD, a hash over HEAD's tree entries of every path that run depends on (tools/covered_tree_hash.py: fredholm_amd/csrc,
-include, bench.py, tests, profiles/*traffic*.json, profiles/*issue_peak.json) and bench.py's source fingerprint.  This test fails when the newest such log is not green or is
+profiles/rNN_final_gpu_tests.log.  The log begins with HEAD, a hash over HEAD's tree entries of every path that run depends on (tools/covered_tree_hash.py: fredholm_amd,
+include, oracle, bench.py, __graft_entry__.py, tests, profiles/*traffic*.json, profiles/*issue_peak.json) and bench.py's source fingerprint.  This test fails when the newest such log is not green or is
 about other contents than HEAD's: nothing under those paths may be committed after the round's final GPU run (round 4 committed a counter file after it, which changed what a
 GPU test asserted, and the driver's run stopped at test 5 of 201).
 """
@@ -52,6 +52,6 @@ def test_final_gpu_run_of_the_round_is_green_and_is_about_this_tree():
     import bench
     assert h["source_fingerprint"] == h["source_fingerprint_on_box"] == bench.source_fingerprint(), "device sources changed after the round's final GPU run: run tools/round_end.sh again"
     assert h["covered_tree_sha256"] == covered_tree_hash("HEAD"), (
-        f"{os.path.relpath(log, ROOT)} saw other contents of fredholm_amd/csrc, include, bench.py, tests or the counter files than HEAD holds: run tools/round_end.sh again")
+        f"{os.path.relpath(log, ROOT)} saw other contents of fredholm_amd, include, oracle, bench.py, __graft_entry__.py, tests or the counter files than HEAD holds: run tools/round_end.sh again")
     # the logged commit is in this history
     assert subprocess.run(["git", "-C", ROOT, "cat-file", "-e", h["git_head"] + "^{commit}"]).returncode == 0

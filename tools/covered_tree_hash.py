@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""sha256 over HEAD's tree entries (mode, blob id, path) of everything the GPU run of a round's end depends on: fredholm_amd/csrc, include, bench.py, tests,
+"""sha256 over HEAD's tree entries (mode, blob id, path) of everything the GPU run of a round's end depends on: fredholm_amd, include, oracle, bench.py, __graft_entry__.py, tests,
 profiles/*traffic*.json, profiles/*issue_peak.json.  tools/round_end.sh logs it; tests/test_zz_round_end.py compares."""
 import fnmatch
 import hashlib
@@ -8,8 +8,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DIRS = ("fredholm_amd/csrc/", "include/", "tests/")
-FILES = ("bench.py",)
+DIRS = ("fredholm_amd/", "include/", "tests/", "oracle/")  # (round 6: the whole package -- the GPU tests and bench.py import its Python half too -- and the checker)
+FILES = ("bench.py", "__graft_entry__.py")
 GLOBS = ("profiles/*traffic*.json", "profiles/*issue_peak.json")
 
 

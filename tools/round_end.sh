@@ -7,7 +7,7 @@
 # Nothing under the covered paths may be committed after this; the log itself (profiles/rNN_final_*) is not covered.
 set -euo pipefail
 cd "$(dirname "$0")/.."
-tag=${1:-r05}
+tag=${1:-r06}
 if [ -n "$(git status --porcelain)" ]; then
   echo "round_end: the tree is not clean -- commit first:" >&2
   git status --porcelain >&2
