@@ -115,7 +115,9 @@ def scaling_model(cfg, spp):
     x = min(rows, key=lambda x: abs(x["spp"] - spp))
     return {"emulated": True, "world": x["world"], "spp": x["spp"], "whole_ms": x["whole_ms"], "slowest_shard_ms": x["max_ms"], "mean_shard_ms": x["mean_ms"], "max_over_mean": x["max_over_mean"],
             "render_speedup": x["render_speedup_whole_over_max"], "efficiency": x["efficiency"], "from": x["file"],
-            "note": "one GPU rendered each rank's 32x32-tile shard in turn (tools/shard_time.py): render phase only -- the RCCL gather (4.15 MB per rank at 1080p) and rank 0's un-permutation are not in it"}
+            **({"step_speedup": x["step_speedup"], "rank0_sink_ms": x["rank0_sink"], "sharded_step_ms": x["sharded_step_ms"]} if "step_speedup" in x else {}),
+            "note": "one GPU rendered each rank's 32x32-tile shard in turn (tools/shard_time.py).  render_speedup: render phase only; step_speedup (round 6): the presented frame -- slowest shard + rank 0's "
+                    "pack, the gather PRICED at one 4.15 MB shard per xGMI link, the one-launch un-permutation (fh_unpack_shards) and the post chain.  No second GPU was involved: not a measurement of scaling"}
 
 
 def traversal_roofline(cnt, timed, key, steps, launches, avg_ms, avg_alone_ms, bytes_per_launch, kernel_name, where, bw, traffic):
