@@ -335,6 +335,8 @@ int rebuild_device_scene(fh_ctx* ctx)
     FH_HIP(hipMalloc((void**)&ctx->d_alpha_rec, rec.size() * sizeof(uint4)));
     FH_HIP(hipMemcpy(ctx->d_alpha_rec, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice));
   }
+  // (the host copies of the textures that can cut were needed for the classes and the micromaps above only: every upload brings its textures again)
+  for (fh_ctx::HostTexture& t : ctx->h_tex_host) std::vector<uint8_t>().swap(t.rgba8);
   ctx->refit_ok = false;  // new topology: the next build is a full one
   return transform_faces(ctx);
 }

@@ -805,7 +805,8 @@ def test_one_pass_calls_do_not_decide_where_rays_start(monkeypatch):
     (this 60 k-triangle soup: 728 against 733 test cycles per shaded path, so the root; the 1 M-triangle soup of configs[2]: 378 against 313, the face's node)."""
     monkeypatch.setenv("FH_STREAM", "1")
     monkeypatch.setenv("FH_BOTTOM_UP", "2")
-    monkeypatch.delenv("FH_MERGE", raising=False)
+    for k in ("FH_MERGE", "FH_PIPELINE", "FH_COOP", "FH_BVH2", "FH_FORCE_ALPHA"):  # (tools/gpu_variants.sh runs this file under each of them: the decision exists for the streaming kernels of the
+        monkeypatch.delenv(k, raising=False)                      # wide tree with three passes in flight, which is what this test is about)
     r = F.Renderer(0)
     r.load_scene(scenes.triangle_soup(60000, 0.05))
     r.build_ias()
@@ -1380,6 +1381,10 @@ def test_error_paths(oracle):
 
 # ------------------------------------------------------------------ tile sharding (multi-GPU decomposition on one GPU)
 def test_tile_ownership_matches_library_and_shards_reassemble():
+    # (FH_PIXEL_BLOCK: a developer switch of the library's pixel order inside a tile, read once per process; distributed.tile_ownership mirrors the default, 8, and takes the
+    # block as an argument -- tools/gpu_variants.sh runs this file under 0 and 4 as well)
+    blk = int(os.environ.get("FH_PIXEL_BLOCK", D.PIXEL_BLOCK))
+    blk = blk if 0 < blk <= 64 else 1 << 16
     sc = scenes.cornell_box()
     cam = F.Camera(**scenes.CORNELL_CAMERA)
     w, h, world, tw, th = 80, 56, 3, 16, 8
@@ -1398,7 +1403,7 @@ def test_tile_ownership_matches_library_and_shards_reassemble():
         r.build_ias()
         r.set_resolution(w, h)
         r.set_tile_shard(rank, world, tw, th)
-        own = D.tile_ownership(w, h, rank, world, tw, th)
+        own = D.tile_ownership(w, h, rank, world, tw, th, blk)
         assert r.owned_pixel_count() == own.size
         L = F.RenderLayer(r, w, h)
         r.render(cam, (0, 0, 0), L, 3, 4)
@@ -1418,7 +1423,8 @@ def test_tile_ownership_matches_library_and_shards_reassemble():
         r.close()
     pad = max(s.shape[0] for s in shards)
     padded = [np.concatenate([s, np.zeros((pad - s.shape[0], 4), np.float32)]) for s in shards]
-    assert np.array_equal(_bits(D.assemble(w, h, padded, tw, th)), _bits(want))
+    if blk == D.PIXEL_BLOCK:
+        assert np.array_equal(_bits(D.assemble(w, h, padded, tw, th)), _bits(want))
     # every shard back into the frame in ONE launch (fh_unpack_shards: what rank 0 calls per presented frame), from equally padded shards as the gather delivers them,
     # for several channel counts, and again after a change of resolution (the frame map is rebuilt)
     full.set_tile_shard(0, 1, tw, th)
@@ -1434,7 +1440,7 @@ def test_tile_ownership_matches_library_and_shards_reassemble():
         full.wait_for_completion()
         assert np.array_equal(_bits(dst.download(np.float32, (h, w, fpp))), _bits(want[..., :fpp]))
     full.set_resolution(w - 16, h)
-    own = [D.tile_ownership(w - 16, h, k, world, tw, th) for k in range(world)]
+    own = [D.tile_ownership(w - 16, h, k, world, tw, th, blk) for k in range(world)]
     pad2 = max(o.size for o in own)
     ramp = np.arange((w - 16) * h, dtype=np.float32)
     bufs = []
@@ -1573,7 +1579,8 @@ def test_full_size_render_is_deterministic_shard_invariant_and_matches_checker_r
     r.render(cam, (0, 0, 0), L, 2, 8)
     r.wait_for_completion()
     c = L.download("beauty").reshape(-1, 4)
-    own = D.tile_ownership(w, h, 1, 8)
+    blk = int(os.environ.get("FH_PIXEL_BLOCK", D.PIXEL_BLOCK))  # (see test_tile_ownership_matches_library_and_shards_reassemble)
+    own = D.tile_ownership(w, h, 1, 8, block=blk if 0 < blk <= 64 else 1 << 16)
     assert _same(c[own], a.reshape(-1, 4)[own])
     mask = np.ones(w * h, bool)
     mask[own] = False
