@@ -506,8 +506,8 @@ int fh_ctx_create(int device, fh_ctx** out)
     if (hipMalloc((void**)&ctx->d_sobol_bytes, bytes.size() * sizeof(uint32_t)) != hipSuccess) return bail("hipMalloc failed");
     if (hipMemcpy(ctx->d_sobol_bytes, bytes.data(), bytes.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
   }
-  (void)hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice);
-  (void)hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice);
+  if (hipMemcpy(ctx->d_lut_refl, kLutReflection, kLutReflectionBytes, hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
+  if (hipMemcpy(ctx->d_lut_sheen, kLutSheen, kLutSheenBytes, hipMemcpyHostToDevice) != hipSuccess) return bail("table upload failed");
   (void)hipMemsetAsync(ctx->d_trace_counters, 0, 32 * sizeof(unsigned long long), ctx->stream);  // (never hipMemset: it is asynchronous and ordered with nothing on a non-blocking stream)
   for (int k = 0; k < 2; ++k)
     if (make_stream(&ctx->aux_stream[k]) != hipSuccess) return bail("hipStreamCreate failed");
