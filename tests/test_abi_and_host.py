@@ -881,8 +881,8 @@ def test_counters_of_another_pass_size_are_refused():
     assert got and unusable is None and bench.pass_size_differs(got, 1024, 3, 1) is False
     got, unusable = bench.usable_counters(3, "k_trace_secondary_stream", 512, 5, 1)
     assert got and unusable is None and abs(got["submitted_spp_per_pass"] - 512 / 5) < 0.02 * 512 / 5
-    got, unusable = bench.usable_counters(3, "k_trace_secondary_stream", 540, 12, 1)  # (round 5: the general_scene leg, twelve passes of 45)
-    assert got and unusable is None and got["file"].startswith("profiles/r05_") and round(got["submitted_spp_per_pass"]) == 45
+    got, unusable = bench.usable_counters(3, "k_trace_secondary_stream", 540, 12, 1)  # (the general_scene leg, twelve passes of 45: the newest file of that pass size)
+    assert got and unusable is None and got["file"].startswith("profiles/r06_") and round(got["submitted_spp_per_pass"]) == 45
     # ... the short runs of the bench-contract test (GPUTEST_r04: configs[1] at 8 spp = 3 passes of 2.7, configs[2] at 12 spp = 3 passes of 4) get NOTHING
     for cfg, kernel, spp in ((1, "k_shade", 8), (2, "k_trace_secondary_stream", 12), (3, "k_trace_secondary_stream", 12)):
         got, unusable = bench.usable_counters(cfg, kernel, spp, 3, 1)
