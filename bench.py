@@ -168,16 +168,17 @@ def shade_record(r, cfg, spp, timed, alone, cnt, steps):
             break
         hits = max(sh.get("shaded_hits_in_counter_run") or 0, 1)
         rec.update({"valu_lane_utilisation": sh.get("valu_lane_utilisation"), "wait_any_frac_of_wave_cycles": sh.get("wait_any_frac_of_wave_cycles"), "l2_hit_rate": sh.get("tcc_hit_rate"),
-                    "valu_insts_per_hit": round(sh["valu_insts_total"] / hits, 1) if sh.get("valu_insts_total") and sh.get("shaded_hits_in_counter_run") else None,
+                    "valu_wave_insts_per_hit": round(sh["valu_insts_total"] / hits, 1) if sh.get("valu_insts_total") and sh.get("shaded_hits_in_counter_run") else None,  # SQ_INSTS_VALU counts wave64 instructions
+                    "valu_lane_insts_per_hit": round(sh["valu_insts_total"] / hits * 64.0 * sh["valu_lane_utilisation"], 0) if sh.get("valu_insts_total") and sh.get("shaded_hits_in_counter_run") and sh.get("valu_lane_utilisation") else None,
                     "fabric_bytes_per_hit": round(sh["traffic_bytes_total"] / hits, 1) if sh.get("traffic_bytes_total") and sh.get("shaded_hits_in_counter_run") else None,
                     "lds_bank_conflict_frac": sh.get("lds_bank_conflict_frac"), "counters_from": tj["file"], "counters_stale": tj.get("source_fingerprint") != source_fingerprint()})
         shares = [fma_share_of(f"k_shade<{k['compiled_for_lobes']}u, 3>") for k in rec["kernels"]]
         shares = [x["share"] for x in shares if x]
         fs = {"share": sum(shares) / len(shares)} if shares else None  # (the scene's shade kernels weigh alike here: their static mixes differ by a few per cent)
-        if fs and rec.get("valu_insts_per_hit") and alone["shade_ms"] > 0:
+        if fs and rec.get("valu_wave_insts_per_hit") and alone["shade_ms"] > 0:
             rec["fma_class_share_static"] = round(fs["share"], 4)
             cyc_mix = max(fs["share"] / VALU_FMA_PEAK_PER_CYCLE, (1.0 - fs["share"]) / VALU_OTHER_PEAK_PER_CYCLE)
-            rec["valu_busy"] = round(rec["valu_insts_per_hit"] * cnt["shaded_hits"] * cyc_mix / (alone["shade_ms"] * 1e-3 * N_SIMDS * NOMINAL_CLOCK_GHZ * 1e9), 4)
+            rec["valu_busy"] = round(rec["valu_wave_insts_per_hit"] * cnt["shaded_hits"] * cyc_mix / (alone["shade_ms"] * 1e-3 * N_SIMDS * NOMINAL_CLOCK_GHZ * 1e9), 4)
         break
     return rec
 
@@ -519,6 +520,8 @@ def general_scene_block(local_rank, tmpdir, bw, spp=540, steps=2, warmup=1, pool
         roof["counters_stale"] = not (pmc_k.get("source_fingerprint") == source_fingerprint())
         if pmc_k.get("traffic_bytes_per_launch") and f["alone"] > 0:
             roof["frac_hbm_measured"] = round(pmc_k["traffic_bytes_per_launch"] / (f["alone"] / max(launches / steps, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        if pmc_k.get("vl1d"):
+            roof["vl1d"] = dict(pmc_k["vl1d"], note="TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / (GRBM_GUI_ACTIVE / 8 XCDs) and TA_TA_BUSY_sum likewise, kernels serialised")
         fs = fma_share_of(pmc_k.get("kernel", ""))
         if fs and pmc_k.get("valu_insts_per_launch") and f["alone"] > 0:  # (as in the headline's record: executed VALU instructions per cycle and SIMD x the issue cycles of the kernel's static mix)
             per_cycle = pmc_k["valu_insts_per_launch"] / N_SIMDS / (f["alone"] / max(launches / steps, 1) * 1e-3) / 1e9 / (roof.get("clock_ghz_in_kernel") or NOMINAL_CLOCK_GHZ)
