@@ -550,6 +550,35 @@ def test_reference_firsthit_bug_compat_mode(oracle, scene_name):
     r.close()
 
 
+def test_large_one_pass_calls_of_the_bug_compat_and_measuring_modes_are_not_split():
+    """A call of more than 50 M camera paths that fits ONE pass is cut into three that overlap -- unless its passes run one after the other anyway: FH_FLAG_REFERENCE_FIRSTHIT
+    (per-pixel state carried through the launch) and FH_FLAG_SERIAL_PASSES, where a split is pure overhead.  1080p x 26 samples of the Cornell box = 54 M
+    paths: the two passes the default pool needs in either mode, three by default; and the bug-compat frame does not depend on how the call is cut (a pool of two samples per pixel: thirteen passes)."""
+    w, h, k, depth = 1920, 1080, 26, 3
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    frames = {}
+    for mode, flags, pool in (("plain", 0, None), ("serial", N.FLAG_SERIAL_PASSES, None), ("quirk", N.FLAG_REFERENCE_FIRSTHIT, None), ("quirk_small_pool", N.FLAG_REFERENCE_FIRSTHIT, w * h * 2)):
+        r = F.Renderer(0)
+        if pool:
+            r.set_path_pool(pool)
+        r.load_scene(scenes.cornell_box())
+        r.build_ias()
+        r.set_resolution(w, h)
+        L = F.RenderLayer(r, w, h)
+        r.set_flags(flags)
+        r.reset_stats()
+        r.render(cam, (0.1, 0.2, 0.4), L, k, depth)
+        r.wait_for_completion()
+        n_passes = r.stats()["n_passes"]
+        frames[mode] = L.download("beauty")
+        r.close()
+        # (the default pool holds 32 Mi paths: two passes are what the call needs; three is the cut for overlap)
+        assert n_passes == {"plain": 3, "serial": 2, "quirk": 2, "quirk_small_pool": 13}[mode], (mode, n_passes)
+    assert _same(frames["plain"], frames["serial"])              # (the cut never changes a bit)
+    assert _same(frames["quirk"], frames["quirk_small_pool"])
+    assert not _same(frames["plain"], frames["quirk"])
+
+
 @pytest.mark.parametrize("start", ["auto", "face"])
 def test_moving_instances_refit_the_tree_and_match_checker_and_rebuild(oracle, monkeypatch, start):
     """(start = "face": the streaming kernels forced, first-hit rays forced to start at the node of the face they leave -- the start node rides in the face records, which
