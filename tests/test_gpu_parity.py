@@ -1485,6 +1485,34 @@ def test_tile_ownership_matches_library_and_shards_reassemble():
     full.close()
 
 
+@pytest.mark.parametrize("world", [1, 2, 8, 16, 17, 40])
+def test_unpack_shards_for_any_number_of_ranks(world):
+    """fh_unpack_shards: one launch for up to sixteen ranks (a node has eight), one launch per rank beyond; either way the inverse of every rank's pack -- here against numpy
+    with distributed.tile_ownership, on a frame whose edge tiles are partial"""
+    blk = int(os.environ.get("FH_PIXEL_BLOCK", D.PIXEL_BLOCK))
+    blk = blk if 0 < blk <= 64 else 1 << 16
+    w, h, tw, th = 200, 88, 32, 32
+    r = F.Renderer(0)
+    r.set_resolution(w, h)
+    r.set_tile_shard(0, 1, tw, th)
+    rng = np.random.default_rng(world)
+    want = rng.random((h * w, 4), dtype=np.float32)
+    own = [D.tile_ownership(w, h, k, world, tw, th, blk) for k in range(world)]
+    assert sum(o.size for o in own) == w * h
+    pad = max(max(o.size for o in own), 1)
+    bufs = []
+    for o in own:
+        b = F.renderer.DeviceBuffer(r, pad * 16)
+        b.upload(np.concatenate([want[o], np.full((pad - o.size, 4), -1.0, np.float32)]))
+        bufs.append(b)
+    dst = F.renderer.DeviceBuffer(r, w * h * 16)
+    dst.clear()
+    r.unpack_shards([b.ptr for b in bufs], 4, dst.ptr)
+    r.wait_for_completion()
+    assert np.array_equal(_bits(dst.download(np.float32, (h * w, 4))), _bits(want))
+    r.close()
+
+
 # ------------------------------------------------------------------ post-process
 def test_denoiser_slot_matches_checker_and_denoises(renderer, oracle):
     """Denoiser::denoise (denoiser.h:87-95) is NVIDIA's AI denoiser in the reference; the slot runs an edge-avoiding a-trous filter guided by the
