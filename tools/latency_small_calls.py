@@ -1,5 +1,5 @@
 """fh_render(n) + fh_sync for n = 1, 4, 16 at 1080p on configs[1..3] (the reference's own call pattern): median / min ms, and a CRC of the frame.
-    python tools/latency_small_calls.py [cfg ...]      env: any FH_* switch (FH_SUBPASS=1: no pixel sub-passes)"""
+    python tools/latency_small_calls.py [cfg ...]      env: any FH_* switch"""
 import os, sys, time, tempfile, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -30,5 +30,5 @@ for cfg in [int(a) for a in sys.argv[1:]] or [2, 3, 1]:
         r.render(cam, w["bg"], L, spp, w["depth"])
     r.wait_for_completion()
     crc = zlib.crc32(np.ascontiguousarray(L.download("beauty")).tobytes())
-    print(f"configs[{cfg}] FH_SUBPASS={os.environ.get('FH_SUBPASS', 'default')} FH_SUBPASS_MIN={os.environ.get('FH_SUBPASS_MIN', 'default')}: " + ", ".join(out) + f" (median / min), crc of 1+1+16 spp {crc:08x}", flush=True)
+    print(f"configs[{cfg}]: " + ", ".join(out) + f" (median / min), crc of 1+1+16 spp {crc:08x}", flush=True)
     r.close()
