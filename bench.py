@@ -898,7 +898,7 @@ def main():
                        "sky_pixel_sample_share": round(timed["sky_pixel_samples"] / max(timed["paths"], 1), 4),  # samples of pixels no ray of which can reach the scene bounds: rendered by k_sky_pixels, outside the passes (the path pools hold the other pixels only, so a pass takes more samples of them than spp_per_pass)
                        "path_pools": {"pools": n_pools, "bytes_per_path": slot_bytes, "gb": round(pool_bytes_timed / 1e9, 1), "paths": int(pool_paths_timed), "budget_gb": round(n_pools * slot_bytes * n_owned * pool_spp / 1e9, 1),
                                       "note": "gb = device memory the pools held after the timed region (fh_path_pool_allocated): a pool is allocated for the paths its passes start, pixels that can see the scene x samples per pass; budget_gb = what the caller allowed (fh_set_path_pool)"}, "triangles": int(sc["indices"].shape[0]), "parallelism": f"pixel-tile x{world}" if world > 1 else "single GPU",
-                       "gather": "RCCL gather of packed float4 beauty tiles to rank 0 + fh_unpack_shard, inside the timed region" if world > 1 else "none",
+                       "gather": (("RCCL" if backend == "nccl" else backend + " (functional test: staged through host memory)") + " gather of packed float4 beauty tiles to rank 0 + fh_unpack_shards (one launch), inside the timed region") if world > 1 else "none",
                        "post": "bloom + chromatic aberration + tone map on the whole frame, inside the timed region" if post else "none"},
             "step_ms": {"min": round(sm[0], 3), "median": round(sm[len(sm) // 2], 3), "max": round(sm[-1], 3)},
             "source_fingerprint": source_fingerprint(),  # of the device sources this library was built from (what profiles/*_traffic_config*.json are checked against)
