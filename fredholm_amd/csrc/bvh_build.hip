@@ -902,6 +902,7 @@ int bvh_build_device(fh_ctx* ctx)
   }
   ctx->refit_ok = false;
   ctx->bu_choice = 0; ctx->bu_toggle = 0; ctx->bu_cost[0] = ctx->bu_cost[1] = ctx->bu_items[0] = ctx->bu_items[1] = 0.0;  // a new tree: where its rays should start is measured again (render.hip)
+  ctx->survival_n = 0;  // ... and how long its paths live is not known yet (context.h: survival)
   if (ctx->d_bvh8_box) { (void)hipFree(ctx->d_bvh8_box); ctx->d_bvh8_box = nullptr; }
   ctx->bvh8_level_start.clear();
   if (ctx->d_bvh2_nodes) { (void)hipFree(ctx->d_bvh2_nodes); ctx->d_bvh2_nodes = nullptr; }

@@ -134,11 +134,19 @@ struct fh_ctx {
   uint32_t pool_target_default = 1u << 25, pool_target = 1u << 25;  // (pool_target: the default as capped by the free device memory whenever a pool is (re)allocated, or the caller's size)
   bool pool_target_by_caller = false;
   uint32_t tail_depth = 0;          // bounces run as wavefront kernels before k_tail finishes the survivors; 0 = adaptive
-  uint32_t auto_wave_depth = 2;     // adaptive choice, updated from the per-bounce survivor counts of earlier passes
+  uint32_t auto_wave_depth = 2;     // adaptive choice of the pass submitted last (kept for the debug print)
+  // the adaptive choice is made per pass from the SHARE of a pass's paths still alive at each depth, taken from the newest snapshot of an earlier pass's counters: a share is a
+  // property of the scene and the camera, not of the pass, so a call of another size (one final frame of 4096 spp after a session of 1-spp calls, or the other way round)
+  // picks its depth right from its first pass.  (Up to round 5 the DEPTH picked for the earlier pass was carried over: the first 16-spp passes after small calls handed
+  // millions of paths to the fused tail, 300 ms each on configs[3].)  survival_n = 0: nothing known yet (a new tree: bvh_build.hip); entries deeper than the newest
+  // snapshot's wavefront bounces are an earlier pass's.
+  double survival[66] = {};
+  uint32_t survival_n = 0;
   uint32_t* h_counters[3] = {nullptr, nullptr, nullptr};  // pinned snapshots of the per-bounce counters of a finished pass
   hipEvent_t ev_counters[3] = {nullptr, nullptr, nullptr};
   bool counters_in_flight[3] = {false, false, false};
   uint32_t counters_wave_depth[3] = {0, 0, 0};  // wave depth used by the pass the snapshot comes from
+  uint32_t counters_paths[3] = {0, 0, 0};       // ... and the paths it started
   int counters_bu[3] = {-1, -1, -1};            // ... and, while the scene is being probed, where its first-hit rays started (0: the root, 1: the node of their face; -1: not a probing pass)
   int bu_choice = 0;                            // 0: probing, 1: rays start at the root, 2: first-hit rays start at the node of the face they leave (render.hip; reset by every full BVH build)
   uint32_t bu_toggle = 0;

@@ -1386,7 +1386,7 @@ __device__ __attribute__((noinline)) bool tail_trace_lane(const SceneDev& sc, ui
   return any ? traverse_bvh8<true, false, true, false>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc)
              : traverse_bvh8<false, false, true, false>(sc.bvh8, o, d, tmax, h, a, b, nullptr, lds_stack, (int)sc.bvh8.depth, &sc);
 }
-struct TailRay { bool has = false; bool any = true; f3 o, d; float tmax = 0.0f; HitRec h; bool hit = false; };
+struct TailRay { bool has = false; bool any = true; f3 o = mk3(0.0f), d = mk3(0.0f, 0.0f, 1.0f); float tmax = 0.0f; HitRec h = HitRec{0.0f, 0.0f, 0.0f, 0xffffffffu}; bool hit = false; };  // (no indeterminate field: r6-13)
 
 template <uint32_t LOBES>
 __global__ void __launch_bounds__(kBlock, LOBES == L_ALL ? 1 : 2) k_tail(SceneDev sc, FrameDev fr, PoolDev pool, uint32_t first_depth, uint32_t coop_flush)
@@ -1395,6 +1395,7 @@ __global__ void __launch_bounds__(kBlock, LOBES == L_ALL ? 1 : 2) k_tail(SceneDe
   __shared__ __attribute__((aligned(16))) unsigned char lds_coop[(kBlock / 64) * kCoopLdsBytesPerWave];
   __shared__ float4 s_in[kBlock / 64][2][64];  // one round of packed rays of a wave: (origin, tmax), (direction, stops at its first hit)
   __shared__ float4 s_out[kBlock / 64][64];    // and their hits: t, u, v, face id bits
+  if (blockIdx.x * blockDim.x >= pool.counters[first_depth * kCounterStride + CNT_RAD]) return;  // (the grid is sized for the pass, the survivors are few: most blocks have nothing to do, and leave before the tables are staged)
   const CoopLds cl = coop_lds(lds_coop, threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const bool coop = sc.use_bvh8 && coop_flush != 0u;
@@ -2275,21 +2276,11 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       ctx->counters_in_flight[k] = false;
       const uint32_t wd = ctx->counters_wave_depth[k];
       const uint32_t* hc = ctx->h_counters[k];
-      uint32_t pick = 0;
-      for (uint32_t d = 1; d <= wd && !pick; ++d)
-        if (hc[d * kCounterStride + CNT_RAD] <= kTailPaths) pick = d;
-      if (!pick) {
-        // too many survivors even at the old switch depth: extrapolate with the survival ratio of the last bounce.  (Snapshots only
-        // arrive when the host happens to be behind the GPU -- after a synchronisation -- so the depth has to be right in one step.)
-        const double last = (double)hc[wd * kCounterStride + CNT_RAD], prev = wd ? (double)hc[(wd - 1u) * kCounterStride + CNT_RAD] : 0.0;
-        uint32_t more = 1;
-        if (last > 0.0 && prev > last) {
-          const double steps = ceil(log((double)kTailPaths / last) / log(last / prev));
-          more = steps < 1.0 ? 1u : (steps > 16.0 ? 16u : (uint32_t)steps);
-        }
-        pick = wd + more;
+      if (ctx->counters_paths[k]) {  // the share of the pass's paths alive at each depth it ran as a wavefront (context.h: survival)
+        const uint32_t n = wd < 65u ? wd : 65u;
+        for (uint32_t d = 0; d <= n; ++d) ctx->survival[d] = (double)hc[d * kCounterStride + CNT_RAD] / (double)ctx->counters_paths[k];
+        if (ctx->survival_n < n + 1u) ctx->survival_n = n + 1u;  // (a pass the tail took over early says nothing about the deeper shares: what an earlier pass of this scene measured stays)
       }
-      ctx->auto_wave_depth = pick;
       if (ctx->counters_bu[k] >= 0 && ctx->bu_choice == 0) {  // (a pass of the scene's probing phase: what its secondary launches cost, by the issue model's weights)
         double cost = 0.0, items = 0.0;
         for (uint32_t d = 0; d < wd; ++d) { cost += 510.0 * hc[d * kCounterStride + CNT_COST_NODE] + 175.0 * hc[d * kCounterStride + CNT_COST_TRI]; items += hc[d * kCounterStride + CNT_SEC]; }
@@ -2301,7 +2292,29 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
         }
       }
       ctx->counters_bu[k] = -1;
-      if (tun.debug_tail) { fprintf(stderr, "[tail] slot %d wd %u pick %u survivors:", k, wd, pick); for (uint32_t d = 0; d <= wd; ++d) fprintf(stderr, " %u", ctx->h_counters[k][d * kCounterStride + CNT_RAD]); fprintf(stderr, "\n"); }
+      if (tun.debug_tail) { fprintf(stderr, "[tail] slot %d wd %u paths %u survivors:", k, wd, ctx->counters_paths[k]); for (uint32_t d = 0; d <= wd; ++d) fprintf(stderr, " %u", ctx->h_counters[k][d * kCounterStride + CNT_RAD]); fprintf(stderr, "\n"); }
+    }
+    // the first depth at which THIS pass is expected to have at most kTailPaths survivors
+    {
+      uint32_t pick = 0;
+      if (!ctx->survival_n) pick = n_paths > (1u << 22) ? max_depth : 2u;  // (nothing known: a big pass runs without the tail -- a wavefront bounce of few paths costs it 0.5 ms, a tail of millions of paths seconds)
+      else {
+        const uint32_t known = ctx->survival_n - 1u;
+        for (uint32_t d = 1; d <= known && !pick; ++d)
+          if ((double)n_paths * ctx->survival[d] <= (double)kTailPaths) pick = d;
+        if (!pick) {
+          // too many survivors even at the last depth counted: extrapolate with the survival ratio of the last bounce.  (Snapshots only
+          // arrive when the host happens to be behind the GPU -- after a synchronisation -- so the depth has to be right in one step.)
+          const double last = (double)n_paths * ctx->survival[known], prev = known ? (double)n_paths * ctx->survival[known - 1u] : 0.0;
+          uint32_t more = 1;
+          if (last > 0.0 && prev > last) {
+            const double steps = ceil(log((double)kTailPaths / last) / log(last / prev));
+            more = steps < 1.0 ? 1u : (steps > 16.0 ? 16u : (uint32_t)steps);
+          }
+          pick = known + more;
+        }
+      }
+      ctx->auto_wave_depth = pick;
     }
     uint32_t wave_depth = ctx->tail_depth ? ctx->tail_depth : ctx->auto_wave_depth;
     if (env_tail_depth) wave_depth = env_tail_depth;
@@ -2422,6 +2435,7 @@ int render_submit(fh_ctx* ctx, const fh_camera* cam, const float* bg, const fh_r
       FH_HIP(hipEventRecord(ctx->ev_counters[slot], st));
       ctx->counters_in_flight[slot] = true;
       ctx->counters_wave_depth[slot] = wave_depth;
+      ctx->counters_paths[slot] = n_paths;
       ctx->counters_bu[slot] = pass_bu;
     }
   }

@@ -550,6 +550,38 @@ def test_reference_firsthit_bug_compat_mode(oracle, scene_name):
     r.close()
 
 
+def test_a_call_of_another_size_picks_its_own_depth_for_the_fused_tail(monkeypatch):
+    """The depth at which k_tail takes the survivors over is chosen per pass from the SHARE of paths alive at each depth in an earlier pass (context.h: survival), scaled to
+    the pass at hand.  Carrying the earlier pass's DEPTH over instead (up to round 5) made the first final-frame call after a session of 1-spp calls hand millions of paths
+    to the tail (configs[3]: 300 ms per pass of 93 M paths, +7 % on a 256-spp call), and the first 1-spp call after a big one run every bounce as a wavefront.
+    No reference counterpart: Renderer::render is one optixLaunch whatever n_samples (renderer.h:730-733)."""
+    for k in ("FH_TAIL_DEPTH", "FH_TAIL_PATHS"):
+        monkeypatch.delenv(k, raising=False)
+    cam = F.Camera(**scenes.CORNELL_CAMERA)
+    w = h = 1024
+    r = F.Renderer(0)
+    r.load_scene(scenes.cornell_box())
+    r.build_ias()
+    r.set_resolution(w, h)
+    L = F.RenderLayer(r, w, h)
+
+    def tails(spp):
+        r.reset_stats()
+        r.render(cam, (0, 0, 0), L, spp, 8)
+        r.wait_for_completion()
+        st = r.stats()
+        return int(st["n_tail_launches"]), int(st["n_passes"])
+    cold_big = tails(8)        # 8.4 M paths, nothing known about the scene: no tail
+    big = tails(8)
+    small = [tails(1) for _ in range(3)][-1]
+    big_after_small = tails(8)
+    small_after_big = tails(1)
+    r.close()
+    assert cold_big == (0, 1) and big == (0, 1), (cold_big, big)          # a closed box: ~8 % of 8.4 M paths reach depth 7, far above what the tail takes
+    assert small[0] == 1, small                                           # 1 M paths: the tail finishes the last bounces
+    assert big_after_small == big and small_after_big == small, (big_after_small, small_after_big)
+
+
 def test_large_one_pass_calls_of_the_bug_compat_and_measuring_modes_are_not_split():
     """A call of more than 50 M camera paths that fits ONE pass is cut into three that overlap -- unless its passes run one after the other anyway: FH_FLAG_REFERENCE_FIRSTHIT
     (per-pixel state carried through the launch) and FH_FLAG_SERIAL_PASSES, where a split is pure overhead.  1080p x 26 samples of the Cornell box = 54 M
