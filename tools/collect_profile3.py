@@ -40,10 +40,11 @@ pmc_cfg = json.loads(pmc_line)["config"]
 pmc_pass_spp = pmc_cfg["spp_per_pass"]  # the nominal launch size the counters belong to: bench.py quotes them only for runs with the same samples per pass
 # ... and the pass the library really submitted in the counter run (a call that splits off its sky pixels cuts itself differently): bench.py flags a run whose passes differ
 pmc_submitted = round(pmc_cfg["spp_per_step"] / max(pmc_cfg.get("passes_per_step", 0) or 1, 1e-9), 2) if pmc_cfg.get("passes_per_step") else None
+run_spp = pmc_cfg["spp_per_step"]  # samples per pixel of ONE render of the counter run (round 6, r6-15: two passes of `pspp`)
 frame = sum((2 * x.get("FETCH_SIZE", (0, 0))[1] + x.get("WRITE_SIZE", (0, 0))[1]) * 1024 for x in ks)
 d = {"kernel": k["name"], "config": cfg, "spp_per_pass": pmc_pass_spp, "submitted_spp_per_pass": pmc_submitted,
      "source": f"profiles/{tag}_pmc_summary.txt (tools/profile_round3.sh {tag} {cfg} {pspp}: separate rocprofv3 --pmc passes -- SQ group a, SQ group b, FETCH_SIZE, WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- of "
-               f"bench.py --config {cfg} --steps 1 --warmup 1 --spp {pspp} --no-cpu-baseline --no-extras; mean over the {k['dispatches']} dispatches of the kernel)",
+               f"bench.py --config {cfg} --steps 1 --warmup 1 --spp {run_spp} --no-cpu-baseline --no-extras, FH_PIPELINE=0, FH_TAIL_DEPTH pinned to the steady depth: calls of {pmc_cfg.get('passes_per_step')} passes; mean over the {k['dispatches']} dispatches of the kernel)",
      "FETCH_SIZE_KB_per_launch": g("FETCH_SIZE"), "WRITE_SIZE_KB_per_launch": g("WRITE_SIZE"),
      "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; KB = 1024 B.  The guide calibrates the doubling on wide streaming reads only; for scattered 16-B loads it is an upper bound.",
      "traffic_bytes_per_launch": int((2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024),
@@ -53,8 +54,8 @@ d = {"kernel": k["name"], "config": cfg, "spp_per_pass": pmc_pass_spp, "submitte
      "wait_any_frac_of_wave_cycles": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4), "waves_per_launch": int(g("SQ_WAVES")),
      "grbm_gui_active_per_launch": g("GRBM_GUI_ACTIVE"),
      "vl1d": vl1d,
-     "frame_traffic_bytes_per_spp": frame / (renders * pspp),
-     "frame_note": f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every kernel of the run / ({renders} renders x {pspp} spp): fabric-side bytes one sample per pixel of the whole frame costs",
+     "frame_traffic_bytes_per_spp": frame / (renders * run_spp),
+     "frame_note": f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every kernel of the run / ({renders} renders x {run_spp} spp): fabric-side bytes one sample per pixel of the whole frame costs",
      "note": "fabric-side bytes (L2 misses; Infinity-Cache hits are counted)."}
 # ---- round 6: the cooperative triangle test's LDS bank conflicts of the dominant kernel, and the shade kernels' own block (bench.py: `shade` record) -- every un-instrumented k_shade
 # instantiation of the run summed; the counter run renders `renders` times and the shade kernels are the same in all of them
@@ -72,7 +73,7 @@ if sh:
                   "tcc_hit_rate": round(tot("TCC_HIT_sum") / max(tot("TCC_HIT_sum") + tot("TCC_MISS_sum"), 1), 4),
                   "traffic_bytes_total": int((2 * tot("FETCH_SIZE") + tot("WRITE_SIZE")) * 1024),
                   "lds_bank_conflict_frac": round(tot("SQ_LDS_BANK_CONFLICT") / max(tot("SQ_LDS_IDX_ACTIVE"), 1), 4) if tot("SQ_LDS_IDX_ACTIVE") else None,
-                  "shaded_hits_in_counter_run": int(per_sample * res * pspp * renders) if per_sample else None,
+                  "shaded_hits_in_counter_run": int(per_sample * res * run_spp * renders) if per_sample else None,
                   "note": f"summed over the {renders} renders of the counter run (timed step, warm-up, serial step, two counting replays: the shade kernels are the same in all of them)"}
 # what the counters belong to (bench.py: roofline.counters_stale): the device sources and the kernel's registers / LDS / scratch of the run that was profiled, and the commit it was collected at
 import subprocess
