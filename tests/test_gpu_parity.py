@@ -586,7 +586,8 @@ def test_large_one_pass_calls_of_the_bug_compat_and_measuring_modes_are_not_spli
     """A call of more than 50 M camera paths that fits ONE pass is cut into three that overlap -- unless its passes run one after the other anyway: FH_FLAG_REFERENCE_FIRSTHIT
     (per-pixel state carried through the launch) and FH_FLAG_SERIAL_PASSES, where a split is pure overhead.  1080p x 26 samples of the Cornell box = 54 M
     paths: the two passes the default pool needs in either mode, three by default; and the bug-compat frame does not depend on how the call is cut (a pool of two samples per pixel: thirteen passes)."""
-    monkeypatch.delenv("FH_PIPELINE", raising=False)  # (the developer switch for the number of passes in flight: with one or two there is nothing to cut a call in three for)
+    for k in ("FH_PIPELINE", "FH_SKY_SPLIT_MIN_LOG2"):  # (developer switches: with one or two passes in flight there is nothing to cut a call in three for; a sky split forced on
+        monkeypatch.delenv(k, raising=False)            # small frames takes the pixels beside the box out of the passes, and the call under 50 M paths)
     w, h, k, depth = 1920, 1080, 26, 3
     cam = F.Camera(**scenes.CORNELL_CAMERA)
     frames = {}
